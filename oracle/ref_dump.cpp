@@ -1,0 +1,221 @@
+// oracle/ref_dump.cpp -- TEST INFRASTRUCTURE, not product code.
+//
+// Driver that is linked against the *reference's own objects* (oracle/ref.mk builds them
+// from /root/reference/src where they lie) and dumps the state the parity tests are pinned
+// to.  It calls only public entry points of the reference, in the order its own main()
+// (reference src/Common/gandalf.cpp:40-190) and SphSimulation::MainLoop
+// (src/Hydrodynamics/SphSimulation.cpp:574-880) call them; it contains no algorithmic
+// code of its own.
+//
+//   ref_dump passes <params.dat> <out_prefix>
+//       SetupSimulation(), dump "setup"; then one extra density pass and one extra force
+//       pass in MainLoop order (BuildTree -> ghosts -> UpdateAllSphProperties ->
+//       ZeroAccelerations -> UpdateAllSph(Hydro)Forces), dumping after each, so that each
+//       pass has an (input state, output state) pair.
+//   ref_dump steps  <params.dat> <out_prefix> <nsteps>
+//       SetupSimulation(), dump "setup"; nsteps x MainLoop(); dump "final".
+//   ref_dump time   <params.dat> <nsteps> [warmup]
+//       SetupSimulation(); warmup x MainLoop(); time nsteps x MainLoop(); prints one JSON line
+//       (the CPU baseline of bench.py, kind "reference").
+//
+// Dump format ("GDMP1"): records of
+//   u32 name_len, name bytes, u8 dtype ('d' f64, 'i' i32), u32 ndim, u64 dims[ndim], raw data.
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <iostream>
+#include <fstream>
+#include <sys/time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "Exception.h"
+#include "Parameters.h"
+#include "Simulation.h"
+#include "Sph.h"
+#include "Nbody.h"
+#include "Particle.h"
+#include "KDTree.h"
+#include "NeighbourSearch.h"
+#include "SphNeighbourSearch.h"
+
+using namespace std;
+
+static double wall()
+{
+  struct timeval tv;
+  gettimeofday(&tv, 0);
+  return tv.tv_sec + 1e-6*tv.tv_usec;
+}
+
+struct Dump {
+  FILE *f;
+  explicit Dump(const string &path) { f = fopen(path.c_str(), "wb"); if (!f) { perror(path.c_str()); exit(2);} fwrite("GDMP1\0\0\0", 1, 8, f); }
+  ~Dump() { fclose(f); }
+  void head(const char *name, char dt, const vector<uint64_t> &dims) {
+    uint32_t n = strlen(name); fwrite(&n, 4, 1, f); fwrite(name, 1, n, f);
+    fwrite(&dt, 1, 1, f);
+    uint32_t nd = dims.size(); fwrite(&nd, 4, 1, f);
+    for (size_t i = 0; i < dims.size(); i++) fwrite(&dims[i], 8, 1, f);
+  }
+  void d(const char *name, const vector<double> &v, uint64_t cols = 0) {
+    vector<uint64_t> dims;
+    if (cols) { dims.push_back(v.size()/cols); dims.push_back(cols); } else dims.push_back(v.size());
+    head(name, 'd', dims); fwrite(v.data(), 8, v.size(), f);
+  }
+  void i(const char *name, const vector<int> &v, uint64_t cols = 0) {
+    vector<uint64_t> dims;
+    if (cols) { dims.push_back(v.size()/cols); dims.push_back(cols); } else dims.push_back(v.size());
+    head(name, 'i', dims); fwrite(v.data(), 4, v.size(), f);
+  }
+};
+
+#define PSCAL(field)  { vector<double> v(N); for (int i=0;i<N;i++) v[i]=p[i].field; out.d(#field, v); }
+#define PINT(field)   { vector<int> v(N); for (int i=0;i<N;i++) v[i]=p[i].field; out.i(#field, v); }
+#define PVEC(field)   { vector<double> v((size_t)N*ndim); for (int i=0;i<N;i++) for (int k=0;k<ndim;k++) v[(size_t)i*ndim+k]=p[i].field[k]; out.d(#field, v, ndim); }
+
+template <int ndim>
+static void dump_particles(Dump &out, Simulation<ndim> *sim)
+{
+  Sph<ndim> *sph = static_cast<Sph<ndim>*>(sim->hydro);
+  GradhSphParticle<ndim> *p = static_cast<GradhSphParticle<ndim>*>(sph->GetSphParticleArray());
+  const int N = sph->Nhydro;
+  { vector<int> v(1, N); out.i("Nhydro", v); }
+  { vector<int> v(1, sph->Ntot); out.i("Ntot", v); }
+  { vector<int> v(1, ndim); out.i("ndim", v); }
+  { vector<int> v(N); for (int i=0;i<N;i++) v[i]=(int)p[i].flags.get(); out.i("flags", v); }
+  PINT(ptype) PINT(iorig) PINT(levelneib) PINT(nstep) PINT(nlast) PINT(level)
+  PVEC(r) PVEC(v) PVEC(a) PVEC(atree) PVEC(r0) PVEC(v0) PVEC(a0)
+  PSCAL(m) PSCAL(h) PSCAL(hrangesqd) PSCAL(hfactor) PSCAL(sound) PSCAL(rho) PSCAL(pressure)
+  PSCAL(u) PSCAL(u0) PSCAL(dudt0) PSCAL(dudt) PSCAL(gpot) PSCAL(gpot_hydro)
+  PSCAL(dt) PSCAL(dt_next) PSCAL(tlast) PSCAL(div_v) PSCAL(alpha) PSCAL(dalphadt)
+  PSCAL(invomega) PSCAL(zeta)
+  { vector<double> v; v.push_back(sim->t); v.push_back(sim->timestep); out.d("t_timestep", v); }
+  { vector<int> v; v.push_back(sim->n); v.push_back(sim->Nsteps); v.push_back(sim->nresync); out.i("n_Nsteps_nresync", v); }
+}
+
+#define CSCAL(field)  { vector<double> v(Nc); for (int c=0;c<Nc;c++) v[c]=cd[c].field; out.d("cell_" #field, v); }
+#define CINT(field)   { vector<int> v(Nc); for (int c=0;c<Nc;c++) v[c]=cd[c].field; out.i("cell_" #field, v); }
+#define CVEC(name,expr) { vector<double> v((size_t)Nc*ndim); for (int c=0;c<Nc;c++) for (int k=0;k<ndim;k++) v[(size_t)c*ndim+k]=cd[c].expr[k]; out.d("cell_" name, v, ndim); }
+
+template <int ndim>
+static void dump_tree(Dump &out, Simulation<ndim> *sim)
+{
+  typedef KDTree<ndim, GradhSphParticle, KDTreeCell> TreeT;
+  TreeT *tree = static_cast<TreeT*>(sim->sphneib->GetTree());
+  KDTreeCell<ndim> *cd = tree->celldata;
+  const int Nc = tree->Ncell;
+  { vector<int> v; v.push_back(tree->Ncell); v.push_back(tree->ltot); v.push_back(tree->gtot); v.push_back(tree->Ntot); v.push_back(tree->Nleafmax); out.i("tree_Ncell_ltot_gtot_Ntot_Nleafmax", v); }
+  CINT(cnext) CINT(copen) CINT(level) CINT(ifirst) CINT(ilast) CINT(N) CINT(Nactive)
+  CSCAL(cdistsqd) CSCAL(m) CSCAL(rmax) CSCAL(hmax) CSCAL(maxsound)
+  CVEC("bbmin", bb.min) CVEC("bbmax", bb.max) CVEC("hboxmin", hbox.min) CVEC("hboxmax", hbox.max)
+  CVEC("rcell", rcell) CVEC("r", r) CVEC("v", v)
+  { vector<double> v((size_t)Nc*5); for (int c=0;c<Nc;c++) for (int k=0;k<5;k++) v[(size_t)c*5+k]=cd[c].q[k]; out.d("cell_q", v, 5); }
+  const int Ntot = tree->Ntot;
+  { vector<int> v(tree->inext, tree->inext + Ntot); out.i("inext", v); }
+}
+
+// gather neighbour ids of every particle inside kernrange*h_i, through the reference's own
+// point search (NeighbourSearch::GetGatherNeighbourList, HydroTree.cpp) -- real particles only.
+template <int ndim>
+static void dump_gather_lists(Dump &out, Simulation<ndim> *sim)
+{
+  Sph<ndim> *sph = static_cast<Sph<ndim>*>(sim->hydro);
+  GradhSphParticle<ndim> *p = static_cast<GradhSphParticle<ndim>*>(sph->GetSphParticleArray());
+  const int N = sph->Nhydro;
+  vector<int> offs(N+1, 0), ids;
+  int cap = 4096;
+  vector<int> buf(cap);
+  for (int i = 0; i < N; i++) {
+    FLOAT rp[ndim];
+    for (int k = 0; k < ndim; k++) rp[k] = p[i].r[k];
+    int nn;
+    while ((nn = sim->sphneib->GetGatherNeighbourList(rp, sph->kernp->kernrange*p[i].h, p, N, cap, buf.data())) < 0) {
+      cap *= 2; buf.resize(cap);
+    }
+    ids.insert(ids.end(), buf.begin(), buf.begin() + nn);
+    offs[i+1] = (int) ids.size();
+  }
+  out.i("gather_offsets", offs);
+  out.i("gather_ids", ids);
+}
+
+template <int ndim>
+static void set_all_active(Simulation<ndim> *sim)
+{
+  Sph<ndim> *sph = static_cast<Sph<ndim>*>(sim->hydro);
+  for (int i = 0; i < sph->Nhydro; i++) sph->GetSphParticlePointer(i).flags.set(active);
+}
+
+template <int ndim>
+static int run(const string &mode, Parameters *params, SimulationBase *simbase, int argc, char **argv)
+{
+  Simulation<ndim> *sim = static_cast<Simulation<ndim>*>(simbase);
+  Sph<ndim> *sph;
+  sim->SetupSimulation();
+  sph = static_cast<Sph<ndim>*>(sim->hydro);
+
+  if (mode == "time") {
+    const int nsteps = atoi(argv[3]);
+    const int warm   = argc > 4 ? atoi(argv[4]) : 0;
+    for (int s = 0; s < warm; s++) sim->MainLoop();
+    const double t0 = wall();
+    for (int s = 0; s < nsteps; s++) sim->MainLoop();
+    const double dt = wall() - t0;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    printf("{\"N\": %d, \"steps\": %d, \"warmup\": %d, \"seconds\": %.6f, \"particle_steps_per_s\": %.6e, \"threads\": %d}\n",
+           sph->Nhydro, nsteps, warm, dt, (double) sph->Nhydro*nsteps/dt, nthreads);
+    return 0;
+  }
+
+  const string prefix = argv[3];
+  { Dump out(prefix + "_setup.gdmp"); dump_particles<ndim>(out, sim); dump_tree<ndim>(out, sim); dump_gather_lists<ndim>(out, sim); }
+
+  if (mode == "passes") {
+    // MainLoop order (SphSimulation.cpp:634-709) at fixed positions, all particles active
+    set_all_active<ndim>(sim);
+    sim->sphneib->BuildTree(true, 0, sim->ntreebuildstep, sim->ntreestockstep, sim->timestep, sph);
+    sim->sphneib->SearchBoundaryGhostParticles((FLOAT) 0.0, sim->simbox, sph);
+    sim->sphneib->BuildGhostTree(true, 0, sim->ntreebuildstep, sim->ntreestockstep, sim->timestep, sph);
+    { Dump out(prefix + "_tree.gdmp"); dump_tree<ndim>(out, sim); }
+    sim->sphneib->UpdateAllSphProperties(sph, sim->nbody);
+    { Dump out(prefix + "_density.gdmp"); dump_particles<ndim>(out, sim); dump_tree<ndim>(out, sim); dump_gather_lists<ndim>(out, sim); }
+    sph->ZeroAccelerations();
+    if (sph->self_gravity == 1) sim->sphneib->UpdateAllSphForces(sph, sim->nbody, sim->simbox, sim->ewald);
+    else sim->sphneib->UpdateAllSphHydroForces(sph, sim->nbody, sim->simbox);
+    { Dump out(prefix + "_forces.gdmp"); dump_particles<ndim>(out, sim); }
+  }
+  else if (mode == "steps") {
+    const int nsteps = atoi(argv[4]);
+    for (int s = 0; s < nsteps; s++) sim->MainLoop();
+    { Dump out(prefix + "_final.gdmp"); dump_particles<ndim>(out, sim); }
+  }
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 4) {
+    fprintf(stderr, "usage: ref_dump passes|steps|time <params.dat> ...\n");
+    return 1;
+  }
+  const string mode = argv[1];
+  Parameters *params = new Parameters();
+  ExceptionHandler::makeExceptionHandler(cplusplus);
+  params->ReadParamsFile(string(argv[2]));
+  SimulationBase *sim = SimulationBase::SimulationFactory(params->intparams["ndim"],
+                                                          params->stringparams["sim"], params);
+  sim->restart = false;
+  const int ndim = params->intparams["ndim"];
+  if (ndim == 1) return run<1>(mode, params, sim, argc, argv);
+  if (ndim == 2) return run<2>(mode, params, sim, argc, argv);
+  return run<3>(mode, params, sim, argc, argv);
+}

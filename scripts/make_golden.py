@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled reference (oracle/_ref/ref_dump).
+
+Run in the build container only (needs /root/reference to have been compiled by
+`make -f oracle/ref.mk`).  The fixtures are DATA: inputs and the reference's outputs for them.
+
+    python scripts/make_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.gdmp import read_gdmp  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+PARTICLE_IN = ["r", "v", "m", "h", "u", "iorig", "ptype"]
+DENS_OUT = ["h", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound", "pressure", "u", "div_v"]
+FORCE_OUT = ["a", "atree", "gpot", "gpot_hydro", "dudt", "div_v", "dalphadt", "levelneib"]
+STEP_OUT = ["r", "v", "a", "h", "rho", "u", "dudt", "gpot", "dt", "iorig", "r0", "v0", "a0", "u0", "dudt0",
+            "t_timestep", "n_Nsteps_nresync"]
+TREE = ["tree_Ncell_ltot_gtot_Ntot_Nleafmax", "cell_cnext", "cell_copen", "cell_level", "cell_ifirst",
+        "cell_ilast", "cell_N", "cell_Nactive", "cell_cdistsqd", "cell_m", "cell_rmax", "cell_hmax",
+        "cell_bbmin", "cell_bbmax", "cell_hboxmin", "cell_hboxmax", "cell_rcell", "cell_r", "cell_v",
+        "inext"]
+
+
+def run(args, cwd):
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    subprocess.run([REF] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, env=env)
+
+
+def passes(name, nsteps=3):
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["passes", par, os.path.join(tmp, "p")], tmp)
+        setup = read_gdmp(os.path.join(tmp, "p_setup.gdmp"))
+        tree = read_gdmp(os.path.join(tmp, "p_tree.gdmp"))
+        dens = read_gdmp(os.path.join(tmp, "p_density.gdmp"))
+        forc = read_gdmp(os.path.join(tmp, "p_forces.gdmp"))
+        out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"]}
+        for k in PARTICLE_IN:
+            out["in_" + k] = setup[k]
+        # state the reference held when setup finished (initial step quantities)
+        for k in ["a", "atree", "gpot", "dudt", "div_v", "rho", "invomega", "zeta", "dt", "t_timestep"]:
+            out["setup_" + k] = setup[k]
+        for k in TREE:
+            out["tree_" + k] = tree[k]        # tree after BuildTree on the setup state
+        for k in DENS_OUT:
+            out["dens_" + k] = dens[k]
+        out["dens_cell_hmax"] = dens["cell_hmax"]
+        out["dens_cell_hboxmin"] = dens["cell_hboxmin"]
+        out["dens_cell_hboxmax"] = dens["cell_hboxmax"]
+        out["dens_gather_offsets"] = dens["gather_offsets"]
+        out["dens_gather_ids"] = dens["gather_ids"]
+        for k in FORCE_OUT:
+            out["force_" + k] = forc[k]
+        np.savez_compressed(os.path.join(GOLD, name + "_passes.npz"), **out)
+        print(name, "passes ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["steps", par, os.path.join(tmp, "s"), str(nsteps)], tmp)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"], "nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in STEP_OUT:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        out["setup_m"] = setup["m"]
+        np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
+        print(name, "steps ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    for cfg in (sys.argv[1:] or ["box3d_4k", "plummer_4k"]):
+        passes(cfg)
