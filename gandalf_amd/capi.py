@@ -1,0 +1,314 @@
+"""ctypes binding of include/gandalf_hip.h (one-to-one; no logic of its own)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgandalf_hip.so")
+
+GH_T_NAMES = ["BUILD_TREE", "SPH_PROPERTIES", "SPH_FORCES", "KDK"]
+
+FIELDS = {name: i for i, name in enumerate(
+    ["r", "v", "a", "atree", "r0", "v0", "a0",
+     "m", "h", "u", "u0", "dudt", "dudt0", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound",
+     "pressure", "div_v", "gpot", "gpot_hydro", "alpha", "dalphadt", "dt", "dt_next", "tlast"])}
+VECTOR_FIELDS = {"r", "v", "a", "atree", "r0", "v0", "a0"}
+
+
+class GhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gandalf_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int32), ("kernel", C.c_int32), ("gas_eos", C.c_int32), ("avisc", C.c_int32),
+        ("acond", C.c_int32), ("self_gravity", C.c_int32), ("hydro_forces", C.c_int32),
+        ("multipole", C.c_int32), ("gravity_mac", C.c_int32), ("Nleafmax", C.c_int32),
+        ("energy_integration", C.c_int32), ("device", C.c_int32),
+        ("boundary_lhs", C.c_int32 * 3), ("boundary_rhs", C.c_int32 * 3),
+        ("boxmin", C.c_double * 3), ("boxmax", C.c_double * 3),
+        ("h_fac", C.c_double), ("h_converge", C.c_double), ("alpha_visc", C.c_double),
+        ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("temp0", C.c_double),
+        ("mu_bar", C.c_double), ("rho_bary", C.c_double), ("thetamaxsqd", C.c_double),
+        ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_particles", C.c_int64), ("n_iterations", C.c_int64), ("n_candidates", C.c_int64),
+                ("n_direct", C.c_int64), ("n_cells", C.c_int64), ("n_retries", C.c_int64),
+                ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+_PL = C.POINTER(C.c_int64)
+_CTX = C.c_void_p
+
+# every symbol include/gandalf_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "gh_create": (C.c_int, [C.POINTER(Config), C.POINTER(_CTX)]),
+    "gh_destroy": (None, [_CTX]),
+    "gh_last_error": (C.c_char_p, [_CTX]),
+    "gh_upload_particles": (C.c_int, [_CTX, C.c_int64, _PD, _PD, _PD, _PD, _PD]),
+    "gh_upload_field": (C.c_int, [_CTX, C.c_int, _PD]),
+    "gh_download": (C.c_int, [_CTX, C.c_int, _PD]),
+    "gh_num_particles": (C.c_int64, [_CTX]),
+    "gh_build_tree": (C.c_int, [_CTX]),
+    "gh_tree_size": (C.c_int, [_CTX, _PI, _PI, _PI]),
+    "gh_export_tree": (C.c_int, [_CTX, _PI, _PI, _PI, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PI]),
+    "gh_update_density": (C.c_int, [_CTX, C.POINTER(Stats)]),
+    "gh_zero_accelerations": (C.c_int, [_CTX]),
+    "gh_update_hydro_forces": (C.c_int, [_CTX, C.POINTER(Stats)]),
+    "gh_update_all_forces": (C.c_int, [_CTX, C.POINTER(Stats)]),
+    "gh_kdk_advance": (C.c_int, [_CTX, C.c_int, C.c_double, C.c_double]),
+    "gh_compute_global_timestep": (C.c_int, [_CTX, _PD]),
+    "gh_kdk_end": (C.c_int, [_CTX, C.c_int, C.c_double, C.c_double]),
+    "gh_setup": (C.c_int, [_CTX, C.c_int, _PD]),
+    "gh_set_time": (C.c_int, [_CTX, C.c_double, C.c_double]),
+    "gh_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
+    "gh_gather_neighbours": (C.c_int, [_CTX, C.c_int64, _PL, _PI]),
+    "gh_get_timers": (C.c_int, [_CTX, _PD, C.POINTER(Stats), C.POINTER(Stats)]),
+    "gh_reset_timers": (C.c_int, [_CTX]),
+    "gh_set_shard": (C.c_int, [_CTX, C.c_int, C.c_int]),
+    "gh_shard_range": (C.c_int, [_CTX, C.c_int, _PL, _PL]),
+    "gh_field_dev": (C.c_void_p, [_CTX, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libgandalf_hip.so and bind every declared symbol.  Raises if it is missing: there is no
+    CPU fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError("%s not built (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_PD) if a is not None else None
+
+
+_ENUMS = {
+    "boundary": {"open": 0, "periodic": 1},
+    "kernel": {"m4": 0, "quintic": 1},
+    "gas_eos": {"energy_eqn": 0, "isothermal": 1, "barotropic": 2},
+    "avisc": {"none": 0, "mon97": 1},
+    "acond": {"none": 0, "wadsley2008": 1, "price2008": 2},
+    "multipole": {"monopole": 0, "quadrupole": 1},
+    "gravity_mac": {"geometric": 0},
+}
+
+
+def config_from_params(p, device=0):
+    """Build a gh_config from a dict that uses the reference's parameter-file keys."""
+    c = Config()
+    nd = int(p.get("ndim", 3))
+    c.ndim = nd
+    c.kernel = _ENUMS["kernel"][p.get("kernel", "m4")]
+    if int(p.get("tabulated_kernel", 0)) != 0:
+        raise ValueError("tabulated_kernel = 1 is not built (piecewise-constant tables); set tabulated_kernel = 0")
+    c.gas_eos = _ENUMS["gas_eos"][p.get("gas_eos", "energy_eqn")]
+    c.avisc = _ENUMS["avisc"][p.get("avisc", "mon97")]
+    c.acond = _ENUMS["acond"][p.get("acond", "none")]
+    c.self_gravity = int(p.get("self_gravity", 0))
+    c.hydro_forces = int(p.get("hydro_forces", 1))
+    c.multipole = _ENUMS["multipole"][p.get("multipole", "quadrupole")]
+    c.gravity_mac = _ENUMS["gravity_mac"][p.get("gravity_mac", "geometric")]
+    c.Nleafmax = int(p.get("Nleafmax", 6))
+    c.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
+    c.device = device
+    for k in range(3):
+        c.boundary_lhs[k] = _ENUMS["boundary"][p.get("boundary_lhs[%d]" % k, "open")]
+        c.boundary_rhs[k] = _ENUMS["boundary"][p.get("boundary_rhs[%d]" % k, "open")]
+        c.boxmin[k] = float(p.get("boxmin[%d]" % k, 0.0))
+        c.boxmax[k] = float(p.get("boxmax[%d]" % k, 0.0))
+    c.h_fac = float(p.get("h_fac", 1.2))
+    c.h_converge = float(p.get("h_converge", 0.01))
+    c.alpha_visc = float(p.get("alpha_visc", 1.0))
+    c.beta_visc = float(p.get("beta_visc", 2.0))
+    c.gamma_eos = float(p.get("gamma_eos", 1.66666666666666))
+    c.temp0 = float(p.get("temp0", 1.0))
+    c.mu_bar = float(p.get("mu_bar", 1.0))
+    c.rho_bary = float(p.get("rho_bary", 1.0e-14))
+    c.thetamaxsqd = float(p.get("thetamaxsqd", 0.1))
+    c.courant_mult = float(p.get("courant_mult", 0.15))
+    c.accel_mult = float(p.get("accel_mult", 0.3))
+    c.energy_mult = float(p.get("energy_mult", 0.3))
+    return c
+
+
+class GandalfHip:
+    """One device context (= one GPU).  Methods map one-to-one onto the C ABI."""
+
+    def __init__(self, params, device=0):
+        self.lib = load_library()
+        self.cfg = config_from_params(params, device) if not isinstance(params, Config) else params
+        self.ndim = self.cfg.ndim
+        self.ctx = _CTX()
+        rc = self.lib.gh_create(C.byref(self.cfg), C.byref(self.ctx))
+        if rc:
+            msg = self.lib.gh_last_error(self.ctx).decode() if self.ctx else "gh_create failed"
+            if self.ctx:
+                self.lib.gh_destroy(self.ctx)
+                self.ctx = None
+            raise GhError(rc, msg)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gh_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise GhError(rc, self.lib.gh_last_error(self.ctx).decode())
+
+    @property
+    def N(self):
+        return int(self.lib.gh_num_particles(self.ctx))
+
+    def upload(self, r, m, h, v=None, u=None):
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1, self.ndim)
+        n = r.shape[0]
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        v = None if v is None else np.ascontiguousarray(v, dtype=np.float64).reshape(n, self.ndim)
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        assert m.shape == (n,) and h.shape == (n,)
+        self._chk(self.lib.gh_upload_particles(self.ctx, n, _dp(r), _dp(v), _dp(m), _dp(h), _dp(u)))
+
+    def upload_field(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._chk(self.lib.gh_upload_field(self.ctx, FIELDS[name], _dp(arr)))
+
+    def download(self, name):
+        n = self.N
+        shape = (n, self.ndim) if name in VECTOR_FIELDS else (n,)
+        out = np.empty(shape, dtype=np.float64)
+        self._chk(self.lib.gh_download(self.ctx, FIELDS[name], _dp(out)))
+        return out
+
+    def build_tree(self):
+        self._chk(self.lib.gh_build_tree(self.ctx))
+
+    def tree_size(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.gh_tree_size(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def export_tree(self):
+        ncell, ltot, gtot = self.tree_size()
+        nd, n = self.ndim, self.N
+        t = {"Ncell": ncell, "ltot": ltot, "gtot": gtot}
+        for k in ("level", "first", "N"):
+            t[k] = np.zeros(ncell, dtype=np.int32)
+        for k in ("bbmin", "bbmax", "hboxmin", "hboxmax", "rcell", "com"):
+            t[k] = np.zeros((ncell, nd))
+        for k in ("m", "rmax", "hmax", "cdistsqd"):
+            t[k] = np.zeros(ncell)
+        t["order"] = np.zeros(n, dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(_PI)  # noqa: E731
+        self._chk(self.lib.gh_export_tree(self.ctx, ip(t["level"]), ip(t["first"]), ip(t["N"]), _dp(t["bbmin"]),
+                                          _dp(t["bbmax"]), _dp(t["hboxmin"]), _dp(t["hboxmax"]), _dp(t["rcell"]),
+                                          _dp(t["com"]), _dp(t["m"]), _dp(t["rmax"]), _dp(t["hmax"]),
+                                          _dp(t["cdistsqd"]), ip(t["order"])))
+        return t
+
+    def update_density(self, stats=False):
+        st = Stats()
+        self._chk(self.lib.gh_update_density(self.ctx, C.byref(st) if stats else None))
+        return st.as_dict() if stats else None
+
+    def zero_accelerations(self):
+        self._chk(self.lib.gh_zero_accelerations(self.ctx))
+
+    def update_hydro_forces(self, stats=False):
+        st = Stats()
+        self._chk(self.lib.gh_update_hydro_forces(self.ctx, C.byref(st) if stats else None))
+        return st.as_dict() if stats else None
+
+    def update_all_forces(self, stats=False):
+        st = Stats()
+        self._chk(self.lib.gh_update_all_forces(self.ctx, C.byref(st) if stats else None))
+        return st.as_dict() if stats else None
+
+    def update_forces(self, stats=False):
+        return self.update_all_forces(stats) if self.cfg.self_gravity else self.update_hydro_forces(stats)
+
+    def kdk_advance(self, n, t, timestep):
+        self._chk(self.lib.gh_kdk_advance(self.ctx, n, t, timestep))
+
+    def compute_global_timestep(self):
+        dt = C.c_double()
+        self._chk(self.lib.gh_compute_global_timestep(self.ctx, C.byref(dt)))
+        return dt.value
+
+    def kdk_end(self, n, t, timestep):
+        self._chk(self.lib.gh_kdk_end(self.ctx, n, t, timestep))
+
+    def setup(self, initial_h_provided=True):
+        dt = C.c_double()
+        self._chk(self.lib.gh_setup(self.ctx, 1 if initial_h_provided else 0, C.byref(dt)))
+        return dt.value
+
+    def set_time(self, t, timestep):
+        self._chk(self.lib.gh_set_time(self.ctx, t, timestep))
+
+    def step(self, nsteps=1):
+        t, dt = C.c_double(), C.c_double()
+        self._chk(self.lib.gh_step(self.ctx, nsteps, C.byref(t), C.byref(dt)))
+        return t.value, dt.value
+
+    def gather_neighbours(self):
+        n = self.N
+        offs = np.zeros(n + 1, dtype=np.int64)
+        cap = 128 * n
+        ids = np.zeros(cap, dtype=np.int32)
+        rc = self.lib.gh_gather_neighbours(self.ctx, cap, offs.ctypes.data_as(_PL), ids.ctypes.data_as(_PI))
+        if rc == 1:
+            cap = int(offs[n])
+            ids = np.zeros(cap, dtype=np.int32)
+            rc = self.lib.gh_gather_neighbours(self.ctx, cap, offs.ctypes.data_as(_PL), ids.ctypes.data_as(_PI))
+        self._chk(rc)
+        return offs, ids[:offs[n]]
+
+    def timers(self):
+        ms = (C.c_double * 4)()
+        d, f = Stats(), Stats()
+        self._chk(self.lib.gh_get_timers(self.ctx, ms, C.byref(d), C.byref(f)))
+        return dict(zip(GH_T_NAMES, list(ms))), d.as_dict(), f.as_dict()
+
+    def reset_timers(self):
+        self._chk(self.lib.gh_reset_timers(self.ctx))
+
+    def set_shard(self, rank, nranks):
+        self._chk(self.lib.gh_set_shard(self.ctx, rank, nranks))
+
+    def shard_range(self, rank):
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.gh_shard_range(self.ctx, rank, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def field_dev(self, name, k=0):
+        return self.lib.gh_field_dev(self.ctx, FIELDS[name], k)

@@ -1,0 +1,679 @@
+// api.hip -- the extern "C" surface of libgandalf_hip.so (include/gandalf_hip.h) and the step driver.
+#include "gh_internal.hpp"
+#include "walk.hpp"
+#include <algorithm>
+#include <cmath>
+
+int gh_advance_time_impl(gh_ctx *ctx);
+
+struct CtxExtra { double *d_time; };
+static double *g_dummy = nullptr;
+
+// ctx->redbuf layout: [0 .. 256*6) reduction partials, then 2 doubles of {t, timestep}
+double *gh_time_dev(gh_ctx *ctx) { return ctx->redbuf + 256*6; }
+
+static int field_comp(int field, int *first, int *ncomp, int ndim)
+{
+  switch (field) {
+    case GH_F_R: *first = D_RX; *ncomp = ndim; return 0;
+    case GH_F_V: *first = D_VX; *ncomp = ndim; return 0;
+    case GH_F_A: *first = D_AX; *ncomp = ndim; return 0;
+    case GH_F_ATREE: *first = D_ATX; *ncomp = ndim; return 0;
+    case GH_F_R0: *first = D_R0X; *ncomp = ndim; return 0;
+    case GH_F_V0: *first = D_V0X; *ncomp = ndim; return 0;
+    case GH_F_A0: *first = D_A0X; *ncomp = ndim; return 0;
+    default: break;
+  }
+  if (field >= GH_F_M && field < GH_F_COUNT) { *first = D_M + (field - GH_F_M); *ncomp = 1; return 0; }
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase timing
+// ------------------------------------------------------------------------------------------------
+int gh_phase_begin(gh_ctx *ctx, int phase)
+{
+  gh_ctx::EvPair p;
+  if (!ctx->ev_free.empty()) { p = ctx->ev_free.back(); ctx->ev_free.pop_back(); }
+  else { GH_CHECK(ctx, hipEventCreate(&p.a)); GH_CHECK(ctx, hipEventCreate(&p.b)); }
+  GH_CHECK(ctx, hipEventRecord(p.a, ctx->stream));
+  ctx->ev_used[phase].push_back(p);
+  return GH_OK;
+}
+
+int gh_phase_end(gh_ctx *ctx, int phase)
+{
+  GH_CHECK(ctx, hipEventRecord(ctx->ev_used[phase].back().b, ctx->stream));
+  return GH_OK;
+}
+
+int gh_sync_collect(gh_ctx *ctx, const char *where)
+{
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int ph = 0; ph < GH_T_COUNT; ph++) {
+    for (auto &p : ctx->ev_used[ph]) {
+      float ms = 0.f;
+      GH_CHECK(ctx, hipEventElapsedTime(&ms, p.a, p.b));
+      ctx->timers[ph] += ms;
+      ctx->dom_ms[ph] += ms;
+      ctx->dom_calls[ph]++;
+      ctx->ev_free.push_back(p);
+    }
+    ctx->ev_used[ph].clear();
+  }
+  int flags = 0;
+  GH_CHECK(ctx, hipMemcpy(&flags, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (flags) {
+    GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
+    std::string m = std::string(where) + ":";
+    if (flags & FLAG_FRONTIER_OVERFLOW) m += " tree-walk frontier overflow (GH_FCAP)";
+    if (flags & FLAG_LEAFLIST_OVERFLOW) m += " candidate leaf list overflow (GH_LCAP)";
+    if (flags & FLAG_ILIST_OVERFLOW) m += " interaction list overflow";
+    if (flags & FLAG_H_NOT_CONVERGED) m += " h-rho iteration did not converge (GradhSph.cpp:249)";
+    ctx->err = m;
+    return (flags & FLAG_H_NOT_CONVERGED) && !(flags & ~FLAG_H_NOT_CONVERGED) ? GH_ERR_NOTCONVERGED : GH_ERR_CAPACITY;
+  }
+  return GH_OK;
+}
+
+static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
+{
+  unsigned long long hs[ST_COUNT];
+  GH_CHECK(ctx, hipMemcpy(hs, ctx->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+  GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(hs)));
+  gh_stats loc;
+  memset(&loc, 0, sizeof(loc));
+  loc.n_particles = ctx->N;
+  loc.n_iterations = (int64_t) hs[ST_ITER];
+  loc.n_candidates = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_CAND] : (int64_t) hs[ST_PAIRS];
+  loc.n_retries = (int64_t) hs[ST_RETRY];
+  loc.n_direct = (int64_t) hs[ST_DIRECT];
+  loc.n_cells = (int64_t) hs[ST_CELLS];
+  loc.kernel_ms = ctx->dom_calls[phase] ? ctx->dom_ms[phase]/ctx->dom_calls[phase] : 0.0;
+  if (st) *st = loc;
+  if (phase == GH_T_SPH_PROPERTIES) ctx->st_density = loc; else ctx->st_forces = loc;
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------------
+extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
+{
+  if (!cfg || !out) return GH_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->ndim < 1 || cfg->ndim > 3) return GH_ERR_INVALID;
+  gh_ctx *ctx = new gh_ctx();
+  ctx->cfg = *cfg;
+  ctx->ndim = cfg->ndim;
+  *out = ctx;
+  if (cfg->kernel != GH_KERNEL_M4) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only kernel = m4 (tabulated_kernel = 0) is built");
+  if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");
+  GH_CHECK(ctx, hipSetDevice(cfg->device));
+  GH_CHECK(ctx, hipStreamCreate(&ctx->stream));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->redbuf, sizeof(double)*(256*6 + 8)));
+  GH_CHECK(ctx, hipMemset(ctx->redbuf, 0, sizeof(double)*(256*6 + 8)));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_stats, sizeof(unsigned long long)*ST_COUNT));
+  GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long)*ST_COUNT));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
+  GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*2*D_COUNT));
+  return GH_OK;
+}
+
+static void free_particles(gh_ctx *ctx)
+{
+  for (int b = 0; b < 2; b++) {
+    for (int f = 0; f < D_COUNT; f++) { if (ctx->fbuf[b][f]) (void) hipFree(ctx->fbuf[b][f]); ctx->fbuf[b][f] = nullptr; }
+    if (ctx->iorig[b]) (void) hipFree(ctx->iorig[b]); ctx->iorig[b] = nullptr;
+    for (int k = 0; k < 3; k++) { if (ctx->P[b][k]) (void) hipFree(ctx->P[b][k]); ctx->P[b][k] = nullptr; }
+    if (ctx->cellnode[b]) (void) hipFree(ctx->cellnode[b]); ctx->cellnode[b] = nullptr;
+  }
+  for (int k = 0; k < 3; k++) {
+    if (ctx->W[k]) (void) hipFree(ctx->W[k]); ctx->W[k] = nullptr;
+    if (ctx->Wpre[k]) (void) hipFree(ctx->Wpre[k]); ctx->Wpre[k] = nullptr;
+  }
+  void *ptrs[] = {ctx->posm, ctx->side, ctx->sortkeys_out, ctx->sortvals};
+  for (void *p : ptrs) if (p) (void) hipFree(p);
+  ctx->posm = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
+}
+
+extern "C" void gh_destroy(gh_ctx *ctx)
+{
+  if (!ctx) return;
+  if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+  free_particles(ctx);
+  void *ptrs[] = {ctx->cfirst, ctx->cN, ctx->cbox, ctx->cgrav, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+                  ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
+  for (void *p : ptrs) if (p) (void) hipFree(p);
+  for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+  for (auto &p : ctx->ev_free) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+  if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *gh_last_error(const gh_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" int64_t gh_num_particles(const gh_ctx *ctx) { return ctx ? ctx->N : 0; }
+
+int gh_alloc_particles(gh_ctx *ctx, int64_t N)
+{
+  if (N <= ctx->Ncap) { ctx->N = N; return GH_OK; }
+  free_particles(ctx);
+  const size_t n = (size_t) N;
+  for (int b = 0; b < 2; b++) {
+    for (int f = 0; f < D_COUNT; f++) {
+      GH_CHECK(ctx, hipMalloc((void**) &ctx->fbuf[b][f], sizeof(double)*n));
+      GH_CHECK(ctx, hipMemset(ctx->fbuf[b][f], 0, sizeof(double)*n));
+    }
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->iorig[b], sizeof(int)*n));
+    for (int k = 0; k < 3; k++) GH_CHECK(ctx, hipMalloc((void**) &ctx->P[b][k], sizeof(int)*n));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->cellnode[b], sizeof(int)*n));
+  }
+  const size_t nwords = (n + 63)/64 + 1;
+  for (int k = 0; k < 3; k++) {
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->W[k], sizeof(unsigned long long)*nwords));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->Wpre[k], sizeof(unsigned int)*nwords));
+  }
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->posm, sizeof(double4)*n));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->side, n));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*n));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->sortvals, sizeof(int)*n));
+  ctx->Ncap = N; ctx->N = N;
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// particle transfer (caller order <-> tree order)
+// ------------------------------------------------------------------------------------------------
+extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, const double *v, const double *m,
+                                   const double *h, const double *u)
+{
+  if (!ctx || N <= 0 || !r || !m || !h) return ctx ? gh_fail(ctx, GH_ERR_INVALID, "gh_upload_particles: bad arguments") : GH_ERR_INVALID;
+  if (N >= (1ll << 31)) return gh_fail(ctx, GH_ERR_INVALID, "N too large");
+  int rc = gh_alloc_particles(ctx, N);
+  if (rc) return rc;
+  ctx->cur = 0;
+  const int nd = ctx->ndim;
+  const size_t n = (size_t) N;
+  std::vector<double> tmp(n);
+  auto put = [&](int comp, const double *src, int stride, int off, double fill) -> int {
+    if (src) for (size_t i = 0; i < n; i++) tmp[i] = src[i*stride + off];
+    else std::fill(tmp.begin(), tmp.end(), fill);
+    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[0][comp], tmp.data(), sizeof(double)*n, hipMemcpyHostToDevice));
+    return GH_OK;
+  };
+  for (int f = 0; f < D_COUNT; f++) GH_CHECK(ctx, hipMemset(ctx->fbuf[0][f], 0, sizeof(double)*n));
+  for (int k = 0; k < nd; k++) {
+    if ((rc = put(D_RX + k, r, nd, k, 0.0))) return rc;
+    if ((rc = put(D_R0X + k, r, nd, k, 0.0))) return rc;
+    if ((rc = put(D_VX + k, v, nd, k, 0.0))) return rc;
+    if ((rc = put(D_V0X + k, v, nd, k, 0.0))) return rc;
+  }
+  if ((rc = put(D_M, m, 1, 0, 0.0))) return rc;
+  if ((rc = put(D_H, h, 1, 0, 0.0))) return rc;
+  if ((rc = put(D_U, u, 1, 0, 0.0))) return rc;
+  if ((rc = put(D_U0, u, 1, 0, 0.0))) return rc;
+  if ((rc = put(D_ALPHA, nullptr, 1, 0, ctx->cfg.alpha_visc))) return rc;
+  std::vector<int> ids(n);
+  for (size_t i = 0; i < n; i++) ids[i] = (int) i;
+  GH_CHECK(ctx, hipMemcpy(ctx->iorig[0], ids.data(), sizeof(int)*n, hipMemcpyHostToDevice));
+  ctx->tree_valid = false;
+  ctx->n = 0; ctx->Nsteps = 0; ctx->t = 0.0; ctx->timestep = 0.0;
+  double tt[2] = {0.0, 0.0};
+  GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
+static int fetch_iorig(gh_ctx *ctx, std::vector<int> &ids)
+{
+  ids.resize((size_t) ctx->N);
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  GH_CHECK(ctx, hipMemcpy(ids.data(), ctx->iorig[ctx->cur], sizeof(int)*ids.size(), hipMemcpyDeviceToHost));
+  return GH_OK;
+}
+
+extern "C" int gh_download(gh_ctx *ctx, int field, double *dst)
+{
+  if (!ctx || !dst) return GH_ERR_INVALID;
+  int first, nc;
+  if (field_comp(field, &first, &nc, ctx->ndim)) return gh_fail(ctx, GH_ERR_INVALID, "gh_download: bad field");
+  std::vector<int> ids;
+  int rc = fetch_iorig(ctx, ids);
+  if (rc) return rc;
+  const size_t n = (size_t) ctx->N;
+  std::vector<double> tmp(n);
+  for (int k = 0; k < nc; k++) {
+    GH_CHECK(ctx, hipMemcpy(tmp.data(), ctx->fbuf[ctx->cur][first + k], sizeof(double)*n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) dst[(size_t) ids[i]*nc + k] = tmp[i];
+  }
+  return GH_OK;
+}
+
+extern "C" int gh_upload_field(gh_ctx *ctx, int field, const double *src)
+{
+  if (!ctx || !src) return GH_ERR_INVALID;
+  int first, nc;
+  if (field_comp(field, &first, &nc, ctx->ndim)) return gh_fail(ctx, GH_ERR_INVALID, "gh_upload_field: bad field");
+  std::vector<int> ids;
+  int rc = fetch_iorig(ctx, ids);
+  if (rc) return rc;
+  const size_t n = (size_t) ctx->N;
+  std::vector<double> tmp(n);
+  for (int k = 0; k < nc; k++) {
+    for (size_t i = 0; i < n; i++) tmp[i] = src[(size_t) ids[i]*nc + k];
+    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[ctx->cur][first + k], tmp.data(), sizeof(double)*n, hipMemcpyHostToDevice));
+  }
+  if (field == GH_F_R || field == GH_F_M) gh_pack_posm(ctx);
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tree
+// ------------------------------------------------------------------------------------------------
+extern "C" int gh_build_tree(gh_ctx *ctx)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  gh_phase_begin(ctx, GH_T_BUILD_TREE);
+  int rc = gh_tree_build_impl(ctx);
+  gh_phase_end(ctx, GH_T_BUILD_TREE);
+  if (rc) return rc;
+  return gh_sync_collect(ctx, "gh_build_tree");
+}
+
+extern "C" int gh_tree_size(gh_ctx *ctx, int32_t *Ncell, int32_t *ltot, int32_t *gtot)
+{
+  if (!ctx || !ctx->tree_valid) return GH_ERR_INVALID;
+  if (Ncell) *Ncell = ctx->Ncell;
+  if (ltot) *ltot = ctx->ltot;
+  if (gtot) *gtot = ctx->gtot;
+  return GH_OK;
+}
+
+extern "C" int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_first, int32_t *cell_N,
+                              double *bbmin, double *bbmax, double *hboxmin, double *hboxmax, double *rcell,
+                              double *com, double *mass, double *rmax, double *hmax, double *cdistsqd,
+                              int32_t *order)
+{
+  if (!ctx || !ctx->tree_valid) return ctx ? gh_fail(ctx, GH_ERR_INVALID, "gh_export_tree: no tree") : GH_ERR_INVALID;
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int Nc = ctx->Ncell, nd = ctx->ndim;
+  std::vector<CellBox> hb(Nc);
+  std::vector<CellGrav> hg(Nc);
+  GH_CHECK(ctx, hipMemcpy(hb.data(), ctx->cbox, sizeof(CellBox)*Nc, hipMemcpyDeviceToHost));
+  GH_CHECK(ctx, hipMemcpy(hg.data(), ctx->cgrav, sizeof(CellGrav)*Nc, hipMemcpyDeviceToHost));
+  // heap index -> reference pre-order id: child1 = c+1, child2 = c + 2^(ltot-level)  (KDTree.cpp:412-417)
+  std::vector<int> pre(Nc), lev(Nc);
+  pre[0] = 0; lev[0] = 0;
+  for (int n = 0; n < ctx->gtot - 1; n++) {
+    pre[2*n + 1] = pre[n] + 1;
+    pre[2*n + 2] = pre[n] + (1 << (ctx->ltot - lev[n]));
+    lev[2*n + 1] = lev[2*n + 2] = lev[n] + 1;
+  }
+  for (int n = 0; n < Nc; n++) {
+    const int c = pre[n];
+    if (cell_level) cell_level[c] = lev[n];
+    if (cell_first) cell_first[c] = ctx->h_cfirst[n];
+    if (cell_N) cell_N[c] = ctx->h_cN[n];
+    for (int k = 0; k < nd; k++) {
+      if (bbmin) bbmin[c*nd + k] = hb[n].bbmin[k];
+      if (bbmax) bbmax[c*nd + k] = hb[n].bbmax[k];
+      if (hboxmin) hboxmin[c*nd + k] = hb[n].hbmin[k];
+      if (hboxmax) hboxmax[c*nd + k] = hb[n].hbmax[k];
+      if (rcell) rcell[c*nd + k] = hg[n].rcell[k];
+      if (com) com[c*nd + k] = hg[n].com[k];
+    }
+    if (mass) mass[c] = hg[n].m;
+    if (rmax) rmax[c] = hg[n].rmax;
+    if (hmax) hmax[c] = hg[n].hmax;
+    if (cdistsqd) cdistsqd[c] = hg[n].cdistsqd;
+  }
+  if (order) GH_CHECK(ctx, hipMemcpy(order, ctx->iorig[ctx->cur], sizeof(int)*(size_t) ctx->N, hipMemcpyDeviceToHost));
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hot path entry points
+// ------------------------------------------------------------------------------------------------
+static int density_and_hmax(gh_ctx *ctx, bool count)
+{
+  int rc = gh_density_impl(ctx, count);
+  if (rc) return rc;
+  return gh_update_hmax_impl(ctx);                      // tree->UpdateAllHmaxValues, GradhSphTree.cpp:268
+}
+
+extern "C" int gh_update_density(gh_ctx *ctx, gh_stats *stats)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->dom_ms[GH_T_SPH_PROPERTIES] = 0; ctx->dom_calls[GH_T_SPH_PROPERTIES] = 0;
+  int rc = density_and_hmax(ctx, stats != nullptr);
+  if (rc) return rc;
+  rc = gh_sync_collect(ctx, "gh_update_density");
+  if (rc) return rc;
+  if (stats) return read_stats(ctx, stats, GH_T_SPH_PROPERTIES);
+  return GH_OK;
+}
+
+extern "C" int gh_zero_accelerations(gh_ctx *ctx)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  gh_zero_acc_impl(ctx);
+  return gh_sync_collect(ctx, "gh_zero_accelerations");
+}
+
+extern "C" int gh_update_hydro_forces(gh_ctx *ctx, gh_stats *stats)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->dom_ms[GH_T_SPH_FORCES] = 0; ctx->dom_calls[GH_T_SPH_FORCES] = 0;
+  int rc = gh_hydro_forces_impl(ctx, stats != nullptr);
+  if (rc) return rc;
+  rc = gh_sync_collect(ctx, "gh_update_hydro_forces");
+  if (rc) return rc;
+  if (stats) return read_stats(ctx, stats, GH_T_SPH_FORCES);
+  return GH_OK;
+}
+
+extern "C" int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->dom_ms[GH_T_SPH_FORCES] = 0; ctx->dom_calls[GH_T_SPH_FORCES] = 0;
+  int rc = gh_all_forces_impl(ctx, stats != nullptr);
+  if (rc) return rc;
+  rc = gh_sync_collect(ctx, "gh_update_all_forces");
+  if (rc) return rc;
+  if (stats) return read_stats(ctx, stats, GH_T_SPH_FORCES);
+  return GH_OK;
+}
+
+static int forces_impl(gh_ctx *ctx)
+{
+  if (ctx->cfg.self_gravity) return gh_all_forces_impl(ctx, false);
+  if (ctx->cfg.hydro_forces) return gh_hydro_forces_impl(ctx, false);
+  return gh_fail(ctx, GH_ERR_INVALID, "Error: No forces included in simulation");   // SphSimulation.cpp:474
+}
+
+// ------------------------------------------------------------------------------------------------
+// KDK glue
+// ------------------------------------------------------------------------------------------------
+static int push_time(gh_ctx *ctx)
+{
+  double tt[2] = {ctx->t, ctx->timestep};
+  GH_CHECK(ctx, hipMemcpyAsync(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice, ctx->stream));
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+static int pull_time(gh_ctx *ctx)
+{
+  double tt[2];
+  GH_CHECK(ctx, hipMemcpy(tt, gh_time_dev(ctx), sizeof(tt), hipMemcpyDeviceToHost));
+  ctx->t = tt[0]; ctx->timestep = tt[1];
+  return GH_OK;
+}
+
+extern "C" int gh_kdk_advance(gh_ctx *ctx, int n, double t, double timestep)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->n = n; ctx->t = t; ctx->timestep = timestep;
+  int rc = push_time(ctx);
+  if (rc) return rc;
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_kdk_advance_impl(ctx, n, t, timestep);
+  gh_phase_end(ctx, GH_T_KDK);
+  ctx->tree_valid = false;
+  return gh_sync_collect(ctx, "gh_kdk_advance");
+}
+
+extern "C" int gh_compute_global_timestep(gh_ctx *ctx, double *dt_min)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_timestep_impl(ctx);
+  gh_phase_end(ctx, GH_T_KDK);
+  int rc = gh_sync_collect(ctx, "gh_compute_global_timestep");
+  if (rc) return rc;
+  rc = pull_time(ctx);
+  if (rc) return rc;
+  ctx->n = 0;
+  if (dt_min) *dt_min = ctx->timestep;
+  return GH_OK;
+}
+
+extern "C" int gh_kdk_end(gh_ctx *ctx, int n, double t, double timestep)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  (void) n; (void) timestep;
+  ctx->t = t;
+  double tt = t;
+  GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), &tt, sizeof(double), hipMemcpyHostToDevice));
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_kdk_end_impl(ctx, n, t, timestep);
+  gh_phase_end(ctx, GH_T_KDK);
+  return gh_sync_collect(ctx, "gh_kdk_end");
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole steps
+// ------------------------------------------------------------------------------------------------
+static int build_tree_timed(gh_ctx *ctx)
+{
+  gh_phase_begin(ctx, GH_T_BUILD_TREE);
+  int rc = gh_tree_build_impl(ctx);
+  gh_phase_end(ctx, GH_T_BUILD_TREE);
+  return rc;
+}
+
+extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  // SphSimulation::PostInitialConditionsSetup (SphSimulation.cpp:266-345): density with the guessed h
+  // first if no h was provided, then tree + density, then (iteration loop :381-473) tree + density + forces
+  const int npass = initial_h_provided ? 2 : 3;
+  for (int p = 0; p < npass; p++) {
+    if ((rc = build_tree_timed(ctx))) return rc;
+    if ((rc = density_and_hmax(ctx, false))) return rc;
+    if ((rc = gh_sync_collect(ctx, "gh_setup/density"))) return rc;
+  }
+  gh_zero_acc_impl(ctx);
+  if ((rc = forces_impl(ctx))) return rc;
+  // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
+  ctx->t = 0.0; ctx->timestep = 0.0; ctx->n = 0;
+  if ((rc = push_time(ctx))) return rc;
+  gh_timestep_impl(ctx);                                 // ComputeGlobalTimestep (:532)
+  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // hydroint->EndTimestep (:551)
+  if ((rc = gh_sync_collect(ctx, "gh_setup"))) return rc;
+  if ((rc = pull_time(ctx))) return rc;
+  if (timestep) *timestep = ctx->timestep;
+  return GH_OK;
+}
+
+extern "C" int gh_set_time(gh_ctx *ctx, double t, double timestep)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->t = t; ctx->timestep = timestep;
+  return push_time(ctx);
+}
+
+extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  for (int s = 0; s < nsteps; s++) {
+    // SphSimulation::MainLoop (SphSimulation.cpp:585-876), Nlevels = 1, no stars
+    ctx->n++; ctx->Nsteps++;
+    gh_advance_time_impl(ctx);                           // t = t + timestep
+    gh_phase_begin(ctx, GH_T_KDK);
+    gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // AdvanceParticles + CheckBoundaries
+    gh_phase_end(ctx, GH_T_KDK);
+    if ((rc = build_tree_timed(ctx))) return rc;         // BuildTree (rebuilt every step)
+    if ((rc = density_and_hmax(ctx, false))) return rc;  // UpdateAllSphProperties
+    gh_zero_acc_impl(ctx);                               // ZeroAccelerations
+    if ((rc = forces_impl(ctx))) return rc;              // UpdateAllSph(Hydro)Forces
+    gh_phase_begin(ctx, GH_T_KDK);
+    gh_timestep_impl(ctx);                               // ComputeGlobalTimestep
+    gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                   // EndTimestep
+    gh_phase_end(ctx, GH_T_KDK);
+    ctx->n = 0;
+  }
+  if ((rc = gh_sync_collect(ctx, "gh_step"))) return rc;
+  if ((rc = pull_time(ctx))) return rc;
+  if (t) *t = ctx->t;
+  if (timestep) *timestep = ctx->timestep;
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timers / shards
+// ------------------------------------------------------------------------------------------------
+extern "C" int gh_get_timers(gh_ctx *ctx, double *ms, gh_stats *density, gh_stats *forces)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  if (ms) for (int k = 0; k < GH_T_COUNT; k++) ms[k] = ctx->timers[k];
+  if (density) { *density = ctx->st_density; density->kernel_ms = ctx->dom_calls[GH_T_SPH_PROPERTIES] ? ctx->dom_ms[GH_T_SPH_PROPERTIES]/ctx->dom_calls[GH_T_SPH_PROPERTIES] : 0.0; }
+  if (forces) { *forces = ctx->st_forces; forces->kernel_ms = ctx->dom_calls[GH_T_SPH_FORCES] ? ctx->dom_ms[GH_T_SPH_FORCES]/ctx->dom_calls[GH_T_SPH_FORCES] : 0.0; }
+  return GH_OK;
+}
+
+extern "C" int gh_reset_timers(gh_ctx *ctx)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  for (int k = 0; k < GH_T_COUNT; k++) { ctx->timers[k] = 0.0; ctx->dom_ms[k] = 0.0; ctx->dom_calls[k] = 0; }
+  return GH_OK;
+}
+
+extern "C" int gh_set_shard(gh_ctx *ctx, int rank, int nranks)
+{
+  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return GH_ERR_INVALID;
+  ctx->rank = rank; ctx->nranks = nranks;
+  return GH_OK;
+}
+
+extern "C" int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count)
+{
+  if (!ctx || !ctx->tree_valid || rank < 0 || rank >= ctx->nranks) return GH_ERR_INVALID;
+  int g0, g1;
+  gh_shard_groups(ctx, rank, g0, g1);
+  const int base = (1 << ctx->lgroup) - 1;
+  const int64_t f = g0 < ctx->ngroups ? ctx->h_cfirst[base + g0] : ctx->N;
+  const int64_t e = g1 < ctx->ngroups ? ctx->h_cfirst[base + g1] : ctx->N;
+  if (first) *first = f;
+  if (count) *count = e - f;
+  return GH_OK;
+}
+
+extern "C" void *gh_field_dev(gh_ctx *ctx, int field, int k)
+{
+  if (!ctx) return nullptr;
+  int first, nc;
+  if (field_comp(field, &first, &nc, ctx->ndim) || k < 0 || k >= nc) return nullptr;
+  return ctx->fbuf[ctx->cur][first + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather neighbour query (parity tests)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain dom, double kernrange, int pass,
+                                                          const long long *offsets, long long *counts, int *ids, int *flags)
+{
+  __shared__ int s_front[2][GH_FCAP];
+  __shared__ unsigned long long s_leaf[GH_LCAP];
+  __shared__ double s_x[64], s_y[64], s_z[64];
+  __shared__ int s_id[64];
+  const int lane = threadIdx.x;
+  const int q = blockIdx.x;
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
+  if (gN == 0) return;
+  const bool act = lane < gN;
+  const int i = gfirst + (act ? lane : 0);
+  double ri[3] = {0, 0, 0};
+  for (int k = 0; k < d.ndim; k++) ri[k] = d.f[D_RX + k][i];
+  const double hi_ = d.f[D_H][i];
+  const double rs = kernrange*hi_;
+  const double rs2 = rs*rs;
+  const CellBox gb = d.cbox[gnode];
+  const double hs = wave_max(act ? hi_ : 0.0);
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    lo[k] = k < d.ndim ? gb.bbmin[k] - kernrange*hs : -1e300;
+    hi[k] = k < d.ndim ? gb.bbmax[k] + kernrange*hs : 1e300;
+  }
+  const unsigned int codes = image_codes(dom, d.ndim, lo, hi);
+  auto pred = [&](int n, const double sh[3]) -> bool {
+    const CellBox &b = d.cbox[n];
+    for (int k = 0; k < d.ndim; k++) {
+      if (lo[k] > b.bbmax[k] + sh[k]) return false;
+      if (b.bbmin[k] + sh[k] > hi[k]) return false;
+    }
+    return true;
+  };
+  const int nleaf = walk_collect_leaves(d, dom, codes, pred, s_front, s_leaf, flags);
+  const int occ = d.leafocc, lpt = 64/occ, ls = lane/occ, kk = lane - ls*occ;
+  const int ntiles = (nleaf + lpt - 1)/lpt;
+  const int myorig = d.iorig[i];
+  long long cnt = 0;
+  const long long base = pass ? offsets[myorig] : 0;
+  for (int t = 0; t < ntiles; t++) {
+    double x = 1e30, y = 1e30, z = 1e30; int id = -1;
+    const int li = t*lpt + ls;
+    if (ls < lpt && li < nleaf) {
+      const unsigned long long e = s_leaf[li];
+      const int first = (int) (e & 0xffffffffu), c = (int) ((e >> 32) & 0xff), code = (int) ((e >> 40) & 0xff);
+      if (kk < c) {
+        double sh[3]; code_shift(dom, code, sh);
+        const int j = first + kk;
+        x = d.f[D_RX][j] + sh[0];
+        y = d.ndim > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
+        z = d.ndim > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
+        id = d.iorig[j];
+      }
+    }
+    s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_id[lane] = id;
+    __syncthreads();
+    if (act) {
+      for (int c = 0; c < 64; c++) {
+        if (s_id[c] < 0) continue;
+        const double dx = s_x[c] - ri[0]; double r2 = dx*dx;
+        if (d.ndim > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
+        if (d.ndim > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
+        if (r2 < rs2) {                                   // Tree.cpp:255 (strict <)
+          if (pass) ids[base + cnt] = s_id[c];
+          cnt++;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (act && !pass) counts[myorig] = cnt;
+}
+
+extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, int32_t *ids)
+{
+  if (!ctx || !offsets) return GH_ERR_INVALID;
+  if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_gather_neighbours: no tree");
+  const size_t n = (size_t) ctx->N;
+  long long *d_counts = nullptr, *d_off = nullptr; int *d_ids = nullptr;
+  GH_CHECK(ctx, hipMalloc((void**) &d_counts, sizeof(long long)*n));
+  GH_CHECK(ctx, hipMalloc((void**) &d_off, sizeof(long long)*(n + 1)));
+  Domain dom; gh_fill_domain(ctx, dom);
+  DevicePtrs d = gh_dev(ctx);
+  const double kr = ctx->cfg.kernel == GH_KERNEL_QUINTIC ? 3.0 : 2.0;
+  hipLaunchKernelGGL(k_gather_count_fill, dim3(ctx->ngroups), dim3(64), 0, ctx->stream, d, dom, kr, 0, d_off, d_counts, d_ids, ctx->d_flags);
+  int rc = gh_sync_collect(ctx, "gh_gather_neighbours");
+  if (rc) { (void) hipFree(d_counts); (void) hipFree(d_off); return rc; }
+  std::vector<long long> cnt(n);
+  GH_CHECK(ctx, hipMemcpy(cnt.data(), d_counts, sizeof(long long)*n, hipMemcpyDeviceToHost));
+  offsets[0] = 0;
+  for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + cnt[i];
+  if (offsets[n] > cap || !ids) { (void) hipFree(d_counts); (void) hipFree(d_off); return gh_fail(ctx, GH_ERR_CAPACITY, "gh_gather_neighbours: ids buffer too small"); }
+  GH_CHECK(ctx, hipMemcpy(d_off, offsets, sizeof(long long)*(n + 1), hipMemcpyHostToDevice));
+  GH_CHECK(ctx, hipMalloc((void**) &d_ids, sizeof(int)*(size_t) std::max<int64_t>(offsets[n], 1)));
+  hipLaunchKernelGGL(k_gather_count_fill, dim3(ctx->ngroups), dim3(64), 0, ctx->stream, d, dom, kr, 1, d_off, d_counts, d_ids, ctx->d_flags);
+  rc = gh_sync_collect(ctx, "gh_gather_neighbours");
+  if (!rc) GH_CHECK(ctx, hipMemcpy(ids, d_ids, sizeof(int)*(size_t) offsets[n], hipMemcpyDeviceToHost));
+  (void) hipFree(d_counts); (void) hipFree(d_off); (void) hipFree(d_ids);
+  return rc;
+}

@@ -1,0 +1,545 @@
+// forces.hip -- grad-h SPH hydro forces, and hydro + self-gravity forces, on the GPU.
+//
+// Replaces GradhSphTree::UpdateAllSphHydroForces / UpdateAllSphForces and everything they call per cell:
+// Tree::ComputeNeighbourAndGhostList, Tree::ComputeGravityInteractionAndGhostList (+ open_cell_for_gravity),
+// NeighbourManager::_EndSearch / TrimNeighbourLists, GradhSph::ComputeSphHydroForces /
+// ComputeSphHydroGravForces / ComputeDirectGravForces and ComputeCellMonopoleForces
+// (reference src/GradhSph/GradhSphTree.cpp:280-657, src/Tree/Tree.cpp:562-735, src/Headers/Tree.h:413-432,
+//  src/Headers/NeighbourManager.h:368-543, src/GradhSph/GradhSph.cpp:361-690,
+//  src/Headers/NeighbourSearch.h:350-377).
+//
+// Mapping: one wavefront per group of <= 64 particles (= up to 16 leaf cells of the KD-tree), one lane
+// per particle.  The reference builds one interaction list per LEAF CELL; to evaluate exactly the same
+// interactions the wave walks the tree once for all of its leaves and keeps, per frontier node, a
+// 16-bit mask of the leaves that still descend through it.  Every classification of the reference's
+// walk is taken per (node, leaf) with the leaf's own rcell/rmax/hmax; accepted cells and near-field
+// particles go to LDS lists tagged with the mask of leaves they belong to, and are flushed through
+// broadcast LDS tiles: lanes whose leaf bit is clear skip the entry.
+#include "gh_internal.hpp"
+#include "sph_kernels.hpp"
+#include "walk.hpp"
+
+struct ForceParams {
+  Domain dom;
+  EosParams eos;
+  double alpha_visc, beta_visc;
+  int avisc, acond;
+  int group0;
+};
+
+// per-neighbour record of the force tiles (reference HydroForcesParticle, Particle.h:313-364)
+enum { T_X = 0, T_Y, T_Z, T_M, T_VX, T_VY, T_VZ, T_HR2, T_INVH, T_HFAC, T_PFAC, T_INVRHO, T_SOUND, T_ZETA, T_U, T_PRESS, T_NF };
+
+struct TargetI {
+  double r[3], v[3];
+  double invh, hfactor, pfac, invrho, sound, zeta, hr2, u, press, invhsqd;
+};
+
+struct Accum {
+  double a[3], at[3];
+  double dudt, div_v, gpot;
+};
+
+// one SPH pair, particle i <- neighbour j               (GradhSph.cpp:384-448 / 498-572)
+template <int ND, bool GRAV>
+__device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const double (*s_t)[64], int c,
+                                         const double dr_in[3], double r2)
+{
+  typedef M4<ND> K;
+  double dr[3] = {dr_in[0], dr_in[1], dr_in[2]};
+  double drmag;
+  if (GRAV) {
+    drmag = sqrt(r2 + GH_SMALL);
+    const double inv = 1.0/drmag;
+    for (int k = 0; k < ND; k++) dr[k] *= inv;
+  }
+  else {
+    drmag = sqrt(r2);
+    if (drmag > 0.0) { const double inv = 1.0/drmag; for (int k = 0; k < ND; k++) dr[k] *= inv; }
+  }
+  const double mj = s_t[T_M][c];
+  const double invh_j = s_t[T_INVH][c];
+  const double wkerni = ti.hfactor*K::w1(drmag*ti.invh);
+  const double wkernj = s_t[T_HFAC][c]*K::w1(drmag*invh_j);
+  double dvdr = 0.0;
+  {
+    dvdr = (s_t[T_VX][c] - ti.v[0])*dr[0];
+    if (ND > 1) dvdr += (s_t[T_VY][c] - ti.v[1])*dr[1];
+    if (ND > 2) dvdr += (s_t[T_VZ][c] - ti.v[2])*dr[2];
+  }
+  A.div_v -= mj*dvdr*wkerni;
+  double paux = ti.pfac*wkerni + s_t[T_PFAC][c]*wkernj;
+  if (dvdr < 0.0) {
+    const double invrho_j = s_t[T_INVRHO][c];
+    const double winvrho = 0.25*(wkerni + wkernj)*(ti.invrho + invrho_j);
+    if (P.avisc == GH_AVISC_MON97) {
+      const double vsignal = ti.sound + s_t[T_SOUND][c] - P.beta_visc*P.alpha_visc*dvdr;
+      paux -= P.alpha_visc*vsignal*dvdr*winvrho;
+      A.dudt -= 0.5*mj*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;
+    }
+    if (P.acond == GH_ACOND_WADSLEY2008)
+      A.dudt += mj*dvdr*(s_t[T_U][c] - ti.u)*(ti.invrho*wkerni + invrho_j*wkernj);
+    else if (P.acond == GH_ACOND_PRICE2008)
+      A.dudt += 0.5*mj*(ti.u - s_t[T_U][c])*winvrho*(ti.invrho + invrho_j)*sqrt(fabs(ti.press - s_t[T_PRESS][c]));
+  }
+  for (int k = 0; k < ND; k++) A.a[k] += mj*dr[k]*paux;
+  if (GRAV) {
+    const double pg = 0.5*(ti.invhsqd*K::wgrav(drmag*ti.invh) + ti.zeta*wkerni +
+                           invh_j*invh_j*K::wgrav(drmag*invh_j) + s_t[T_ZETA][c]*wkernj);
+    for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*pg;
+    A.gpot += 0.5*mj*(ti.invh*K::wpot(drmag*ti.invh) + invh_j*K::wpot(drmag*invh_j));
+  }
+}
+
+__device__ __forceinline__ void load_target(const DevicePtrs &d, int i, int ND, TargetI &t)
+{
+  for (int k = 0; k < 3; k++) { t.r[k] = k < ND ? d.f[D_RX + k][i] : 0.0; t.v[k] = k < ND ? d.f[D_VX + k][i] : 0.0; }
+  const double h = d.f[D_H][i], rho = d.f[D_RHO][i];
+  t.invh = 1.0/h; t.invhsqd = t.invh*t.invh;
+  t.hfactor = d.f[D_HFACTOR][i];
+  t.press = d.f[D_PRESSURE][i];
+  t.pfac = (t.press*d.f[D_INVOMEGA][i])/(rho*rho);
+  t.invrho = 1.0/rho;
+  t.sound = d.f[D_SOUND][i];
+  t.zeta = d.f[D_ZETA][i];
+  t.hr2 = d.f[D_HRANGESQD][i];
+  t.u = d.f[D_U][i];
+}
+
+// stage particle j (tree-order index) with image shift sh into tile slot `slot`
+__device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (*s_t)[64], int slot, int j, const double sh[3], bool valid)
+{
+  if (valid) {
+    const double h = d.f[D_H][j], rho = d.f[D_RHO][j], press = d.f[D_PRESSURE][j];
+    s_t[T_X][slot] = d.f[D_RX][j] + sh[0];
+    s_t[T_Y][slot] = ND > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
+    s_t[T_Z][slot] = ND > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
+    s_t[T_M][slot] = d.f[D_M][j];
+    s_t[T_VX][slot] = d.f[D_VX][j];
+    s_t[T_VY][slot] = ND > 1 ? d.f[D_VY][j] : 0.0;
+    s_t[T_VZ][slot] = ND > 2 ? d.f[D_VZ][j] : 0.0;
+    s_t[T_HR2][slot] = d.f[D_HRANGESQD][j];
+    s_t[T_INVH][slot] = 1.0/h;
+    s_t[T_HFAC][slot] = d.f[D_HFACTOR][j];
+    s_t[T_PFAC][slot] = (press*d.f[D_INVOMEGA][j])/(rho*rho);
+    s_t[T_INVRHO][slot] = 1.0/rho;
+    s_t[T_SOUND][slot] = d.f[D_SOUND][j];
+    s_t[T_ZETA][slot] = d.f[D_ZETA][j];
+    s_t[T_U][slot] = d.f[D_U][j];
+    s_t[T_PRESS][slot] = press;
+  }
+  else {
+    for (int f = 0; f < T_NF; f++) s_t[f][slot] = 0.0;
+    s_t[T_X][slot] = 1e30; s_t[T_Y][slot] = 1e30; s_t[T_Z][slot] = 1e30;
+    s_t[T_INVH][slot] = 1.0; s_t[T_INVRHO][slot] = 1.0;
+  }
+}
+
+// ================================================================================================
+// hydro only                                                     (GradhSphTree.cpp:280-435)
+// ================================================================================================
+template <int ND, bool COUNT>
+__global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
+{
+  __shared__ int s_front[2][GH_FCAP];
+  __shared__ unsigned long long s_leaf[GH_LCAP];
+  __shared__ double s_t[T_NF][64];
+
+  const int lane = threadIdx.x;
+  const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
+  if (gN == 0) return;
+  const bool act = lane < gN;
+  const int i = gfirst + (act ? lane : 0);
+  TargetI ti;
+  load_target(d, i, ND, ti);
+  Accum A;
+  for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
+  A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
+
+  // candidate leaves: overlap(cell.bb, other.hbox) || overlap(cell.hbox, other.bb)   (Tree.cpp:579-580)
+  const CellBox gb = d.cbox[gnode];
+  const double hr_root = M4<ND>::kernrange*d.cgrav[0].hmax;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    lo[k] = k < ND ? fmin(gb.hbmin[k], gb.bbmin[k] - hr_root) : -1e300;
+    hi[k] = k < ND ? fmax(gb.hbmax[k], gb.bbmax[k] + hr_root) : 1e300;
+  }
+  const unsigned int codes = image_codes(P.dom, ND, lo, hi);
+  auto pred = [&](int n, const double sh[3]) -> bool {
+    const CellBox &b = d.cbox[n];
+    bool o1 = true, o2 = true;
+    for (int k = 0; k < ND; k++) {
+      if (gb.bbmin[k] > b.hbmax[k] + sh[k] || b.hbmin[k] + sh[k] > gb.bbmax[k]) o1 = false;
+      if (gb.hbmin[k] > b.bbmax[k] + sh[k] || b.bbmin[k] + sh[k] > gb.hbmax[k]) o2 = false;
+    }
+    return o1 || o2;
+  };
+  const int nleaf = walk_collect_leaves(d, P.dom, codes, pred, s_front, s_leaf, flags);
+
+  const int occ = d.leafocc;
+  const int lpt = 64/occ;
+  const int ls = lane/occ, kk = lane - ls*occ;
+  const int ntiles = (nleaf + lpt - 1)/lpt;
+  unsigned long long n_pairs = 0;
+
+  for (int t = 0; t < ntiles; t++) {
+    {
+      const int li = t*lpt + ls;
+      bool valid = false; int j = 0; double sh[3] = {0.0, 0.0, 0.0};
+      if (ls < lpt && li < nleaf) {
+        const unsigned long long e = s_leaf[li];
+        const int first = (int) (e & 0xffffffffu), cnt = (int) ((e >> 32) & 0xff), code = (int) ((e >> 40) & 0xff);
+        if (kk < cnt) { valid = true; j = first + kk; code_shift(P.dom, code, sh); }
+      }
+      stage_neib(d, ND, s_t, lane, j, sh, valid);
+    }
+    __syncthreads();
+    unsigned long long mask = 0;
+    if (act) {
+#pragma unroll 16
+      for (int c = 0; c < 64; c++) {
+        double r2;
+        { const double dx = s_t[T_X][c] - ti.r[0]; r2 = dx*dx; }
+        if (ND > 1) { const double dy = s_t[T_Y][c] - ti.r[1]; r2 += dy*dy; }
+        if (ND > 2) { const double dz = s_t[T_Z][c] - ti.r[2]; r2 += dz*dz; }
+        // neighbour unless (r2 >= hrangesqd_i && r2 >= hrangesqd_j)      (NeighbourManager.h:521)
+        if (!(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c])) mask |= 1ull << c;
+      }
+    }
+    while (__any(mask != 0ull)) {
+      if (mask != 0ull) {
+        const int c = __ffsll((long long) mask) - 1;
+        mask &= mask - 1ull;
+        double dr[3] = {0.0, 0.0, 0.0};
+        dr[0] = s_t[T_X][c] - ti.r[0];
+        if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
+        if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
+        double r2 = dr[0]*dr[0];
+        if (ND > 1) r2 += dr[1]*dr[1];
+        if (ND > 2) r2 += dr[2]*dr[2];
+        sph_pair<ND, false>(P, ti, A, s_t, c, dr, r2);
+        if (COUNT) n_pairs++;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (act) {
+    // GradhSph.cpp:451-453 then GradhSphTree.cpp:396-404 (accumulate on the zeroed main array)
+    A.div_v *= ti.invrho;
+    A.dudt -= ti.press*A.div_v*ti.invrho*d.f[D_INVOMEGA][i];
+    for (int k = 0; k < ND; k++) d.f[D_AX + k][i] += A.a[k];
+    d.f[D_DUDT][i] += A.dudt;
+    d.f[D_DIV_V][i] += A.div_v;
+  }
+  if (COUNT) {
+    const unsigned long long a = wave_sum_u64(act ? n_pairs : 0);
+    if (lane == 0) atomicAdd(&stats[ST_PAIRS], a);
+  }
+}
+
+// ================================================================================================
+// hydro + self-gravity                                           (GradhSphTree.cpp:444-657)
+// ================================================================================================
+#define GH_MAXLEAF 16
+#define GH_CCAP 256          /* cell-interaction list capacity per flush */
+#define GH_PCAP 128          /* near-field leaf list capacity per flush */
+
+template <int ND, bool COUNT>
+__global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
+{
+  typedef M4<ND> K;
+  __shared__ int s_fnode[2][GH_FCAP];
+  __shared__ unsigned short s_fmask[2][GH_FCAP];
+  __shared__ double s_cx[GH_CCAP], s_cy[GH_CCAP], s_cz[GH_CCAP], s_cm[GH_CCAP];
+  __shared__ unsigned short s_cmask[GH_CCAP];
+  __shared__ int s_pfirst[GH_PCAP];
+  __shared__ unsigned short s_pcnt[GH_PCAP], s_phyd[GH_PCAP], s_pdir[GH_PCAP];
+  __shared__ double s_t[T_NF][64];
+  __shared__ unsigned short s_thyd[64], s_tdir[64];
+  __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
+
+  const int lane = threadIdx.x;
+  const unsigned long long lt = lanemask_lt();
+  const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
+  if (gN == 0) return;
+  const bool act = lane < gN;
+  const int i = gfirst + (act ? lane : 0);
+  const int nl = 1 << (d.ltot - d.lgroup);            // leaves in this group (<= 16)
+  const int leafnode0 = (d.gtot - 1) + q*nl;
+
+  // leaf geometry of the group (the reference walks per leaf cell with these, Tree.cpp:639-643)
+  unsigned int allmask = 0;
+  if (lane < nl) {
+    const CellGrav g = d.cgrav[leafnode0 + lane];
+    for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
+    s_lrmax[lane] = g.rmax;
+    s_lhr[lane] = K::kernrange*g.hmax;
+  }
+  for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
+  // leaf of this lane
+  int myleaf = 0;
+  for (int l = 1; l < nl; l++) if (i >= d.cfirst[leafnode0 + l]) myleaf = l;
+  __syncthreads();
+
+  TargetI ti;
+  load_target(d, i, ND, ti);
+  Accum A;
+  for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
+  A.dudt = 0.0; A.div_v = 0.0;
+  A.gpot = (d.f[D_M][i]*ti.invh)*K::wpot(0.0);          // self term, GradhSphTree.cpp:512
+  unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
+
+  const int occ = d.leafocc;
+  const int lpt = 64/occ;
+  const int ls = lane/occ, kk = lane - ls*occ;
+
+  int ncell = 0, npart = 0;
+
+  auto flush = [&]() {
+    __syncthreads();
+    // ---- cells: monopole                                         (NeighbourSearch.h:350-377)
+    if (act) {
+      for (int c = 0; c < ncell; c++) {
+        if ((s_cmask[c] >> myleaf) & 1) {
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = s_cx[c] - ti.r[0];
+          if (ND > 1) dr[1] = s_cy[c] - ti.r[1];
+          if (ND > 2) dr[2] = s_cz[c] - ti.r[2];
+          double drsqd = dr[0]*dr[0];
+          if (ND > 1) drsqd += dr[1]*dr[1];
+          if (ND > 2) drsqd += dr[2]*dr[2];
+          drsqd += GH_SMALL;
+          const double invdrsqd = 1.0/drsqd;
+          const double invdrmag = sqrt(invdrsqd);
+          const double invdr3 = invdrsqd*invdrmag;
+          const double mc = s_cm[c];
+          A.gpot += mc*invdrmag;
+          for (int k = 0; k < ND; k++) A.at[k] += mc*dr[k]*invdr3;
+          if (COUNT) n_cells++;
+        }
+      }
+    }
+    // ---- near-field particles, tile by tile
+    const int ntiles = (npart + lpt - 1)/lpt;
+    for (int t = 0; t < ntiles; t++) {
+      __syncthreads();
+      {
+        const int li = t*lpt + ls;
+        bool valid = false; int j = 0; const double sh[3] = {0.0, 0.0, 0.0};
+        unsigned short hm = 0, dm = 0;
+        if (ls < lpt && li < npart) {
+          if (kk < (int) s_pcnt[li]) { valid = true; j = s_pfirst[li] + kk; hm = s_phyd[li]; dm = s_pdir[li]; }
+        }
+        stage_neib(d, ND, s_t, lane, j, sh, valid);
+        s_thyd[lane] = hm; s_tdir[lane] = dm;
+      }
+      __syncthreads();
+      unsigned long long mask = 0;
+      if (act) {
+#pragma unroll 8
+        for (int c = 0; c < 64; c++) {
+          const bool hydc = (s_thyd[c] >> myleaf) & 1, dirc = (s_tdir[c] >> myleaf) & 1;
+          if (hydc || dirc) {
+            double dr[3] = {0.0, 0.0, 0.0};
+            dr[0] = s_t[T_X][c] - ti.r[0];
+            if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
+            if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
+            double r2 = dr[0]*dr[0];
+            if (ND > 1) r2 += dr[1]*dr[1];
+            if (ND > 2) r2 += dr[2]*dr[2];
+            // hydro candidate that is a real SPH neighbour, NeighbourManager.h:521-533
+            const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
+            if (sph) mask |= 1ull << c;
+            else {
+              // direct Newtonian term                               (GradhSph.cpp:671-686)
+              const double drsqd = r2 + GH_SMALL;
+              const double invdrmag = 1.0/sqrt(drsqd);
+              const double invdr3 = invdrmag*invdrmag*invdrmag;
+              const double mj = s_t[T_M][c];
+              for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*invdr3;
+              A.gpot += mj*invdrmag;
+              if (COUNT) n_direct++;
+            }
+          }
+        }
+      }
+      while (__any(mask != 0ull)) {
+        if (mask != 0ull) {
+          const int c = __ffsll((long long) mask) - 1;
+          mask &= mask - 1ull;
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = s_t[T_X][c] - ti.r[0];
+          if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
+          if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          sph_pair<ND, true>(P, ti, A, s_t, c, dr, r2);
+          if (COUNT) n_pairs++;
+        }
+      }
+    }
+    __syncthreads();
+    ncell = 0; npart = 0;
+  };
+
+  // ---- breadth-first walk with per-leaf masks                     (Tree.cpp:648-731)
+  if (lane == 0) { s_fnode[0][0] = 0; s_fmask[0][0] = (unsigned short) allmask; }
+  __syncthreads();
+  int cur = 0, nfront = 1;
+  const int leaf0 = d.gtot - 1;
+  while (nfront > 0) {
+    int nnext = 0;
+    for (int base = 0; base < nfront; base += 64) {
+      if (ncell > GH_CCAP - 64 || npart > GH_PCAP - 64) flush();
+      const int idx = base + lane;
+      unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
+      int n = 0; bool isleaf = false;
+      CellGrav g;
+      g.first = 0; g.N = 0; g.m = 0.0;
+      for (int k = 0; k < 3; k++) g.com[k] = 0.0;
+      if (idx < nfront) {
+        n = s_fnode[cur][idx];
+        const unsigned int fm = s_fmask[cur][idx];
+        g = d.cgrav[n];
+        isleaf = n >= leaf0;
+        const double khr = K::kernrange*g.hmax;
+        for (int l = 0; l < nl; l++) {
+          if (!((fm >> l) & 1)) continue;
+          double drsqd = 0.0;
+          for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
+          const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
+          const double d2 = s_lrmax[l] + g.rmax + khr;
+          if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
+            if (!isleaf) openm |= 1u << l;
+            else if (g.N > 0) hydm |= 1u << l;
+          }
+          else if (g.N == 0) { }
+          else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
+            if (isleaf && g.N == 1) dirm |= 1u << l;
+            else cellm |= 1u << l;
+          }
+          else {
+            if (!isleaf) openm |= 1u << l;
+            else dirm |= 1u << l;
+          }
+        }
+      }
+      const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0), pm = __ballot((hydm | dirm) != 0);
+      if (openm) {
+        const int pos = nnext + 2*__popcll(om & lt);
+        if (pos + 1 < GH_FCAP) {
+          s_fnode[cur ^ 1][pos] = 2*n + 1; s_fmask[cur ^ 1][pos] = (unsigned short) openm;
+          s_fnode[cur ^ 1][pos + 1] = 2*n + 2; s_fmask[cur ^ 1][pos + 1] = (unsigned short) openm;
+        }
+      }
+      nnext += 2*__popcll(om);
+      if (cellm) {
+        const int pos = ncell + __popcll(cm & lt);
+        s_cx[pos] = g.com[0]; s_cy[pos] = g.com[1]; s_cz[pos] = g.com[2]; s_cm[pos] = g.m;
+        s_cmask[pos] = (unsigned short) cellm;
+      }
+      ncell += __popcll(cm);
+      if (hydm | dirm) {
+        const int pos = npart + __popcll(pm & lt);
+        s_pfirst[pos] = g.first; s_pcnt[pos] = (unsigned short) g.N;
+        s_phyd[pos] = (unsigned short) hydm; s_pdir[pos] = (unsigned short) dirm;
+      }
+      npart += __popcll(pm);
+    }
+    if (nnext > GH_FCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); nnext = GH_FCAP; }
+    __syncthreads();
+    cur ^= 1;
+    nfront = nnext;
+  }
+  flush();
+
+  if (act) {
+    // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619
+    A.div_v *= ti.invrho;
+    A.dudt -= ti.press*A.div_v*ti.invrho*d.f[D_INVOMEGA][i];
+    for (int k = 0; k < ND; k++) {
+      double a = d.f[D_AX + k][i];
+      a += A.a[k];
+      a += A.at[k];
+      d.f[D_AX + k][i] = a;
+      d.f[D_ATX + k][i] += A.at[k];
+    }
+    d.f[D_GPOT][i] += A.gpot;
+    d.f[D_GPOT_HYDRO][i] += A.gpot;
+    d.f[D_DUDT][i] += A.dudt;
+    d.f[D_DIV_V][i] += A.div_v;
+  }
+  if (COUNT) {
+    const unsigned long long a = wave_sum_u64(act ? n_pairs : 0), b = wave_sum_u64(act ? n_direct : 0), c = wave_sum_u64(act ? n_cells : 0);
+    if (lane == 0) { atomicAdd(&stats[ST_PAIRS], a); atomicAdd(&stats[ST_DIRECT], b); atomicAdd(&stats[ST_CELLS], c); }
+  }
+}
+
+static void fill_force_params(gh_ctx *ctx, ForceParams &P)
+{
+  gh_fill_domain(ctx, P.dom);
+  gh_fill_eos(ctx, P.eos);
+  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
+  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond;
+  int g0, g1;
+  gh_shard_groups(ctx, ctx->rank, g0, g1);
+  P.group0 = g0;
+}
+
+int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
+{
+  if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_hydro_forces: no tree");
+  DevicePtrs d = gh_dev(ctx);
+  ForceParams P;
+  fill_force_params(ctx, P);
+  int g0, g1;
+  gh_shard_groups(ctx, ctx->rank, g0, g1);
+  const int nblocks = g1 - g0;
+  hipStream_t s = ctx->stream;
+  gh_phase_begin(ctx, GH_T_SPH_FORCES);
+  if (nblocks > 0) {
+#define LAUNCH(ND_)                                                                                               \
+    if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_hydro_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
+    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#undef LAUNCH
+  }
+  gh_phase_end(ctx, GH_T_SPH_FORCES);
+  GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
+}
+
+int gh_all_forces_impl(gh_ctx *ctx, bool count)
+{
+  if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_all_forces: no tree");
+  for (int k = 0; k < ctx->ndim; k++)
+    if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN)
+      return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
+  if (ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only multipole=monopole, gravity_mac=geometric are built");
+  if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
+  DevicePtrs d = gh_dev(ctx);
+  ForceParams P;
+  fill_force_params(ctx, P);
+  int g0, g1;
+  gh_shard_groups(ctx, ctx->rank, g0, g1);
+  const int nblocks = g1 - g0;
+  hipStream_t s = ctx->stream;
+  gh_phase_begin(ctx, GH_T_SPH_FORCES);
+  if (nblocks > 0) {
+#define LAUNCH(ND_)                                                                                              \
+    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_grav_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
+    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#undef LAUNCH
+  }
+  gh_phase_end(ctx, GH_T_SPH_FORCES);
+  GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
+}

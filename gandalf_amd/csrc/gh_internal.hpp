@@ -1,0 +1,153 @@
+// gh_internal.hpp -- context, device data layout and small helpers of libgandalf_hip.
+//
+// Data layout in HBM:
+//   * particles: structure of arrays, one double array per scalar / vector component, stored in
+//     TREE ORDER (leaf cells contiguous), double-buffered so that a tree rebuild is one gather pass;
+//   * derived per-pass packs (posm = x,y,z,m as 32-byte records) for the LDS tiles;
+//   * KD-tree cells in heap order (children of n are 2n+1, 2n+2), two 96-byte records per cell.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/gandalf_hip.h"
+
+#define GH_WAVE 64
+
+// component arrays: 7 vectors x 3 + 21 scalars
+enum FieldD {
+  D_RX = 0, D_RY, D_RZ, D_VX, D_VY, D_VZ, D_AX, D_AY, D_AZ, D_ATX, D_ATY, D_ATZ,
+  D_R0X, D_R0Y, D_R0Z, D_V0X, D_V0Y, D_V0Z, D_A0X, D_A0Y, D_A0Z,
+  D_M, D_H, D_U, D_U0, D_DUDT, D_DUDT0, D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD,
+  D_SOUND, D_PRESSURE, D_DIV_V, D_GPOT, D_GPOT_HYDRO, D_ALPHA, D_DALPHADT, D_DT, D_DT_NEXT,
+  D_TLAST, D_COUNT
+};
+
+// KD-tree cell records (heap order).  Field meanings follow TreeCellBase (reference TreeCell.h:16-49).
+struct alignas(32) CellBox {       // 96 B
+  double bbmin[3], bbmax[3];       // tight bounding box of particle positions
+  double hbmin[3], hbmax[3];       // bounding box of r -/+ kernrange*h
+};
+struct alignas(32) CellGrav {      // 96 B
+  double rcell[3];                 // centre of bb
+  double rmax;                     // half diagonal of bb
+  double hmax;                     // max h in cell
+  double cdistsqd;                 // max(rmax^2, hmax^2)/thetamaxsqd at stock time
+  double com[3];                   // centre of mass
+  double m;                        // mass
+  int first, N;                    // particle range in tree order
+  double pad;
+};
+
+struct DevicePtrs {                // everything a kernel needs, passed by value
+  double *f[D_COUNT];              // current particle arrays (tree order)
+  int *iorig;                      // caller-order id of each particle
+  double4 *posm;                   // (x,y,z,m) pack
+  CellBox *cbox;
+  CellGrav *cgrav;
+  const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
+  int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
+};
+
+struct gh_ctx {
+  gh_config cfg;
+  int ndim = 3;
+  int64_t N = 0, Ncap = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // particle storage, double buffered
+  double *fbuf[2][D_COUNT] = {};
+  int *iorig[2] = {};
+  int cur = 0;
+  double4 *posm = nullptr;
+  double **d_ptrtab = nullptr;     // device table of 2*D_COUNT pointers for the permute kernel
+
+  // tree
+  int ltot = 0, gtot = 0, Ncell = 0, lgroup = 0, ngroups = 0, leafocc = 0;
+  int64_t tree_layout_N = -1;
+  std::vector<int> h_cfirst, h_cN;
+  int *cfirst = nullptr, *cN = nullptr;
+  CellBox *cbox = nullptr;
+  CellGrav *cgrav = nullptr;
+  double *dbbmin = nullptr, *dbbmax = nullptr;   // divide-time boxes [Ncell][3]
+  int *kdiv = nullptr;
+  int *P[2][3] = {};               // presorted permutations, double buffered
+  int *cellnode[2] = {};
+  unsigned char *side = nullptr;
+  unsigned long long *W[3] = {};   // ballot words
+  unsigned int *Wpre[3] = {};      // exclusive prefix of popcounts
+  double *sortkeys = nullptr, *sortkeys_out = nullptr;
+  int *sortvals = nullptr;
+  void *sorttemp = nullptr; size_t sorttemp_bytes = 0;
+  double *redbuf = nullptr;        // reduction scratch
+  bool tree_valid = false;
+
+  // statistics / timers
+  unsigned long long *d_stats = nullptr;   // device counters
+  int *d_flags = nullptr;                  // device error flags
+  struct EvPair { hipEvent_t a, b; };
+  std::vector<EvPair> ev_used[GH_T_COUNT];    // recorded, not yet read back
+  std::vector<EvPair> ev_free;
+  double timers[GH_T_COUNT] = {};
+  double dom_ms[GH_T_COUNT] = {};             // time of the dominant kernel of each phase
+  long dom_calls[GH_T_COUNT] = {};
+  gh_stats st_density = {}, st_forces = {};
+
+  // time integration state (reference SimulationBase: n, Nsteps, t, timestep)
+  int n = 0, Nsteps = 0;
+  double t = 0.0, timestep = 0.0;
+
+  // multi-GPU work shard
+  int rank = 0, nranks = 1;
+};
+
+#define GH_CHECK(ctx, call)                                                                   \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                        \
+      return GH_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+static inline int gh_fail(gh_ctx *ctx, int code, const std::string &msg)
+{
+  ctx->err = msg;
+  return code;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int) ((a + b - 1)/b); }
+
+// error-flag bits written by kernels
+enum { FLAG_FRONTIER_OVERFLOW = 1, FLAG_LEAFLIST_OVERFLOW = 2, FLAG_H_NOT_CONVERGED = 4,
+       FLAG_ILIST_OVERFLOW = 8 };
+
+// stats slots
+enum { ST_ITER = 0, ST_CAND, ST_RETRY, ST_PAIRS, ST_DIRECT, ST_CELLS, ST_COUNT };
+
+DevicePtrs gh_dev(gh_ctx *ctx);
+int gh_alloc_particles(gh_ctx *ctx, int64_t N);
+int gh_alloc_tree(gh_ctx *ctx);
+int gh_tree_build_impl(gh_ctx *ctx);
+int gh_update_hmax_impl(gh_ctx *ctx);
+// the *_impl functions only enqueue work on ctx->stream (no host synchronisation)
+int gh_density_impl(gh_ctx *ctx, bool count);
+int gh_hydro_forces_impl(gh_ctx *ctx, bool count);
+int gh_all_forces_impl(gh_ctx *ctx, bool count);
+int gh_zero_acc_impl(gh_ctx *ctx);
+int gh_kdk_advance_impl(gh_ctx *ctx, int n, double t, double timestep);
+int gh_kdk_end_impl(gh_ctx *ctx, int n, double t, double timestep);
+int gh_timestep_impl(gh_ctx *ctx);          // leaves min dt in ctx->redbuf[0] and writes dt_next
+int gh_pack_posm(gh_ctx *ctx);
+// phase timing with HIP events on ctx->stream; read back by gh_sync_collect
+int gh_phase_begin(gh_ctx *ctx, int phase);
+int gh_phase_end(gh_ctx *ctx, int phase);
+// synchronise the stream, read event times / error flags / counters
+int gh_sync_collect(gh_ctx *ctx, const char *where);
+struct Domain; struct EosParams;
+void gh_fill_domain(const gh_ctx *ctx, Domain &dom);
+void gh_fill_eos(const gh_ctx *ctx, EosParams &e);
+void gh_shard_groups(const gh_ctx *ctx, int rank, int &g0, int &g1);

@@ -1,0 +1,88 @@
+// sph_kernels.hpp -- device restatement of the reference's M4 (cubic spline) kernel functions
+// (reference src/Headers/SmoothingKernel.h:131-240, normalisation src/Hydrodynamics/M4Kernel.cpp:39-53)
+// and of the closed-form EOS used by the configs (src/Thermal/AdiabaticEOS.cpp:69, IsothermalEOS.cpp).
+// Powers are written as products (the reference calls pow(s,n)); the difference is < 1 ulp per term.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define GH_INVPI 0.31830988618379      /* reference Constants.h:63 (truncated on purpose) */
+#define GH_TWOTHIRDS 0.66666666666666666666666
+#define GH_SMALL 1.0e-20               /* Constants.h:73 small_number */
+#define GH_SMALL_DP 1.0e-50            /* Constants.h:90 small_number_dp */
+
+template <int ND> struct M4 {
+  static constexpr double kernrange = 2.0;
+  static constexpr double kernrangesqd = 4.0;
+  __host__ __device__ static constexpr double norm()
+  {
+    return ND == 1 ? GH_TWOTHIRDS : (ND == 2 ? GH_INVPI*(10.0/7.0) : GH_INVPI);
+  }
+  __device__ static __forceinline__ double w0(double s)
+  {
+    if (s < 1.0) return norm()*(1.0 - 1.5*s*s + 0.75*s*s*s);
+    else if (s < 2.0) { const double t = 2.0 - s; return 0.25*norm()*(t*t*t); }
+    return 0.0;
+  }
+  __device__ static __forceinline__ double w1(double s)
+  {
+    if (s < 1.0) return norm()*(-3.0*s + 2.25*s*s);
+    else if (s < 2.0) return -0.75*norm()*(2.0 - s)*(2.0 - s);
+    return 0.0;
+  }
+  __device__ static __forceinline__ double womega(double s)
+  {
+    const double nd = (double) ND;
+    if (s < 1.0) return norm()*(-nd + 1.5*(nd + 2.0)*s*s - 0.75*(nd + 3.0)*(s*s*s));
+    else if (s < 2.0)
+      return norm()*(-2.0*nd + 3.0*(nd + 1.0)*s - 1.50*(nd + 2.0)*s*s + 0.25*(nd + 3.0)*(s*s*s));
+    return 0.0;
+  }
+  __device__ static __forceinline__ double wzeta(double s)
+  {
+    const double s2 = s*s;
+    if (s < 1.0) return 1.4 - 2.0*s2 + 1.5*(s2*s2) - 0.6*(s2*s2*s);
+    else if (s < 2.0) return 1.6 - 4.0*s2 + 4.0*(s2*s) - 1.5*(s2*s2) + 0.2*(s2*s2*s);
+    return 0.0;
+  }
+  __device__ static __forceinline__ double wgrav(double s)
+  {
+    const double s2 = s*s;
+    if (s < 1.0) return 1.333333333333333333333*s - 1.2*(s2*s) + 0.5*(s2*s2);
+    else if (s < 2.0)
+      return 2.6666666666666666667*s - 3.0*s2 + 1.2*(s2*s) - 0.166666666666666666667*(s2*s2) -
+             0.06666666666666666667/s2;
+    return 1.0/s2;
+  }
+  __device__ static __forceinline__ double wpot(double s)
+  {
+    const double s2 = s*s;
+    if (s < 1.0) return 1.4 - 0.666666666666666666666666*s2 + 0.3*(s2*s2) - 0.1*(s2*s2*s);
+    else if (s < 2.0)
+      return -1.0/(15.0*s) + 1.6 - 1.33333333333333333333333333*s2 + (s2*s) - 0.3*(s2*s2) +
+             (1.0/30.0)*(s2*s2*s);
+    return 1.0/s;
+  }
+};
+
+// pow(x, ND) / pow(x, ND+1) as the reference writes hfactor (GradhSph.cpp:192, 264)
+template <int ND> __device__ __forceinline__ double powN(double x)
+{
+  return ND == 1 ? x : (ND == 2 ? x*x : x*x*x);
+}
+
+struct EosParams { int kind; double gamma, gammam1, temp0, mu_bar, rho_bary; };
+
+// u, sound, pressure of a particle with density rho and energy u (GradhSph::ComputeThermalProperties,
+// GradhSph.cpp:335-347).  energy_eqn: u is kept, c = sqrt(gamma (gamma-1) u), P = (gamma-1) rho u.
+__device__ __forceinline__ void eos_eval(const EosParams &e, double rho, double &u, double &sound, double &press)
+{
+  if (e.kind == GH_EOS_ENERGY_EQN) {
+    sound = sqrt(e.gamma*e.gammam1*u);
+    press = e.gammam1*rho*u;
+  }
+  else {  // isothermal in dimensionless units: u = temp0/gammam1/mu_bar (IsothermalEOS.cpp:72-87)
+    u = e.temp0/e.gammam1/e.mu_bar;
+    sound = sqrt(e.gammam1*u);
+    press = e.gammam1*rho*u;
+  }
+}

@@ -1,0 +1,455 @@
+// tree.hip -- GPU construction of GANDALF's balanced KD-tree.
+//
+// Produces exactly the tree of the reference's KDTree::BuildTree / DivideTreeCell / StockCellProperties
+// (reference src/Tree/KDTree.cpp:220-313, 442-595, 808-1083): the cell at level l that holds N particles
+// is split along the longest axis of its *inherited* box (root box = extent of r -/+ kernrange*h,
+// KDTree.cpp:277-278; children inherit it cut at the split value, :508-527) so that the N/2 particles
+// with the smallest coordinate go left and the rest go right (QuickSelect, :682-750).  Only the SET of
+// particles per cell is defined by that (ties between equal coordinates aside); the reference finds it
+// with a serial recursive quick-select on an index array, here it is found level by level for all
+// cells at once:
+//
+//   1. argsort the particles once per axis (radix sort of the fp64 coordinates);
+//   2. per level: every cell picks its split axis and reads the median straight out of the list sorted
+//      on that axis; every particle is marked left/right; the per-axis lists are stably partitioned
+//      inside each cell segment (ballot words + popcount prefix), which keeps them sorted;
+//   3. the final list is the tree order; all particle arrays are gathered into it (one pass), so that
+//      every cell at every level owns a CONTIGUOUS range of particles from then on;
+//   4. cells are stocked bottom-up, one launch per level.
+//
+// Cells live in heap order (children of n: 2n+1, 2n+2) - levels are contiguous, which is what the
+// level-synchronous kernels want; gh_export_tree renumbers to the reference's pre-order ids.
+#include "gh_internal.hpp"
+#include <rocprim/rocprim.hpp>
+
+#define KERNRANGE_OF(cfg) ((cfg).kernel == GH_KERNEL_QUINTIC ? 3.0 : 2.0)
+
+static const double BIG = 9.9e20;   // reference Constants.h:72 big_number
+
+// ------------------------------------------------------------------------------------------------
+// root box: min/max over particles of r -/+ kernrange*h           (KDTree.cpp:269-280)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */)
+{
+  __shared__ double s[6][256];
+  double mn[3] = {BIG, BIG, BIG}, mx[3] = {-BIG, -BIG, -BIG};
+  for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
+    const double hr = kernrange*d.f[D_H][i];
+    for (int k = 0; k < d.ndim; k++) {
+      const double x = d.f[D_RX + k][i];
+      mx[k] = fmax(mx[k], x + hr);
+      mn[k] = fmin(mn[k], x - hr);
+    }
+  }
+  for (int k = 0; k < 3; k++) { s[k][threadIdx.x] = mn[k]; s[3 + k][threadIdx.x] = mx[k]; }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int) threadIdx.x < off)
+      for (int k = 0; k < 3; k++) {
+        s[k][threadIdx.x] = fmin(s[k][threadIdx.x], s[k][threadIdx.x + off]);
+        s[3 + k][threadIdx.x] = fmax(s[3 + k][threadIdx.x], s[3 + k][threadIdx.x + off]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) out[blockIdx.x*6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ void k_rootbox_final(const double *part, int nblk, double *dbbmin, double *dbbmax)
+{
+  const int k = threadIdx.x;
+  if (k >= 3) return;
+  double mn = BIG, mx = -BIG;
+  for (int b = 0; b < nblk; b++) { mn = fmin(mn, part[b*6 + k]); mx = fmax(mx, part[b*6 + 3 + k]); }
+  dbbmin[k] = mn;
+  dbbmax[k] = mx;
+}
+
+__global__ void k_iota(int *v, int n)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+__global__ void k_fill_int(int *v, int n, int val)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < n) v[i] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// level step 1: per cell, split axis + median + children's inherited boxes   (KDTree.cpp:490-533)
+// ------------------------------------------------------------------------------------------------
+struct LevelArgs {
+  const int *P[3];
+  int *Pn[3];
+  const int *cellnode; int *cellnode_next;
+  unsigned char *side;
+  unsigned long long *W[3];
+  unsigned int *Wpre[3];
+  double *dbbmin, *dbbmax;
+  int *kdiv;
+  int level, nwords;
+};
+
+__global__ void k_divide_cells(DevicePtrs d, LevelArgs a)
+{
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= (1 << a.level)) return;
+  const int n = (1 << a.level) - 1 + j;
+  const int first = d.cfirst[n], cnt = d.cN[n];
+  double rkmax = 0.0;
+  int kd = 0;
+  for (int k = 0; k < d.ndim; k++) {
+    const double ext = a.dbbmax[n*3 + k] - a.dbbmin[n*3 + k];
+    if (ext > rkmax) { rkmax = ext; kd = k; }
+  }
+  double rdiv = a.dbbmin[n*3 + kd];
+  if (cnt > 0) rdiv = d.f[D_RX + kd][a.P[kd][first + cnt/2]];
+  const int c1 = 2*n + 1, c2 = 2*n + 2;
+  for (int k = 0; k < 3; k++) {
+    a.dbbmin[c1*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c1*3 + k] = a.dbbmax[n*3 + k];
+    a.dbbmin[c2*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c2*3 + k] = a.dbbmax[n*3 + k];
+  }
+  a.dbbmax[c1*3 + kd] = rdiv;
+  a.dbbmin[c2*3 + kd] = rdiv;
+  a.kdiv[n] = kd;
+}
+
+// level step 2: mark every particle left (0) / right (1) from its cell's split-axis list
+__global__ void k_mark_side(DevicePtrs d, LevelArgs a)
+{
+  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  if (p >= d.N) return;
+  const int n = a.cellnode[p];
+  const int first = d.cfirst[n], half = d.cN[n]/2;
+  const int kd = a.kdiv[n];
+  const int right = (p - first >= half) ? 1 : 0;
+  a.side[a.P[kd][p]] = (unsigned char) right;
+  a.cellnode_next[p] = 2*n + 1 + right;
+}
+
+// level step 3: one 64-bit word of "is left" flags per wave per axis
+__global__ void k_ballot_words(DevicePtrs d, LevelArgs a)
+{
+  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  for (int k = 0; k < d.ndim; k++) {
+    const int flag = (p < d.N) ? (a.side[a.P[k][p]] == 0) : 0;
+    const unsigned long long w = __ballot(flag);
+    if ((threadIdx.x & 63) == 0 && (p >> 6) < a.nwords) a.W[k][p >> 6] = w;
+  }
+}
+
+// level step 4: exclusive prefix sum of the popcounts of the words (one block per axis)
+__global__ void k_scan_words(LevelArgs a)
+{
+  const int k = blockIdx.x;
+  const unsigned long long *W = a.W[k];
+  unsigned int *pre = a.Wpre[k];
+  __shared__ unsigned int s[1024];
+  const int per = (a.nwords + 1023)/1024;
+  const int lo = threadIdx.x*per, hi = min(lo + per, a.nwords);
+  unsigned int sum = 0;
+  for (int i = lo; i < hi; i++) sum += __popcll(W[i]);
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned int v = ((int) threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned int run = s[threadIdx.x] - sum;
+  for (int i = lo; i < hi; i++) { pre[i] = run; run += __popcll(W[i]); }
+}
+
+__device__ __forceinline__ unsigned int rank_left(const unsigned long long *W, const unsigned int *pre, int p)
+{
+  const int w = p >> 6, b = p & 63;
+  const unsigned long long m = b ? (W[w] & ((1ull << b) - 1ull)) : 0ull;
+  return pre[w] + __popcll(m);
+}
+
+// level step 5: stable partition of every cell segment of every axis list
+__global__ void k_partition(DevicePtrs d, LevelArgs a)
+{
+  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  if (p >= d.N) return;
+  const int n = a.cellnode[p];
+  const int first = d.cfirst[n], half = d.cN[n]/2;
+  for (int k = 0; k < d.ndim; k++) {
+    const int id = a.P[k][p];
+    const int right = a.side[id];
+    const int nleft_before = (int) (rank_left(a.W[k], a.Wpre[k], p) - rank_left(a.W[k], a.Wpre[k], first));
+    const int np = right ? first + half + ((p - first) - nleft_before) : first + nleft_before;
+    a.Pn[k][np] = id;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather all particle arrays into tree order
+// ------------------------------------------------------------------------------------------------
+__global__ void k_permute(double **tab /* [2*D_COUNT]: src then dst */, const int *perm, int N)
+{
+  const int f = blockIdx.y;
+  const double *src = tab[f];
+  double *dst = tab[D_COUNT + f];
+  for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < N; i += gridDim.x*blockDim.x) dst[i] = src[perm[i]];
+}
+
+__global__ void k_permute_int(const int *src, int *dst, const int *perm, int N)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < N) dst[i] = src[perm[i]];
+}
+
+__global__ void k_pack_posm(DevicePtrs d)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  double4 v;
+  v.x = d.f[D_RX][i];
+  v.y = d.ndim > 1 ? d.f[D_RY][i] : 0.0;
+  v.z = d.ndim > 2 ? d.f[D_RZ][i] : 0.0;
+  v.w = d.f[D_M][i];
+  d.posm[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stocking                                                    (KDTree.cpp:808-1083, 1128-1208)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void finish_cell(const DevicePtrs &d, CellBox &b, CellGrav &g, double thetamaxsqd)
+{
+  double dr2 = 0.0;
+  for (int k = 0; k < d.ndim; k++) {
+    g.rcell[k] = 0.5*(b.bbmin[k] + b.bbmax[k]);
+    const double dr = 0.5*(b.bbmax[k] - b.bbmin[k]);
+    dr2 += dr*dr;
+  }
+  g.cdistsqd = fmax(dr2, g.hmax*g.hmax)/thetamaxsqd;
+  g.rmax = sqrt(dr2);
+}
+
+// hmax_only = 1 restates KDTree::UpdateHmaxValues: only hmax and hbox are refreshed
+__global__ void k_stock_leaves(DevicePtrs d, double kernrange, double thetamaxsqd, int hmax_only)
+{
+  const int g = blockIdx.x*blockDim.x + threadIdx.x;
+  if (g >= d.gtot) return;
+  const int n = d.gtot - 1 + g;
+  const int first = d.cfirst[n], cnt = d.cN[n];
+  CellBox b = d.cbox[n];
+  CellGrav c = d.cgrav[n];
+  c.hmax = 0.0;
+  for (int k = 0; k < 3; k++) { b.hbmin[k] = BIG; b.hbmax[k] = -BIG; }
+  if (!hmax_only) {
+    c.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG;
+    for (int k = 0; k < 3; k++) { c.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
+    c.first = first; c.N = cnt; c.pad = 0.0;
+  }
+  for (int i = first; i < first + cnt; i++) {
+    const double h = d.f[D_H][i];
+    c.hmax = fmax(c.hmax, h);
+    const double m = d.f[D_M][i];
+    if (!hmax_only) c.m += m;
+    for (int k = 0; k < d.ndim; k++) {
+      const double x = d.f[D_RX + k][i];
+      if (!hmax_only) {
+        c.com[k] += m*x;
+        if (x < b.bbmin[k]) b.bbmin[k] = x;
+        if (x > b.bbmax[k]) b.bbmax[k] = x;
+      }
+      if (x - kernrange*h < b.hbmin[k]) b.hbmin[k] = x - kernrange*h;
+      if (x + kernrange*h > b.hbmax[k]) b.hbmax[k] = x + kernrange*h;
+    }
+  }
+  if (!hmax_only) {
+    if (c.m > 0) for (int k = 0; k < d.ndim; k++) c.com[k] /= c.m;
+    if (cnt > 0) finish_cell(d, b, c, thetamaxsqd);
+  }
+  d.cbox[n] = b;
+  d.cgrav[n] = c;
+}
+
+__global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only)
+{
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= (1 << level)) return;
+  const int n = (1 << level) - 1 + j;
+  const int c1 = 2*n + 1, c2 = 2*n + 2;
+  CellBox b = d.cbox[n];
+  CellGrav c = d.cgrav[n];
+  c.hmax = 0.0;
+  for (int k = 0; k < 3; k++) { b.hbmin[k] = BIG; b.hbmax[k] = -BIG; }
+  if (!hmax_only) {
+    c.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG;
+    for (int k = 0; k < 3; k++) { c.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
+    c.first = d.cfirst[n]; c.N = d.cN[n]; c.pad = 0.0;
+  }
+  const CellGrav g1 = d.cgrav[c1], g2 = d.cgrav[c2];
+  const CellBox b1 = d.cbox[c1], b2 = d.cbox[c2];
+  if (g1.N > 0) {
+    for (int k = 0; k < d.ndim; k++) {
+      if (!hmax_only) { b.bbmin[k] = fmin(b1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b1.bbmax[k], b.bbmax[k]); }
+      b.hbmin[k] = fmin(b1.hbmin[k], b.hbmin[k]); b.hbmax[k] = fmax(b1.hbmax[k], b.hbmax[k]);
+    }
+    c.hmax = fmax(c.hmax, g1.hmax);
+  }
+  if (g2.N > 0) {
+    for (int k = 0; k < d.ndim; k++) {
+      if (!hmax_only) { b.bbmin[k] = fmin(b2.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b2.bbmax[k], b.bbmax[k]); }
+      b.hbmin[k] = fmin(b2.hbmin[k], b.hbmin[k]); b.hbmax[k] = fmax(b2.hbmax[k], b.hbmax[k]);
+    }
+    c.hmax = fmax(c.hmax, g2.hmax);
+  }
+  if (!hmax_only) {
+    c.m = g1.m + g2.m;
+    if (c.m > 0) for (int k = 0; k < d.ndim; k++) c.com[k] = (g1.m*g1.com[k] + g2.m*g2.com[k])/c.m;
+    if (c.N > 0) finish_cell(d, b, c, thetamaxsqd);
+  }
+  d.cbox[n] = b;
+  d.cgrav[n] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+DevicePtrs gh_dev(gh_ctx *ctx)
+{
+  DevicePtrs d;
+  for (int f = 0; f < D_COUNT; f++) d.f[f] = ctx->fbuf[ctx->cur][f];
+  d.iorig = ctx->iorig[ctx->cur];
+  d.posm = ctx->posm;
+  d.cbox = ctx->cbox; d.cgrav = ctx->cgrav;
+  d.cfirst = ctx->cfirst; d.cN = ctx->cN;
+  d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
+  d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
+  return d;
+}
+
+// tree size (KDTree::ComputeTreeSize, KDTree.cpp:322-352) and the static particle ranges of all cells
+int gh_alloc_tree(gh_ctx *ctx)
+{
+  const int64_t N = ctx->N;
+  if (ctx->tree_layout_N == N) return GH_OK;
+  int ltot = 0;
+  while ((int64_t) ctx->cfg.Nleafmax*(1ll << ltot) < N) ltot++;
+  const int gtot = 1 << ltot, Ncell = 2*gtot - 1;
+  ctx->ltot = ltot; ctx->gtot = gtot; ctx->Ncell = Ncell;
+  ctx->h_cfirst.assign(Ncell, 0); ctx->h_cN.assign(Ncell, 0);
+  ctx->h_cN[0] = (int) N;
+  for (int n = 0; n < gtot - 1; n++) {
+    const int half = ctx->h_cN[n]/2;
+    ctx->h_cfirst[2*n + 1] = ctx->h_cfirst[n];        ctx->h_cN[2*n + 1] = half;
+    ctx->h_cfirst[2*n + 2] = ctx->h_cfirst[n] + half; ctx->h_cN[2*n + 2] = ctx->h_cN[n] - half;
+  }
+  int occ = 0;
+  for (int g = 0; g < gtot; g++) occ = std::max(occ, ctx->h_cN[gtot - 1 + g]);
+  ctx->leafocc = occ;
+  // a group = the subtree whose particles one wavefront handles: as many leaves as fit 64 lanes
+  int G = 0;
+  while (G < ltot && occ*(2 << G) <= GH_WAVE) G++;
+  ctx->lgroup = ltot - G;
+  ctx->ngroups = 1 << ctx->lgroup;
+
+  auto re = [&](void **p, size_t bytes) -> hipError_t { if (*p) (void) hipFree(*p); *p = nullptr; return hipMalloc(p, bytes); };
+  GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->cN, sizeof(int)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->cbox, sizeof(CellBox)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->cgrav, sizeof(CellGrav)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->dbbmin, sizeof(double)*3*(Ncell + 2)));
+  GH_CHECK(ctx, re((void**) &ctx->dbbmax, sizeof(double)*3*(Ncell + 2)));
+  GH_CHECK(ctx, re((void**) &ctx->kdiv, sizeof(int)*Ncell));
+  GH_CHECK(ctx, hipMemcpyAsync(ctx->cfirst, ctx->h_cfirst.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
+  GH_CHECK(ctx, hipMemcpyAsync(ctx->cN, ctx->h_cN.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
+  GH_CHECK(ctx, hipMemsetAsync(ctx->cbox, 0, sizeof(CellBox)*Ncell, ctx->stream));
+  GH_CHECK(ctx, hipMemsetAsync(ctx->cgrav, 0, sizeof(CellGrav)*Ncell, ctx->stream));
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->tree_layout_N = N;
+  return GH_OK;
+}
+
+int gh_pack_posm(gh_ctx *ctx)
+{
+  DevicePtrs d = gh_dev(ctx);
+  hipLaunchKernelGGL(k_pack_posm, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, d);
+  return GH_OK;
+}
+
+static int stock_tree(gh_ctx *ctx, int hmax_only)
+{
+  DevicePtrs d = gh_dev(ctx);
+  const double kr = KERNRANGE_OF(ctx->cfg);
+  hipLaunchKernelGGL(k_stock_leaves, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, d, kr,
+                     ctx->cfg.thetamaxsqd, hmax_only);
+  for (int l = ctx->ltot - 1; l >= 0; l--)
+    hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << l, 256)), dim3(256), 0, ctx->stream, d, l,
+                       ctx->cfg.thetamaxsqd, hmax_only);
+  return GH_OK;
+}
+
+int gh_update_hmax_impl(gh_ctx *ctx) { return stock_tree(ctx, 1); }
+
+int gh_tree_build_impl(gh_ctx *ctx)
+{
+  int rc = gh_alloc_tree(ctx);
+  if (rc) return rc;
+  const int N = (int) ctx->N;
+  const int nb = cdiv(N, 256);
+  DevicePtrs d = gh_dev(ctx);
+  hipStream_t s = ctx->stream;
+  const double kr = KERNRANGE_OF(ctx->cfg);
+
+  // root box
+  const int nblk = 256;
+  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, s, d, kr, ctx->redbuf);
+  hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, s, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
+
+  // one argsort per axis
+  for (int k = 0; k < ctx->ndim; k++) {
+    hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, s, ctx->sortvals, N);
+    size_t need = 0;
+    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX + k], ctx->sortkeys_out, ctx->sortvals,
+                                            ctx->P[0][k], (size_t) N, 0, 64, s));
+    if (need > ctx->sorttemp_bytes) {
+      GH_CHECK(ctx, hipStreamSynchronize(s));
+      if (ctx->sorttemp) (void) hipFree(ctx->sorttemp);
+      GH_CHECK(ctx, hipMalloc(&ctx->sorttemp, need));
+      ctx->sorttemp_bytes = need;
+    }
+    GH_CHECK(ctx, rocprim::radix_sort_pairs(ctx->sorttemp, ctx->sorttemp_bytes, d.f[D_RX + k], ctx->sortkeys_out,
+                                            ctx->sortvals, ctx->P[0][k], (size_t) N, 0, 64, s));
+  }
+  hipLaunchKernelGGL(k_fill_int, dim3(nb), dim3(256), 0, s, ctx->cellnode[0], N, 0);
+
+  int pb = 0;
+  const int nwords = (N + 63)/64;
+  for (int l = 0; l < ctx->ltot; l++) {
+    LevelArgs a;
+    for (int k = 0; k < 3; k++) { a.P[k] = ctx->P[pb][k]; a.Pn[k] = ctx->P[pb ^ 1][k]; a.W[k] = ctx->W[k]; a.Wpre[k] = ctx->Wpre[k]; }
+    a.cellnode = ctx->cellnode[pb]; a.cellnode_next = ctx->cellnode[pb ^ 1];
+    a.side = ctx->side; a.dbbmin = ctx->dbbmin; a.dbbmax = ctx->dbbmax; a.kdiv = ctx->kdiv;
+    a.level = l; a.nwords = nwords;
+    hipLaunchKernelGGL(k_divide_cells, dim3(cdiv(1 << l, 256)), dim3(256), 0, s, d, a);
+    hipLaunchKernelGGL(k_mark_side, dim3(nb), dim3(256), 0, s, d, a);
+    hipLaunchKernelGGL(k_ballot_words, dim3(nb), dim3(256), 0, s, d, a);
+    hipLaunchKernelGGL(k_scan_words, dim3(ctx->ndim), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_partition, dim3(nb), dim3(256), 0, s, d, a);
+    pb ^= 1;
+  }
+
+  // gather every particle array into tree order (perm[new] = old position)
+  const int *perm = ctx->P[pb][0];
+  {
+    double *tab[2*D_COUNT];
+    for (int f = 0; f < D_COUNT; f++) { tab[f] = ctx->fbuf[ctx->cur][f]; tab[D_COUNT + f] = ctx->fbuf[ctx->cur ^ 1][f]; }
+    GH_CHECK(ctx, hipMemcpyAsync(ctx->d_ptrtab, tab, sizeof(tab), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), D_COUNT), dim3(256), 0, s, ctx->d_ptrtab, perm, N);
+    hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
+    GH_CHECK(ctx, hipStreamSynchronize(s));   // tab[] lives on this stack frame
+    ctx->cur ^= 1;
+  }
+  stock_tree(ctx, 0);
+  gh_pack_posm(ctx);
+  GH_CHECK(ctx, hipGetLastError());
+  ctx->tree_valid = true;
+  return GH_OK;
+}

@@ -1,0 +1,200 @@
+/* gandalf_hip.h -- C ABI of libgandalf_hip.so: the MI355X (gfx950) replacement for GANDALF's
+ * grad-h SPH + KD-tree gravity hot path.
+ *
+ * The reference (SJaffa/gandalf v0.4.0) has no FFI for this path: its seam is the set of C++
+ * virtual interfaces picked by string parameters in GradhSphSimulation::ProcessSphParameters
+ * (reference src/GradhSph/GradhSphSimulation.cpp:129-246).  Each entry point below names the
+ * reference member function(s) it replaces.  A reference-side shell class that binds them is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every pointer is a HOST pointer unless the
+ *     name ends in _dev.
+ *   - all entry points are synchronous at return and must be called from one host thread per
+ *     context (the reference's callers are serial: SphSimulation::MainLoop).
+ *   - return value: 0 ok, >0 recoverable (GH_ERR_CAPACITY ...), <0 fatal; gh_last_error() gives
+ *     the message (the host shell maps fatal codes to ExceptionHandler::raise, Exception.cpp:50).
+ *   - particle arrays cross the boundary in the caller's order ("iorig order"); the library keeps
+ *     its own tree-ordered SoA copy on the device.
+ *   - precision: double only (reference PRECISION=DOUBLE, Precision.h:44-50).
+ */
+#ifndef GANDALF_HIP_H
+#define GANDALF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gh_ctx gh_ctx;
+
+enum { GH_OK = 0, GH_ERR_CAPACITY = 1, GH_ERR_NOTCONVERGED = 2,
+       GH_ERR_INVALID = -1, GH_ERR_HIP = -2, GH_ERR_UNSUPPORTED = -3 };
+
+/* boundary types per face (reference DomainBox.h boundaryEnum: open / periodic / mirror / wall) */
+enum { GH_BOUNDARY_OPEN = 0, GH_BOUNDARY_PERIODIC = 1 };
+/* kernels (reference SmoothingKernel.h: M4Kernel :101-240, QuinticKernel :251-408) */
+enum { GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1 };
+/* gas_eos (reference EOS.h; energy_eqn = AdiabaticEOS.cpp, isothermal = IsothermalEOS.cpp,
+ * barotropic = BarotropicEOS.cpp) */
+enum { GH_EOS_ENERGY_EQN = 0, GH_EOS_ISOTHERMAL = 1, GH_EOS_BAROTROPIC = 2 };
+/* avisc / acond (reference Sph.h aviscenum, acondenum) */
+enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1 };
+enum { GH_ACOND_NONE = 0, GH_ACOND_WADSLEY2008 = 1, GH_ACOND_PRICE2008 = 2 };
+/* multipole / gravity_mac (reference Tree.h MAC_Type; NeighbourSearch.h:350-475) */
+enum { GH_MULTIPOLE_MONOPOLE = 0, GH_MULTIPOLE_QUADRUPOLE = 1 };
+enum { GH_MAC_GEOMETRIC = 0 };
+
+/* Parameter block: the hot-path subset of the reference's parameter file
+ * (Parameters.cpp:160-520; key names in comments). */
+typedef struct gh_config {
+  int32_t ndim;            /* ndim: 1, 2 or 3 */
+  int32_t kernel;          /* kernel = m4 | quintic      (tabulated_kernel must be 0) */
+  int32_t gas_eos;         /* gas_eos */
+  int32_t avisc;           /* avisc */
+  int32_t acond;           /* acond */
+  int32_t self_gravity;    /* self_gravity */
+  int32_t hydro_forces;    /* hydro_forces */
+  int32_t multipole;       /* multipole */
+  int32_t gravity_mac;     /* gravity_mac */
+  int32_t Nleafmax;        /* Nleafmax */
+  int32_t energy_integration; /* 1 if gas_eos = energy_eqn and energy_integration != none */
+  int32_t device;          /* HIP device ordinal */
+  int32_t boundary_lhs[3]; /* boundary_lhs[k] */
+  int32_t boundary_rhs[3]; /* boundary_rhs[k] */
+  double  boxmin[3];       /* boxmin[k] */
+  double  boxmax[3];       /* boxmax[k] */
+  double  h_fac;           /* h_fac */
+  double  h_converge;      /* h_converge */
+  double  alpha_visc;      /* alpha_visc */
+  double  beta_visc;       /* beta_visc */
+  double  gamma_eos;       /* gamma_eos */
+  double  temp0;           /* temp0   (isothermal / barotropic) */
+  double  mu_bar;          /* mu_bar */
+  double  rho_bary;        /* rho_bary (barotropic) */
+  double  thetamaxsqd;     /* thetamaxsqd */
+  double  courant_mult;    /* courant_mult */
+  double  accel_mult;      /* accel_mult */
+  double  energy_mult;     /* energy_mult */
+} gh_config;
+
+/* field ids for gh_download / gh_upload_field (values are per particle; vectors are [N][ndim]) */
+enum {
+  GH_F_R = 0, GH_F_V, GH_F_A, GH_F_ATREE, GH_F_R0, GH_F_V0, GH_F_A0,          /* vectors */
+  GH_F_M, GH_F_H, GH_F_U, GH_F_U0, GH_F_DUDT, GH_F_DUDT0, GH_F_RHO, GH_F_INVOMEGA, GH_F_ZETA,
+  GH_F_HFACTOR, GH_F_HRANGESQD, GH_F_SOUND, GH_F_PRESSURE, GH_F_DIV_V, GH_F_GPOT, GH_F_GPOT_HYDRO,
+  GH_F_ALPHA, GH_F_DALPHADT, GH_F_DT, GH_F_DT_NEXT, GH_F_TLAST,                 /* scalars */
+  GH_F_COUNT
+};
+
+/* per-call statistics the roofline accounting is computed from */
+typedef struct gh_stats {
+  int64_t n_particles;     /* particles processed */
+  int64_t n_iterations;    /* density: sum over particles of h-iterations executed */
+  int64_t n_candidates;    /* density: sum over particles and iterations of candidates inside the
+                              reference's (kernrange*hmax)^2 cull (GradhSphTree.cpp:205-219);
+                              forces: hydro pairs evaluated */
+  int64_t n_direct;        /* gravity: direct (Newtonian) particle interactions */
+  int64_t n_cells;         /* gravity: cell (multipole) interactions */
+  int64_t n_retries;       /* density: groups redone with a larger search radius */
+  double  kernel_ms;       /* device time of the dominant kernel of the call (hipEvent) */
+} gh_stats;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+/* replaces: new GradhSph<ndim,Kernel> + new GradhSphTree + new SphLeapfrogKDK
+ * (GradhSphSimulation.cpp:131-246) */
+int gh_create(const gh_config *cfg, gh_ctx **out);
+void gh_destroy(gh_ctx *ctx);
+const char *gh_last_error(const gh_ctx *ctx);
+
+/* ---- particle data ------------------------------------------------------------------------ */
+/* replaces: GradhSph::AllocateMemory + the IC copy loop (GradhSph.cpp:83-111, e.g. UniformIc.cpp:118-129).
+ * r, v: [N][ndim]; m, h, u: [N].  v, u may be NULL (zeros). Sets r0=r, v0=v, a=0, alpha=alpha_visc,
+ * iorig=i, all particles active (SphSimulation.cpp:245-256). */
+int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, const double *v, const double *m,
+                        const double *h, const double *u);
+/* overwrite one field (caller order) -- used to restart from / compare with reference snapshots */
+int gh_upload_field(gh_ctx *ctx, int field, const double *src);
+/* replaces: reading sph->GetSphParticleArray() (Sph.h:139).  dst is [N] or [N][ndim], caller order */
+int gh_download(gh_ctx *ctx, int field, double *dst);
+int64_t gh_num_particles(const gh_ctx *ctx);
+
+/* ---- tree --------------------------------------------------------------------------------- */
+/* replaces: HydroTree::BuildTree(rebuild=true,...) -> KDTree::BuildTree + StockTree
+ * (HydroTree.cpp:310-372, KDTree.cpp:220-313, 442-595, 808-1083).  Reorders the device copy of the
+ * particles into tree order. */
+int gh_build_tree(gh_ctx *ctx);
+/* tree export for parity tests, in the reference's pre-order cell numbering (KDTree.cpp:362-433).
+ * Any pointer may be NULL.  Ncell = 2*gtot-1.  cell_first/cell_N index the `order` array:
+ * order[cell_first[c] .. +cell_N[c]) are the caller-order ids of the particles of cell c. */
+int gh_tree_size(gh_ctx *ctx, int32_t *Ncell, int32_t *ltot, int32_t *gtot);
+int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_first, int32_t *cell_N,
+                   double *bbmin, double *bbmax, double *hboxmin, double *hboxmax, double *rcell,
+                   double *com, double *mass, double *rmax, double *hmax, double *cdistsqd,
+                   int32_t *order);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* replaces: GradhSphTree::UpdateAllSphProperties -> GradhSph::ComputeH + ComputeThermalProperties
+ * + KDTree::UpdateHmaxValues (GradhSphTree.cpp:83-271, GradhSph.cpp:142-347, KDTree.cpp:1128).
+ * Periodic images are made on the fly instead of materialising ghost particles
+ * (replaces HydroTree::SearchBoundaryGhostParticles/BuildGhostTree, HydroTree.cpp:382-543). */
+int gh_update_density(gh_ctx *ctx, gh_stats *stats);
+/* replaces: Sph::ZeroAccelerations (Sph.cpp:126-140) */
+int gh_zero_accelerations(gh_ctx *ctx);
+/* replaces: GradhSphTree::UpdateAllSphHydroForces -> Tree::ComputeNeighbourAndGhostList,
+ * NeighbourManager::EndSearch/GetParticleNeib, GradhSph::ComputeSphHydroForces
+ * (GradhSphTree.cpp:280-435, Tree.cpp:562-617, NeighbourManager.h:368-543, GradhSph.cpp:361-460) */
+int gh_update_hydro_forces(gh_ctx *ctx, gh_stats *stats);
+/* replaces: GradhSphTree::UpdateAllSphForces -> Tree::ComputeGravityInteractionAndGhostList,
+ * GradhSph::ComputeSphHydroGravForces/ComputeDirectGravForces, ComputeCellMonopoleForces
+ * (GradhSphTree.cpp:444-657, Tree.cpp:628-735, GradhSph.cpp:474-690, NeighbourSearch.h:350-377) */
+int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats);
+
+/* ---- leapfrog KDK glue --------------------------------------------------------------------- */
+/* replaces: SphLeapfrogKDK::AdvanceParticles (SphLeapfrogKDK.cpp:76-127) + CheckBoundaries */
+int gh_kdk_advance(gh_ctx *ctx, int n, double t, double timestep);
+/* replaces: Simulation::ComputeGlobalTimestep + SphIntegration::Timestep
+ * (Simulation.cpp:1669-1754, SphIntegration.cpp:81-134); sets dt_next of every particle */
+int gh_compute_global_timestep(gh_ctx *ctx, double *dt_min);
+/* replaces: SphLeapfrogKDK::EndTimestep (SphLeapfrogKDK.cpp:219-272) */
+int gh_kdk_end(gh_ctx *ctx, int n, double t, double timestep);
+
+/* ---- whole steps --------------------------------------------------------------------------- */
+/* replaces: the force part of SphSimulation::PostInitialConditionsSetup (SphSimulation.cpp:204-565):
+ * tree + density twice (three times if the caller's h is only InitialSmoothingLengthGuess, Sph.cpp:76-119,
+ * i.e. initial_h_provided = 0), forces, first timestep, KDK end. */
+int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep);
+/* set the simulation clock (reference SimulationBase::t, ::timestep) - used when a run is continued
+ * from a state uploaded field by field */
+int gh_set_time(gh_ctx *ctx, double t, double timestep);
+/* replaces: SphSimulation::MainLoop (SphSimulation.cpp:574-880) for Nlevels=1, no stars/sinks.
+ * Runs nsteps steps without returning to the host in between. */
+int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep);
+
+/* ---- queries for parity tests -------------------------------------------------------------- */
+/* replaces: NeighbourSearch::GetGatherNeighbourList (HydroTree.cpp / Tree.cpp:208-280): ids (caller
+ * order) of particles with |r_j - r_i|^2 < (kernrange*h_i)^2 for every i, CSR form.
+ * offsets: [N+1]; ids: [cap]; returns GH_ERR_CAPACITY (and the needed size in offsets[N]) if
+ * cap is too small. */
+int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, int32_t *ids);
+/* device time (ms) spent in each phase since the last call to gh_reset_timers, reference block
+ * names (CodeTiming: BUILD_TREE, SPH_PROPERTIES, SPH_HYDRO_FORCES / SPH_ALL_FORCES, KDK) */
+enum { GH_T_BUILD_TREE = 0, GH_T_SPH_PROPERTIES, GH_T_SPH_FORCES, GH_T_KDK, GH_T_COUNT };
+int gh_get_timers(gh_ctx *ctx, double *ms /* [GH_T_COUNT] */, gh_stats *density, gh_stats *forces);
+int gh_reset_timers(gh_ctx *ctx);
+
+/* ---- multi-GPU (one process per GPU) ---------------------------------------- */
+/* Work sharding: rank `rank` of `nranks` computes density/forces only for its contiguous slice of
+ * tree groups; the caller all-gathers the result slices (RCCL via torch.distributed) through the
+ * device pointers below.  With nranks=1 (default) nothing changes. */
+int gh_set_shard(gh_ctx *ctx, int rank, int nranks);
+/* particle range [first, first+count) (tree order) owned by a rank after the last gh_build_tree */
+int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count);
+/* device pointer of a field's tree-ordered storage: component k of a vector field, k=0 for scalars */
+void *gh_field_dev(gh_ctx *ctx, int field, int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANDALF_HIP_H */

@@ -121,7 +121,7 @@ static void dump_tree(Dump &out, Simulation<ndim> *sim)
 }
 
 // gather neighbour ids of every particle inside kernrange*h_i, through the reference's own
-// point search (NeighbourSearch::GetGatherNeighbourList, HydroTree.cpp) -- real particles only.
+// point search (HydroTree::GetGatherNeighbourList, HydroTree.cpp:451-471: real + periodic-ghost trees).
 template <int ndim>
 static void dump_gather_lists(Dump &out, Simulation<ndim> *sim)
 {
@@ -138,7 +138,7 @@ static void dump_gather_lists(Dump &out, Simulation<ndim> *sim)
     while ((nn = sim->sphneib->GetGatherNeighbourList(rp, sph->kernp->kernrange*p[i].h, p, N, cap, buf.data())) < 0) {
       cap *= 2; buf.resize(cap);
     }
-    ids.insert(ids.end(), buf.begin(), buf.begin() + nn);
+    for (int k = 0; k < nn; k++) ids.push_back(p[buf[k]].iorig);   // periodic ghosts -> id of their parent
     offs[i+1] = (int) ids.size();
   }
   out.i("gather_offsets", offs);

@@ -1,0 +1,138 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the reference's own outputs
+(tests/golden/*.npz, written by scripts/make_golden.py from the compiled reference).
+
+Tolerances: tree membership and neighbour ids exact; h, rho <= 1e-12 relative;
+forces <= 1e-11 relative to max(|a_i|, mean|a|)."""
+import numpy as np
+import pytest
+
+from conftest import PARAMS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["box3d_4k", "plummer_4k"]
+
+
+def make(case):
+    import gandalf_amd
+    from gandalf_amd.params import read_params_file
+    p = read_params_file("%s/%s.dat" % (PARAMS, case))
+    return gandalf_amd.GandalfHip(p), p
+
+
+def relerr(a, b, floor=0.0):
+    a = np.asarray(a); b = np.asarray(b)
+    return np.max(np.abs(a - b)/np.maximum(np.abs(b), floor + 1e-300))
+
+
+def vec_err(a, b):
+    """max |a-b| relative to max(|b_i|, mean|b|) per particle (vector fields)."""
+    nb = np.linalg.norm(b.reshape(len(b), -1), axis=1)
+    scale = np.maximum(nb, nb.mean())
+    return np.max(np.linalg.norm((a - b).reshape(len(b), -1), axis=1)/scale)
+
+
+def ref_leaf_sets(g):
+    """particle id sets of every reference cell, from the dumped linked lists"""
+    ifirst, ilast, N = g["tree_cell_ifirst"], g["tree_cell_ilast"], g["tree_cell_N"]
+    inext = g["tree_inext"]
+    level = g["tree_cell_level"]
+    ltot = int(g["tree_tree_Ncell_ltot_gtot_Ntot_Nleafmax"][1])
+    out = {}
+    for c in np.nonzero(level == ltot)[0]:
+        ids = []
+        i = ifirst[c]
+        while i != -1:
+            ids.append(int(i))
+            if i == ilast[c]:
+                break
+            i = inext[i]
+        assert len(ids) == N[c]
+        out[int(c)] = frozenset(ids)
+    return out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tree_matches_reference(case):
+    g = load_golden(case + "_passes")
+    sim, _ = make(case)
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.build_tree()
+    t = sim.export_tree()
+    ncell, ltot, gtot = [int(x) for x in g["tree_tree_Ncell_ltot_gtot_Ntot_Nleafmax"][:3]]
+    assert (t["Ncell"], t["ltot"], t["gtot"]) == (ncell, ltot, gtot)
+    assert np.array_equal(t["level"], g["tree_cell_level"])
+    assert np.array_equal(t["N"], g["tree_cell_N"])
+    # identical particle sets in every leaf cell (and therefore in every cell)
+    ref = ref_leaf_sets(g)
+    for c, ids in ref.items():
+        mine = frozenset(int(x) for x in t["order"][t["first"][c]:t["first"][c] + t["N"][c]])
+        assert mine == ids, "leaf cell %d differs" % c
+    # stocked cell properties
+    for mine, refk in [("bbmin", "cell_bbmin"), ("bbmax", "cell_bbmax"), ("hboxmin", "cell_hboxmin"),
+                       ("hboxmax", "cell_hboxmax"), ("rcell", "cell_rcell")]:
+        assert np.array_equal(t[mine], g["tree_" + refk]), mine
+    assert np.array_equal(t["hmax"], g["tree_cell_hmax"])
+    assert relerr(t["rmax"], g["tree_cell_rmax"]) < 1e-15
+    assert relerr(t["cdistsqd"], g["tree_cell_cdistsqd"]) < 1e-15
+    assert relerr(t["m"], g["tree_cell_m"]) < 1e-14
+    assert np.max(np.abs(t["com"] - g["tree_cell_r"])) < 1e-14*max(1.0, np.abs(g["tree_cell_r"]).max())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_density_and_forces_match_reference(case):
+    g = load_golden(case + "_passes")
+    sim, p = make(case)
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.build_tree()
+    st = sim.update_density(stats=True)
+    assert st["n_iterations"] >= st["n_particles"]
+    for name in ["h", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound", "pressure", "u"]:
+        e = relerr(sim.download(name), g["dens_" + name], floor=1e-30 if name != "zeta" else np.abs(g["dens_zeta"]).mean())
+        assert e < 1e-12, (name, e)
+    # hmax / hbox refreshed in the tree (KDTree::UpdateHmaxValues)
+    t = sim.export_tree()
+    assert relerr(t["hmax"], g["dens_cell_hmax"]) < 1e-12
+    # neighbour ids: exact given the reference's h
+    sim.upload_field("h", g["dens_h"])
+    offs, ids = sim.gather_neighbours()
+    ro, ri = g["dens_gather_offsets"], g["dens_gather_ids"]
+    assert np.array_equal(np.diff(offs), np.diff(ro)), "gather neighbour counts differ"
+    for i in range(len(ro) - 1):
+        assert np.array_equal(np.sort(ids[offs[i]:offs[i + 1]]), np.sort(ri[ro[i]:ro[i + 1]])), i
+    # force pass on the density state the GPU itself produced
+    sim.upload_field("h", sim.download("h"))
+    sim.zero_accelerations()
+    fst = sim.update_forces(stats=True)
+    assert fst["n_candidates"] > 0
+    assert vec_err(sim.download("a"), g["force_a"]) < 1e-11
+    for name in ["dudt", "div_v"]:
+        ref = g["force_" + name]
+        e = np.max(np.abs(sim.download(name) - ref))/max(np.abs(ref).mean(), 1e-300)
+        assert e < 1e-10, (name, e)
+    if int(p.get("self_gravity", 0)):
+        assert vec_err(sim.download("atree"), g["force_atree"]) < 1e-11
+        assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
+        assert fst["n_cells"] > 0 and fst["n_direct"] > 0
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_steps_match_reference(case):
+    """three full MainLoop steps from the reference's post-setup state"""
+    g = load_golden(case + "_steps")
+    sim, _ = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    sim.upload(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
+        sim.upload_field(k, s(k))
+    t0, dt0 = s("t_timestep")
+    sim.set_time(float(t0), float(dt0))
+    t, dt = sim.step(int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert abs(t - tf) <= 1e-12*abs(tf)
+    assert abs(dt - dtf) <= 1e-9*abs(dtf)
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-11*np.abs(g["final_r"]).max()
+    assert relerr(sim.download("h"), g["final_h"]) < 1e-10
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
+    assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
+    assert relerr(sim.download("u"), g["final_u"]) < 1e-10
