@@ -66,8 +66,8 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
   if (flags) {
     GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
     std::string m = std::string(where) + ":";
-    if (flags & FLAG_FRONTIER_OVERFLOW) m += " tree-walk frontier overflow (GH_FCAP)";
-    if (flags & FLAG_LEAFLIST_OVERFLOW) m += " candidate leaf list overflow (GH_LCAP)";
+    if (flags & FLAG_FRONTIER_OVERFLOW) m += " tree-walk stack overflow (GH_SCAP)";
+    if (flags & FLAG_LEAFLIST_OVERFLOW) m += " candidate list overflow";
     if (flags & FLAG_ILIST_OVERFLOW) m += " interaction list overflow";
     if (flags & FLAG_H_NOT_CONVERGED) m += " h-rho iteration did not converge (GradhSph.cpp:249)";
     ctx->err = m;
@@ -578,8 +578,7 @@ extern "C" void *gh_field_dev(gh_ctx *ctx, int field, int k)
 __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain dom, double kernrange, int pass,
                                                           const long long *offsets, long long *counts, int *ids, int *flags)
 {
-  __shared__ int s_front[2][GH_FCAP];
-  __shared__ unsigned long long s_leaf[GH_LCAP];
+  __shared__ WalkLDS<int> L;
   __shared__ double s_x[64], s_y[64], s_z[64];
   __shared__ int s_id[64];
   const int lane = threadIdx.x;
@@ -602,34 +601,30 @@ __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain d
     hi[k] = k < d.ndim ? gb.bbmax[k] + kernrange*hs : 1e300;
   }
   const unsigned int codes = image_codes(dom, d.ndim, lo, hi);
-  auto pred = [&](int n, const double sh[3]) -> bool {
-    const CellBox &b = d.cbox[n];
-    for (int k = 0; k < d.ndim; k++) {
-      if (lo[k] > b.bbmax[k] + sh[k]) return false;
-      if (b.bbmin[k] + sh[k] > hi[k]) return false;
-    }
-    return true;
-  };
-  const int nleaf = walk_collect_leaves(d, dom, codes, pred, s_front, s_leaf, flags);
-  const int occ = d.leafocc, lpt = 64/occ, ls = lane/occ, kk = lane - ls*occ;
-  const int ntiles = (nleaf + lpt - 1)/lpt;
   const int myorig = d.iorig[i];
   long long cnt = 0;
   const long long base = pass ? offsets[myorig] : 0;
-  for (int t = 0; t < ntiles; t++) {
+  auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &c) {
+    const int cn = d.cN[n];
+    if (cn == 0) return;
+    double sh[3];
+    code_shift(dom, code, sh);
+    const CellBox &b = d.cbox[n];
+    for (int k = 0; k < d.ndim; k++) {
+      if (lo[k] > b.bbmax[k] + sh[k]) return;
+      if (b.bbmin[k] + sh[k] > hi[k]) return;
+    }
+    if (n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; c = cn; }
+    else open = true;
+  };
+  auto tile = [&](bool valid, int j, int code) {
     double x = 1e30, y = 1e30, z = 1e30; int id = -1;
-    const int li = t*lpt + ls;
-    if (ls < lpt && li < nleaf) {
-      const unsigned long long e = s_leaf[li];
-      const int first = (int) (e & 0xffffffffu), c = (int) ((e >> 32) & 0xff), code = (int) ((e >> 40) & 0xff);
-      if (kk < c) {
-        double sh[3]; code_shift(dom, code, sh);
-        const int j = first + kk;
-        x = d.f[D_RX][j] + sh[0];
-        y = d.ndim > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
-        z = d.ndim > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
-        id = d.iorig[j];
-      }
+    if (valid) {
+      double sh[3]; code_shift(dom, code, sh);
+      x = d.f[D_RX][j] + sh[0];
+      y = d.ndim > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
+      z = d.ndim > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
+      id = d.iorig[j];
     }
     s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_id[lane] = id;
     __syncthreads();
@@ -646,7 +641,8 @@ __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain d
       }
     }
     __syncthreads();
-  }
+  };
+  walk_dfs_stream(d, L, codes, cls, tile, flags);
   if (act && !pass) counts[myorig] = cnt;
 }
 

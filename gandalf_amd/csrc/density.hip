@@ -4,16 +4,17 @@
 // (reference src/GradhSph/GradhSphTree.cpp:83-271, src/GradhSph/GradhSph.cpp:142-347).
 //
 // Mapping: one wavefront per group (<= 64 particles of one small KD subtree), one lane per target
-// particle.  The wave walks the tree once for the whole group (walk.hpp), then for every h-iteration
-// streams the candidate leaves through a 64-entry SoA tile in LDS:
+// particle.  For every h-iteration the wave walks the tree for the whole group and streams the candidate
+// particles through a 64-entry SoA tile in LDS:
 //   phase 1: every lane tests all 64 tile entries (LDS broadcast reads) and builds a 64-bit mask of
 //            the entries inside its kernel support;
 //   phase 2: every lane walks its own mask and evaluates the three kernel sums only for those.
-// The h fixed-point iteration of ComputeH runs per lane with the reference's exact state machine
-// (30 fixed-point steps, then bisection, GradhSph.cpp:184-257).  Where the reference returns 0 ("h grew
-// beyond the candidate list", :255) and redoes the whole cell with hmax*1.05, the wave enlarges its
-// search radius, re-walks and CONTINUES the affected lanes from the iterate that overflowed - the
-// iterates are the same numbers because every earlier iterate was summed over a complete list.
+// The h fixed-point iteration of ComputeH runs per lane with the reference's state machine (30 fixed-point
+// steps, then bisection, GradhSph.cpp:184-257).  Every iteration re-walks the tree (streaming depth-first
+// walk, walk.hpp) with a search volume that covers kernrange*h of every lane still iterating, so there
+// is no candidate list to overflow: where the reference returns 0 ("h grew beyond the candidate list",
+// :255) and redoes the whole cell with hmax*1.05, the wave simply continues - the iterates are the same
+// numbers because every iterate is summed over a complete list.
 #include "gh_internal.hpp"
 #include "sph_kernels.hpp"
 #include "walk.hpp"
@@ -29,8 +30,7 @@ template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
-  __shared__ int s_front[2][GH_FCAP];
-  __shared__ unsigned long long s_leaf[GH_LCAP];
+  __shared__ WalkLDS<int> L;
   __shared__ double s_x[64], s_y[64], s_z[64], s_m[64];
 
   const int lane = threadIdx.x;
@@ -45,154 +45,137 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   double ri[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < ND; k++) ri[k] = d.f[D_RX + k][i];
   const double mi = d.f[D_M][i];
-  const double h0 = d.f[D_H][i];
   double ui = d.f[D_U][i];
-
   const CellBox gb = d.cbox[gnode];
-  double hsearch = 1.05*d.cgrav[gnode].hmax;
-
-  // leaf slot / particle-in-leaf this lane loads when a tile is staged
-  const int occ = d.leafocc;
-  const int lpt = 64/occ;                 // leaves per tile
-  const int ls = lane/occ, kk = lane - ls*occ;
+  const double hfirst = 1.05*d.cgrav[gnode].hmax;      // the reference's first search radius (hmax*1.05)
 
   // per-lane iteration state (GradhSph.cpp:148-158)
-  double h = h0, hlo = 0.0, hup = hsearch;
+  double h = d.f[D_H][i], hlo = 0.0, hup = hfirst;
   int iter = 0;
-  bool done = !act, fail = false;
+  bool done = !act;
   double rho = 0.0, omg = 0.0, zet = 0.0;
+  double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
   unsigned long long n_iter = 0, n_cand = 0, n_retry = 0;
   // reference cull radius of the first try, for the candidate statistic: kernrange*1.05*hmax(leaf)
   double cullsqd = 0.0;
   if (COUNT) {
-    // leaf of this lane: walk down from the group node by position
     int n = gnode;
     while (n < d.gtot - 1) { const int c2 = 2*n + 2; n = (i >= d.cfirst[c2]) ? c2 : 2*n + 1; }
     const double hm = 1.05*d.cgrav[n].hmax;
     cullsqd = K::kernrangesqd*hm*hm;
   }
 
+  // ---- h iteration (GradhSph.cpp:184-257); every pass re-walks the tree with the radius it needs
   for (;;) {
-    // ---- candidate leaves for the current search radius (Tree.cpp:319-328: box = bb +/- kernrange*hmax)
+    const bool running = !done;
+    if (!__any(running)) break;
+    // the search volume covers kernrange*h of every lane still iterating (Tree.cpp:319-328 uses
+    // bb +/- kernrange*hmax; where the reference's hmax is too small it retries with hmax*1.05)
+    const double hs = fmax(wave_max(running ? h : 0.0), iter == 0 ? hfirst : 0.0);
+    if (hs > hfirst && running && h > hfirst) n_retry++;
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-      lo[k] = k < ND ? gb.bbmin[k] - K::kernrange*hsearch : -1e300;
-      hi[k] = k < ND ? gb.bbmax[k] + K::kernrange*hsearch : 1e300;
+      lo[k] = k < ND ? gb.bbmin[k] - K::kernrange*hs : -1e300;
+      hi[k] = k < ND ? gb.bbmax[k] + K::kernrange*hs : 1e300;
+    }
+    if (running) {
+      iter++; n_iter++;
+      invh = 1.0/h;
+      hfactor = powN<ND>(invh);
+      invhsqd = invh*invh;
+      rho = 0.0; omg = 0.0; zet = 0.0;
+      if (hup < hs) hup = hs;
     }
     const unsigned int codes = image_codes(P.dom, ND, lo, hi);
-    auto pred = [&](int n, const double sh[3]) -> bool {
+    auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
+      const int cn = d.cN[n];
+      if (cn == 0) return;
+      double sh[3];
+      code_shift(P.dom, code, sh);
       const CellBox &b = d.cbox[n];
+      bool inside = true;
       for (int k = 0; k < ND; k++) {
-        if (lo[k] > b.bbmax[k] + sh[k]) return false;     // BoxOverlap, InlineFuncs.h:362-390 (inclusive)
-        if (b.bbmin[k] + sh[k] > hi[k]) return false;
+        const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
+        if (lo[k] > bmax) return;                         // BoxOverlap, InlineFuncs.h:362-390 (inclusive)
+        if (bmin > hi[k]) return;
+        if (bmin < lo[k] || bmax > hi[k]) inside = false;
       }
-      return true;
+      if (inside || n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; cnt = cn; }
+      else open = true;
     };
-    const int nleaf = walk_collect_leaves(d, P.dom, codes, pred, s_front, s_leaf, flags);
-    const int ntiles = (nleaf + lpt - 1)/lpt;
-
-    // ---- h iteration (GradhSph.cpp:184-257)
-    for (;;) {
-      const bool running = !done && !fail;
-      if (!__any(running)) break;
-      double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
-      if (running) {
-        iter++; n_iter++;
-        invh = 1.0/h;
-        hfactor = powN<ND>(invh);
-        invhsqd = invh*invh;
-        rho = 0.0; omg = 0.0; zet = 0.0;
-      }
-      for (int t = 0; t < ntiles; t++) {
-        // stage one tile: lpt leaves x occ slots
-        {
-          double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
-          const int li = t*lpt + ls;
-          if (ls < lpt && li < nleaf) {
-            const unsigned long long e = s_leaf[li];
-            const int first = (int) (e & 0xffffffffu), cnt = (int) ((e >> 32) & 0xff), code = (int) ((e >> 40) & 0xff);
-            if (kk < cnt) {
-              const double4 v = d.posm[first + kk];
-              double sh[3];
-              code_shift(P.dom, code, sh);
-              x = v.x + sh[0]; y = v.y + sh[1]; z = v.z + sh[2]; m = v.w;
-            }
-          }
-          s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_m[lane] = m;
+    auto tile = [&](bool valid, int j, int code) {
+      {
+        double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
+        if (valid) {
+          const double4 v = d.posm[j];
+          double sh[3];
+          code_shift(P.dom, code, sh);
+          x = v.x + sh[0]; y = v.y + sh[1]; z = v.z + sh[2]; m = v.w;
         }
-        __syncthreads();
-        // phase 1: support mask
-        unsigned long long mask = 0;
-        if (running) {
+        s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_m[lane] = m;
+      }
+      __syncthreads();
+      // phase 1: support mask
+      unsigned long long mask = 0;
+      if (running) {
 #pragma unroll 16
-          for (int c = 0; c < 64; c++) {
-            double r2 = 0.0;
-            { const double dx = s_x[c] - ri[0]; r2 = dx*dx; }
-            if (ND > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
-            if (ND > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
-            if (invhsqd*r2 < K::kernrangesqd) mask |= 1ull << c;
-            if (COUNT) { if (r2 + GH_SMALL <= cullsqd) n_cand++; }
-          }
+        for (int c = 0; c < 64; c++) {
+          double r2 = 0.0;
+          { const double dx = s_x[c] - ri[0]; r2 = dx*dx; }
+          if (ND > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
+          if (ND > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
+          if (invhsqd*r2 < K::kernrangesqd) mask |= 1ull << c;
+          if (COUNT) { if (r2 + GH_SMALL <= cullsqd) n_cand++; }
         }
-        // phase 2: kernel sums over the lane's own neighbours in this tile
-        while (__any(mask != 0ull)) {
-          if (mask != 0ull) {
-            const int c = __ffsll((long long) mask) - 1;
-            mask &= mask - 1ull;
-            double dr[3] = {0.0, 0.0, 0.0};
-            dr[0] = s_x[c] - ri[0];
-            if (ND > 1) dr[1] = s_y[c] - ri[1];
-            if (ND > 2) dr[2] = s_z[c] - ri[2];
-            const double mj = s_m[c];
-            double r2 = dr[0]*dr[0];
-            if (ND > 1) r2 += dr[1]*dr[1];
-            if (ND > 2) r2 += dr[2]*dr[2];
-            const double s = sqrt(invhsqd*r2);
-            rho += mj*K::w0(s);
-            omg += mj*invh*K::womega(s);
-            zet += mj*K::wzeta(s);
-          }
-        }
-        __syncthreads();
       }
-      if (running) {
-        rho *= hfactor; omg *= hfactor; zet *= invhsqd;
-        const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
-        if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
-        else {
-          if (iter < 30) h = hnew;
-          else if (iter == 30) h = 0.5*(hlo + hup);
-          else if (iter < 150) {
-            if (rho < GH_SMALL || h > hnew) hup = h; else hlo = h;
-            h = 0.5*(hlo + hup);
-          }
-          else { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
-          if (!done) {
-            if (!(h <= hsearch)) fail = true;                                // "return 0", GradhSph.cpp:255
-            else if (!(h > hlo && h < hup)) done = true;                     // loop exit, :257
-          }
+      // phase 2: kernel sums over the lane's own neighbours in this tile
+      while (__any(mask != 0ull)) {
+        if (mask != 0ull) {
+          const int c = __ffsll((long long) mask) - 1;
+          mask &= mask - 1ull;
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = s_x[c] - ri[0];
+          if (ND > 1) dr[1] = s_y[c] - ri[1];
+          if (ND > 2) dr[2] = s_z[c] - ri[2];
+          const double mj = s_m[c];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          const double s = sqrt(invhsqd*r2);
+          rho += mj*K::w0(s);
+          omg += mj*invh*K::womega(s);
+          zet += mj*K::wzeta(s);
+        }
+      }
+      __syncthreads();
+    };
+    walk_dfs_stream(d, L, codes, cls, tile, flags);
+
+    if (running) {
+      rho *= hfactor; omg *= hfactor; zet *= invhsqd;
+      const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
+      if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
+      else {
+        if (iter < 30) h = hnew;
+        else if (iter == 30) h = 0.5*(hlo + hup);
+        else if (iter < 150) {
+          if (rho < GH_SMALL || h > hnew) hup = h; else hlo = h;
+          h = 0.5*(hlo + hup);
+        }
+        else { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
+        if (!done) {
+          if (!isfinite(h)) { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
+          else if (iter >= 30 && !(h > hlo && h < hup)) done = true;         // loop exit, :257
         }
       }
     }
-    if (!__any(fail)) break;
-    // enlarge the search volume to cover the largest overflowing iterate and continue those lanes
-    const double hneed = wave_max(fail ? h : 0.0);
-    hsearch = 1.05*fmax(hsearch, isfinite(hneed) ? hneed : 2.0*hsearch);
-    if (fail && n_retry > 64) { atomicOr(flags, FLAG_H_NOT_CONVERGED); fail = false; done = true; }   // never spin
-    if (fail) {
-      n_retry++;
-      if (iter >= 30 || !isfinite(h)) { h = h0; iter = 0; hlo = 0.0; }      // bisection restarts with the new bound
-      hup = hsearch;
-      fail = false;
-    }
-    if (!fail && !done) hup = fmax(hup, hsearch);
   }
 
   // ---- normalise and store (GradhSph.cpp:262-317)
   if (act) {
     h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
-    const double invh = 1.0/h;
-    const double hfac1 = powN<ND>(invh)*invh;
+    const double invh1 = 1.0/h;
+    const double hfac1 = powN<ND>(invh1)*invh1;
     const double deriv = -invndim*h/rho;                                     // h_rho_deriv, Sph.h:264
     double invomega = 1.0 - deriv*omg;
     invomega = 1.0/invomega;

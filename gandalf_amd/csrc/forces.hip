@@ -14,7 +14,8 @@
 // 16-bit mask of the leaves that still descend through it.  Every classification of the reference's
 // walk is taken per (node, leaf) with the leaf's own rcell/rmax/hmax; accepted cells and near-field
 // particles go to LDS lists tagged with the mask of leaves they belong to, and are flushed through
-// broadcast LDS tiles: lanes whose leaf bit is clear skip the entry.
+// broadcast LDS tiles: lanes whose leaf bit is clear skip the entry.  The walks are the streaming
+// depth-first walks of walk.hpp (bounded LDS whatever the size of the interaction region).
 #include "gh_internal.hpp"
 #include "sph_kernels.hpp"
 #include "walk.hpp"
@@ -141,8 +142,7 @@ __device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
-  __shared__ int s_front[2][GH_FCAP];
-  __shared__ unsigned long long s_leaf[GH_LCAP];
+  __shared__ WalkLDS<int> L;
   __shared__ double s_t[T_NF][64];
 
   const int lane = threadIdx.x;
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
+  unsigned long long n_pairs = 0;
 
-  // candidate leaves: overlap(cell.bb, other.hbox) || overlap(cell.hbox, other.bb)   (Tree.cpp:579-580)
+  // candidate cells: overlap(cell.bb, other.hbox) || overlap(cell.hbox, other.bb)   (Tree.cpp:579-580)
   const CellBox gb = d.cbox[gnode];
   const double hr_root = M4<ND>::kernrange*d.cgrav[0].hmax;
   double lo[3], hi[3];
@@ -167,32 +168,27 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     hi[k] = k < ND ? fmax(gb.hbmax[k], gb.bbmax[k] + hr_root) : 1e300;
   }
   const unsigned int codes = image_codes(P.dom, ND, lo, hi);
-  auto pred = [&](int n, const double sh[3]) -> bool {
+  auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
+    const int cn = d.cN[n];
+    if (cn == 0) return;
+    double sh[3];
+    code_shift(P.dom, code, sh);
     const CellBox &b = d.cbox[n];
-    bool o1 = true, o2 = true;
+    bool o1 = true, o2 = true, inside = true;
     for (int k = 0; k < ND; k++) {
+      const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
       if (gb.bbmin[k] > b.hbmax[k] + sh[k] || b.hbmin[k] + sh[k] > gb.bbmax[k]) o1 = false;
-      if (gb.hbmin[k] > b.bbmax[k] + sh[k] || b.bbmin[k] + sh[k] > gb.hbmax[k]) o2 = false;
+      if (gb.hbmin[k] > bmax || bmin > gb.hbmax[k]) o2 = false;
+      if (bmin < gb.hbmin[k] || bmax > gb.hbmax[k]) inside = false;
     }
-    return o1 || o2;
+    if (!(o1 || o2)) return;
+    if (inside || n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; cnt = cn; }
+    else open = true;
   };
-  const int nleaf = walk_collect_leaves(d, P.dom, codes, pred, s_front, s_leaf, flags);
-
-  const int occ = d.leafocc;
-  const int lpt = 64/occ;
-  const int ls = lane/occ, kk = lane - ls*occ;
-  const int ntiles = (nleaf + lpt - 1)/lpt;
-  unsigned long long n_pairs = 0;
-
-  for (int t = 0; t < ntiles; t++) {
+  auto tile = [&](bool valid, int j, int code) {
     {
-      const int li = t*lpt + ls;
-      bool valid = false; int j = 0; double sh[3] = {0.0, 0.0, 0.0};
-      if (ls < lpt && li < nleaf) {
-        const unsigned long long e = s_leaf[li];
-        const int first = (int) (e & 0xffffffffu), cnt = (int) ((e >> 32) & 0xff), code = (int) ((e >> 40) & 0xff);
-        if (kk < cnt) { valid = true; j = first + kk; code_shift(P.dom, code, sh); }
-      }
+      double sh[3];
+      code_shift(P.dom, code, sh);
       stage_neib(d, ND, s_t, lane, j, sh, valid);
     }
     __syncthreads();
@@ -224,7 +220,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
       }
     }
     __syncthreads();
-  }
+  };
+  walk_dfs_stream(d, L, codes, cls, tile, flags);
 
   if (act) {
     // GradhSph.cpp:451-453 then GradhSphTree.cpp:396-404 (accumulate on the zeroed main array)
@@ -245,20 +242,17 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // ================================================================================================
 #define GH_MAXLEAF 16
 #define GH_CCAP 256          /* cell-interaction list capacity per flush */
-#define GH_PCAP 128          /* near-field leaf list capacity per flush */
 
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
-  __shared__ int s_fnode[2][GH_FCAP];
-  __shared__ unsigned short s_fmask[2][GH_FCAP];
+  __shared__ WalkLDS<int> L;                       // stack of nodes + ring of near-field particle ranges
+  __shared__ unsigned short s_smask[GH_SCAP];      // leaf mask of every stack entry
   __shared__ double s_cx[GH_CCAP], s_cy[GH_CCAP], s_cz[GH_CCAP], s_cm[GH_CCAP];
   __shared__ unsigned short s_cmask[GH_CCAP];
-  __shared__ int s_pfirst[GH_PCAP];
-  __shared__ unsigned short s_pcnt[GH_PCAP], s_phyd[GH_PCAP], s_pdir[GH_PCAP];
   __shared__ double s_t[T_NF][64];
-  __shared__ unsigned short s_thyd[64], s_tdir[64];
+  __shared__ int s_ttag[64];
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
@@ -281,7 +275,6 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     s_lhr[lane] = K::kernrange*g.hmax;
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
-  // leaf of this lane
   int myleaf = 0;
   for (int l = 1; l < nl; l++) if (i >= d.cfirst[leafnode0 + l]) myleaf = l;
   __syncthreads();
@@ -291,18 +284,13 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0;
-  A.gpot = (d.f[D_M][i]*ti.invh)*K::wpot(0.0);          // self term, GradhSphTree.cpp:512
+  A.gpot = (d.f[D_M][i]/d.f[D_H][i])*K::wpot(0.0);      // self term, GradhSphTree.cpp:512
   unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
 
-  const int occ = d.leafocc;
-  const int lpt = 64/occ;
-  const int ls = lane/occ, kk = lane - ls*occ;
-
-  int ncell = 0, npart = 0;
-
-  auto flush = [&]() {
+  int ncell = 0;
+  // ---- cells: monopole                                           (NeighbourSearch.h:350-377)
+  auto flush_cells = [&]() {
     __syncthreads();
-    // ---- cells: monopole                                         (NeighbourSearch.h:350-377)
     if (act) {
       for (int c = 0; c < ncell; c++) {
         if ((s_cmask[c] >> myleaf) & 1) {
@@ -324,54 +312,24 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         }
       }
     }
-    // ---- near-field particles, tile by tile
-    const int ntiles = (npart + lpt - 1)/lpt;
-    for (int t = 0; t < ntiles; t++) {
-      __syncthreads();
-      {
-        const int li = t*lpt + ls;
-        bool valid = false; int j = 0; const double sh[3] = {0.0, 0.0, 0.0};
-        unsigned short hm = 0, dm = 0;
-        if (ls < lpt && li < npart) {
-          if (kk < (int) s_pcnt[li]) { valid = true; j = s_pfirst[li] + kk; hm = s_phyd[li]; dm = s_pdir[li]; }
-        }
-        stage_neib(d, ND, s_t, lane, j, sh, valid);
-        s_thyd[lane] = hm; s_tdir[lane] = dm;
-      }
-      __syncthreads();
-      unsigned long long mask = 0;
-      if (act) {
+    __syncthreads();
+    ncell = 0;
+  };
+  // ---- near-field particles: tag = hydro-candidate leaf mask | direct leaf mask << 16
+  auto tile = [&](bool valid, int j, int tag) {
+    {
+      const double sh[3] = {0.0, 0.0, 0.0};
+      stage_neib(d, ND, s_t, lane, j, sh, valid);
+      s_ttag[lane] = valid ? tag : 0;
+    }
+    __syncthreads();
+    unsigned long long mask = 0;
+    if (act) {
 #pragma unroll 8
-        for (int c = 0; c < 64; c++) {
-          const bool hydc = (s_thyd[c] >> myleaf) & 1, dirc = (s_tdir[c] >> myleaf) & 1;
-          if (hydc || dirc) {
-            double dr[3] = {0.0, 0.0, 0.0};
-            dr[0] = s_t[T_X][c] - ti.r[0];
-            if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
-            if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
-            double r2 = dr[0]*dr[0];
-            if (ND > 1) r2 += dr[1]*dr[1];
-            if (ND > 2) r2 += dr[2]*dr[2];
-            // hydro candidate that is a real SPH neighbour, NeighbourManager.h:521-533
-            const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
-            if (sph) mask |= 1ull << c;
-            else {
-              // direct Newtonian term                               (GradhSph.cpp:671-686)
-              const double drsqd = r2 + GH_SMALL;
-              const double invdrmag = 1.0/sqrt(drsqd);
-              const double invdr3 = invdrmag*invdrmag*invdrmag;
-              const double mj = s_t[T_M][c];
-              for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*invdr3;
-              A.gpot += mj*invdrmag;
-              if (COUNT) n_direct++;
-            }
-          }
-        }
-      }
-      while (__any(mask != 0ull)) {
-        if (mask != 0ull) {
-          const int c = __ffsll((long long) mask) - 1;
-          mask &= mask - 1ull;
+      for (int c = 0; c < 64; c++) {
+        const int tg = s_ttag[c];
+        const bool hydc = (tg >> myleaf) & 1, dirc = (tg >> (16 + myleaf)) & 1;
+        if (hydc || dirc) {
           double dr[3] = {0.0, 0.0, 0.0};
           dr[0] = s_t[T_X][c] - ti.r[0];
           if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
@@ -379,85 +337,110 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
-          sph_pair<ND, true>(P, ti, A, s_t, c, dr, r2);
-          if (COUNT) n_pairs++;
+          // hydro candidate that is a real SPH neighbour, NeighbourManager.h:521-533
+          const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
+          if (sph) mask |= 1ull << c;
+          else {
+            // direct Newtonian term                               (GradhSph.cpp:671-686)
+            const double drsqd = r2 + GH_SMALL;
+            const double invdrmag = 1.0/sqrt(drsqd);
+            const double invdr3 = invdrmag*invdrmag*invdrmag;
+            const double mj = s_t[T_M][c];
+            for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*invdr3;
+            A.gpot += mj*invdrmag;
+            if (COUNT) n_direct++;
+          }
         }
       }
     }
+    while (__any(mask != 0ull)) {
+      if (mask != 0ull) {
+        const int c = __ffsll((long long) mask) - 1;
+        mask &= mask - 1ull;
+        double dr[3] = {0.0, 0.0, 0.0};
+        dr[0] = s_t[T_X][c] - ti.r[0];
+        if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
+        if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
+        double r2 = dr[0]*dr[0];
+        if (ND > 1) r2 += dr[1]*dr[1];
+        if (ND > 2) r2 += dr[2]*dr[2];
+        sph_pair<ND, true>(P, ti, A, s_t, c, dr, r2);
+        if (COUNT) n_pairs++;
+      }
+    }
     __syncthreads();
-    ncell = 0; npart = 0;
   };
 
-  // ---- breadth-first walk with per-leaf masks                     (Tree.cpp:648-731)
-  if (lane == 0) { s_fnode[0][0] = 0; s_fmask[0][0] = (unsigned short) allmask; }
+  // ---- depth-first walk with per-leaf masks                       (Tree.cpp:648-731)
+  if (lane == 0) { L.stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
+  RangeState R; R.nrb = 0; R.nslots = 0;
   __syncthreads();
-  int cur = 0, nfront = 1;
+  int top = 1;
   const int leaf0 = d.gtot - 1;
-  while (nfront > 0) {
-    int nnext = 0;
-    for (int base = 0; base < nfront; base += 64) {
-      if (ncell > GH_CCAP - 64 || npart > GH_PCAP - 64) flush();
-      const int idx = base + lane;
-      unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
-      int n = 0; bool isleaf = false;
-      CellGrav g;
-      g.first = 0; g.N = 0; g.m = 0.0;
-      for (int k = 0; k < 3; k++) g.com[k] = 0.0;
-      if (idx < nfront) {
-        n = s_fnode[cur][idx];
-        const unsigned int fm = s_fmask[cur][idx];
-        g = d.cgrav[n];
-        isleaf = n >= leaf0;
-        const double khr = K::kernrange*g.hmax;
-        for (int l = 0; l < nl; l++) {
-          if (!((fm >> l) & 1)) continue;
-          double drsqd = 0.0;
-          for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
-          const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
-          const double d2 = s_lrmax[l] + g.rmax + khr;
-          if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
-            if (!isleaf) openm |= 1u << l;
-            else if (g.N > 0) hydm |= 1u << l;
-          }
-          else if (g.N == 0) { }
-          else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
-            if (isleaf && g.N == 1) dirm |= 1u << l;
-            else cellm |= 1u << l;
-          }
-          else {
-            if (!isleaf) openm |= 1u << l;
-            else dirm |= 1u << l;
-          }
+  while (top > 0) {
+    if (ncell > GH_CCAP - 64) flush_cells();
+    const int p = top < 64 ? top : 64;
+    const int newtop = top - p;
+    unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
+    int n = 0; bool isleaf = false;
+    CellGrav g;
+    g.first = 0; g.N = 0; g.m = 0.0;
+    for (int k = 0; k < 3; k++) g.com[k] = 0.0;
+    if (lane < p) {
+      n = L.stack[top - 1 - lane];
+      const unsigned int fm = s_smask[top - 1 - lane];
+      g = d.cgrav[n];
+      isleaf = n >= leaf0;
+      const double khr = K::kernrange*g.hmax;
+      for (int l = 0; l < nl; l++) {
+        if (!((fm >> l) & 1)) continue;
+        double drsqd = 0.0;
+        for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
+        const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
+        const double d2 = s_lrmax[l] + g.rmax + khr;
+        if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
+          if (!isleaf) openm |= 1u << l;
+          else if (g.N > 0) hydm |= 1u << l;
+        }
+        else if (g.N == 0) { }
+        else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
+          if (isleaf && g.N == 1) dirm |= 1u << l;
+          else cellm |= 1u << l;
+        }
+        else {
+          if (!isleaf) openm |= 1u << l;
+          else dirm |= 1u << l;
         }
       }
-      const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0), pm = __ballot((hydm | dirm) != 0);
-      if (openm) {
-        const int pos = nnext + 2*__popcll(om & lt);
-        if (pos + 1 < GH_FCAP) {
-          s_fnode[cur ^ 1][pos] = 2*n + 1; s_fmask[cur ^ 1][pos] = (unsigned short) openm;
-          s_fnode[cur ^ 1][pos + 1] = 2*n + 2; s_fmask[cur ^ 1][pos + 1] = (unsigned short) openm;
-        }
-      }
-      nnext += 2*__popcll(om);
-      if (cellm) {
-        const int pos = ncell + __popcll(cm & lt);
-        s_cx[pos] = g.com[0]; s_cy[pos] = g.com[1]; s_cz[pos] = g.com[2]; s_cm[pos] = g.m;
-        s_cmask[pos] = (unsigned short) cellm;
-      }
-      ncell += __popcll(cm);
-      if (hydm | dirm) {
-        const int pos = npart + __popcll(pm & lt);
-        s_pfirst[pos] = g.first; s_pcnt[pos] = (unsigned short) g.N;
-        s_phyd[pos] = (unsigned short) hydm; s_pdir[pos] = (unsigned short) dirm;
-      }
-      npart += __popcll(pm);
     }
-    if (nnext > GH_FCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); nnext = GH_FCAP; }
+    const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0), pm = __ballot((hydm | dirm) != 0);
     __syncthreads();
-    cur ^= 1;
-    nfront = nnext;
+    if (openm) {
+      const int pos = newtop + 2*__popcll(om & lt);
+      if (pos + 1 < GH_SCAP) {
+        L.stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
+        L.stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
+      }
+    }
+    top = newtop + 2*__popcll(om);
+    if (top > GH_SCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); top = GH_SCAP; }
+    if (cellm) {
+      const int pos = ncell + __popcll(cm & lt);
+      s_cx[pos] = g.com[0]; s_cy[pos] = g.com[1]; s_cz[pos] = g.com[2]; s_cm[pos] = g.m;
+      s_cmask[pos] = (unsigned short) cellm;
+    }
+    ncell += __popcll(cm);
+    if (hydm | dirm) {
+      const int pos = R.nrb + __popcll(pm & lt);
+      L.rb_first[pos] = g.first; L.rb_cnt[pos] = g.N; L.rb_tag[pos] = (int) (hydm | (dirm << 16));
+    }
+    R.nrb += __popcll(pm);
+    R.nslots += wave_sum_i((hydm | dirm) ? g.N : 0);
+    if (R.nslots >= 64 || R.nrb > GH_RBCAP - 64) range_drain(L, R, false, tile);
+    else __syncthreads();
   }
-  flush();
+  flush_cells();
+  range_drain(L, R, true, tile);
 
   if (act) {
     // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619

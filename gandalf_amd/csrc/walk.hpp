@@ -8,8 +8,6 @@
 #pragma once
 #include "gh_internal.hpp"
 
-#define GH_FCAP 512          /* frontier capacity (nodes) per buffer */
-#define GH_LCAP 1024         /* leaf-list capacity (leaves) */
 #define GH_NODE_BITS 26
 #define GH_NODE_MASK ((1 << GH_NODE_BITS) - 1)
 
@@ -49,74 +47,131 @@ __device__ __forceinline__ void code_shift(const Domain &dom, int code, double s
   s[2] = c2 == 0 ? 0.0 : (c2 == 1 ? dom.size[2] : -dom.size[2]);
 }
 
-// leaf-list entry: first particle (32 bit) | count << 32 | image code << 40
-__device__ __forceinline__ unsigned long long make_leaf_entry(int first, int cnt, int code)
+// ------------------------------------------------------------------------------------------------
+// Streaming depth-first walk.
+//
+// The wave keeps a LIFO stack of tree nodes in LDS.  Each step pops up to 64 nodes (one per lane),
+// classifies them, pushes the children of the nodes that have to be opened and emits "ranges" -
+// contiguous runs of particles in tree order (a leaf, or a whole subtree that lies inside the search
+// volume) - into a small ring in LDS.  As soon as the ring holds 64 particle slots, they are mapped onto
+// the 64 lanes (prefix sum over the range lengths + binary search) and handed to the kernel's tile
+// function.  Nothing grows with the size of the search volume: the stack is bounded by ~128 entries per
+// tree level, the ring by its drain threshold.  (A breadth-first frontier or a stored candidate list
+// overflows for the outlier groups of a Plummer halo, whose search volume covers the whole system.)
+// ------------------------------------------------------------------------------------------------
+#define GH_SCAP 2560         /* stack capacity: > 128 * (ltot + 1) for ltot <= 18 */
+#define GH_RBCAP 192         /* range ring capacity */
+
+template <typename StackT> struct WalkLDS {
+  StackT stack[GH_SCAP];
+  int rb_first[GH_RBCAP], rb_cnt[GH_RBCAP], rb_tag[GH_RBCAP];
+  int pre[64];
+};
+
+__device__ __forceinline__ int wave_sum_i(int v)
 {
-  return (unsigned long long) (unsigned) first | ((unsigned long long) cnt << 32) | ((unsigned long long) code << 40);
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
 
-// Breadth-first walk: collects, in tree order, all non-empty leaves whose (image-shifted) cell passes
-// `pred(node, shift)`; interior nodes that pass are opened.  `codes` = bit mask of the image codes to
-// walk.  Returns the number of leaves (clamped to GH_LCAP; an overflow raises a flag).
-template <class Pred>
-__device__ int walk_collect_leaves(const DevicePtrs &d, const Domain &dom, unsigned int codes, Pred pred,
-                                   int (*s_front)[GH_FCAP], unsigned long long *s_leaf, int *flags)
+// State of the range ring between drains
+struct RangeState { int nrb, nslots; };
+
+// Hand complete tiles (all of them if `final`) to tile(valid, j, tag): lane's slot holds particle j.
+template <typename StackT, class Tile>
+__device__ void range_drain(WalkLDS<StackT> &L, RangeState &R, bool final, Tile tile)
+{
+  const int lane = threadIdx.x & 63;
+  __syncthreads();
+  int pos = 0, used = 0;
+  while (R.nslots >= 64 || (final && R.nslots > 0)) {
+    int c = (pos + lane < R.nrb) ? L.rb_cnt[pos + lane] : 0;
+    if (lane == 0) c -= used;
+    int inc = c;
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+    L.pre[lane] = inc;
+    __syncthreads();
+    const int tot = __shfl(inc, 63, 64);
+    const int take = tot < 64 ? tot : 64;
+    int lo = 0, hi = 64;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.pre[mid] <= lane) lo = mid + 1; else hi = mid; }
+    const int idx = lo < 63 ? lo : 63;
+    const bool valid = lane < take;
+    const int excl = idx > 0 ? L.pre[idx - 1] : 0;
+    const int off = lane - excl + (idx == 0 ? used : 0);
+    const int j = valid ? L.rb_first[pos + idx] + off : 0;
+    const int tag = valid ? L.rb_tag[pos + idx] : 0;
+    tile(valid, j, tag);
+    const int full = __popcll(__ballot((pos + lane < R.nrb) && inc <= take));
+    int nused = 0;
+    if (pos + full < R.nrb && full < 64) {
+      const int before = full > 0 ? L.pre[full - 1] : 0;
+      nused = take - before + (full == 0 ? used : 0);
+    }
+    pos += full; used = nused; R.nslots -= take;
+    __syncthreads();
+  }
+  // move what is left to the front of the ring
+  const int rem = R.nrb - pos;
+  if (pos > 0 && rem > 0) {
+    for (int base = 0; base < rem; base += 64) {
+      const int k = base + lane;
+      int a = 0, b = 0, c = 0;
+      if (k < rem) { a = L.rb_first[pos + k]; b = L.rb_cnt[pos + k]; c = L.rb_tag[pos + k]; }
+      __syncthreads();
+      if (k < rem) { L.rb_first[k] = a; L.rb_cnt[k] = b; L.rb_tag[k] = c; }
+      __syncthreads();
+    }
+  }
+  if (rem > 0 && used > 0 && lane == 0) { L.rb_first[0] += used; L.rb_cnt[0] -= used; }
+  R.nrb = rem;
+  __syncthreads();
+}
+
+// Depth-first walk over int stack entries (node | image code << 26).
+// cls(node, code, open, emit, first, cnt): classification of one popped node.
+template <class Classify, class Tile>
+__device__ void walk_dfs_stream(const DevicePtrs &d, WalkLDS<int> &L, unsigned int codes, Classify cls, Tile tile, int *flags)
 {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = lanemask_lt();
-  int nfront = 0;
-  // seed: the root once per image code (wave-uniform loop)
+  int top = 0;
   for (int c = 0; c < 27; c++) {
-    if (codes & (1u << c)) {
-      if (lane == 0) s_front[0][nfront] = 0 | (c << GH_NODE_BITS);
-      nfront++;
-    }
+    if (codes & (1u << c)) { if (lane == 0) L.stack[top] = 0 | (c << GH_NODE_BITS); top++; }
   }
+  RangeState R; R.nrb = 0; R.nslots = 0;
   __syncthreads();
-  int cur = 0, nleaf = 0;
-  const int leaf0 = d.gtot - 1;
-  while (nfront > 0) {
-    int nnext = 0;
-    for (int base = 0; base < nfront; base += 64) {
-      const int idx = base + lane;
-      bool hit = false, isleaf = false;
-      int n = 0, code = 0, first = 0, cnt = 0;
-      if (idx < nfront) {
-        const int e = s_front[cur][idx];
-        n = e & GH_NODE_MASK; code = e >> GH_NODE_BITS;
-        cnt = d.cN[n];
-        if (cnt > 0) {
-          double sh[3];
-          code_shift(dom, code, sh);
-          hit = pred(n, sh);
-        }
-        isleaf = n >= leaf0;
-        if (hit && isleaf) first = d.cfirst[n];
-      }
-      const unsigned long long lm = __ballot(hit && isleaf);
-      const unsigned long long om = __ballot(hit && !isleaf);
-      if (hit && isleaf) {
-        const int pos = nleaf + __popcll(lm & lt);
-        if (pos < GH_LCAP) s_leaf[pos] = make_leaf_entry(first, cnt, code);
-      }
-      nleaf += __popcll(lm);
-      if (hit && !isleaf) {
-        const int pos = nnext + 2*__popcll(om & lt);
-        if (pos + 1 < GH_FCAP) {
-          s_front[cur ^ 1][pos] = (2*n + 1) | (code << GH_NODE_BITS);
-          s_front[cur ^ 1][pos + 1] = (2*n + 2) | (code << GH_NODE_BITS);
-        }
-      }
-      nnext += 2*__popcll(om);
+  while (top > 0) {
+    const int p = top < 64 ? top : 64;
+    const int newtop = top - p;
+    bool open = false, emit = false;
+    int n = 0, code = 0, first = 0, cnt = 0;
+    if (lane < p) {
+      const int e = L.stack[top - 1 - lane];
+      n = e & GH_NODE_MASK; code = e >> GH_NODE_BITS;
+      cls(n, code, open, emit, first, cnt);
     }
-    if (nnext > GH_FCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); nnext = GH_FCAP; }
+    const unsigned long long om = __ballot(open), em = __ballot(emit);
     __syncthreads();
-    cur ^= 1;
-    nfront = nnext;
+    if (open) {
+      const int pos = newtop + 2*__popcll(om & lt);
+      if (pos + 1 < GH_SCAP) {
+        L.stack[pos] = (2*n + 1) | (code << GH_NODE_BITS);
+        L.stack[pos + 1] = (2*n + 2) | (code << GH_NODE_BITS);
+      }
+    }
+    top = newtop + 2*__popcll(om);
+    if (top > GH_SCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); top = GH_SCAP; }
+    if (emit) {
+      const int pos = R.nrb + __popcll(em & lt);
+      L.rb_first[pos] = first; L.rb_cnt[pos] = cnt; L.rb_tag[pos] = code;
+    }
+    R.nrb += __popcll(em);
+    R.nslots += wave_sum_i(emit ? cnt : 0);
+    if (R.nslots >= 64 || R.nrb > GH_RBCAP - 64) range_drain(L, R, false, tile);
+    else __syncthreads();
   }
-  if (nleaf > GH_LCAP) { if (lane == 0) atomicOr(flags, FLAG_LEAFLIST_OVERFLOW); nleaf = GH_LCAP; }
-  __syncthreads();
-  return nleaf;
+  range_drain(L, R, true, tile);
 }
 
 // which periodic image codes a search box [lo,hi] needs

@@ -138,7 +138,11 @@ static void dump_gather_lists(Dump &out, Simulation<ndim> *sim)
     while ((nn = sim->sphneib->GetGatherNeighbourList(rp, sph->kernp->kernrange*p[i].h, p, N, cap, buf.data())) < 0) {
       cap *= 2; buf.resize(cap);
     }
-    for (int k = 0; k < nn; k++) ids.push_back(p[buf[k]].iorig);   // periodic ghosts -> id of their parent
+    for (int k = 0; k < nn; k++) {
+      int j = buf[k];
+      while (j >= N) j = p[j].iorig;          // periodic ghosts (and ghosts of ghosts) -> real parent
+      ids.push_back(j);
+    }
     offs[i+1] = (int) ids.size();
   }
   out.i("gather_offsets", offs);
