@@ -149,7 +149,7 @@ def config_from_params(p, device=0):
     c.thetamaxsqd = float(p.get("thetamaxsqd", 0.1))
     c.courant_mult = float(p.get("courant_mult", 0.15))
     c.accel_mult = float(p.get("accel_mult", 0.3))
-    c.energy_mult = float(p.get("energy_mult", 0.3))
+    c.energy_mult = float(p.get("energy_mult", 0.4))
     return c
 
 
@@ -169,7 +169,23 @@ class GandalfHip:
                 self.ctx = None
             raise GhError(rc, msg)
 
+    @classmethod
+    def borrow(cls, ctx_ptr, ndim, self_gravity=0):
+        """wrap a gh_ctx* owned by someone else (the C++ host shell)"""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.cfg = Config()
+        self.cfg.ndim = ndim
+        self.cfg.self_gravity = self_gravity
+        self.ndim = ndim
+        self.ctx = _CTX(ctx_ptr)
+        self._borrowed = True
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.ctx = None
+            return
         if getattr(self, "ctx", None):
             self.lib.gh_destroy(self.ctx)
             self.ctx = None

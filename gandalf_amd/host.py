@@ -1,0 +1,122 @@
+"""ctypes binding of libgandalf_host.so: the C++ host shell (parameter files, IC generators,
+SetupSimulation / MainLoop) that sits above the C ABI.  No logic of its own."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libgandalf_host.so")
+_PD = C.POINTER(C.c_double)
+_H = C.c_void_p
+_hlib = None
+
+HOST_SYMBOLS = {
+    "gah_create": (_H, []),
+    "gah_destroy": (None, [_H]),
+    "gah_last_error": (C.c_char_p, [_H]),
+    "gah_read_params": (C.c_int, [_H, C.c_char_p]),
+    "gah_set_param": (C.c_int, [_H, C.c_char_p, C.c_char_p]),
+    "gah_get_param": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_int]),
+    "gah_generate_ic": (C.c_int, [_H]),
+    "gah_num_particles": (C.c_int, [_H]),
+    "gah_initial_h_provided": (C.c_int, [_H]),
+    "gah_get_ic": (C.c_int, [_H, _PD, _PD, _PD, _PD, _PD]),
+    "gah_post_ic_setup": (C.c_int, [_H]),
+    "gah_setup": (C.c_int, [_H]),
+    "gah_main_loop": (C.c_int, [_H, C.c_int]),
+    "gah_time": (C.c_double, [_H]),
+    "gah_timestep": (C.c_double, [_H]),
+    "gah_ctx": (C.c_void_p, [_H]),
+}
+
+
+def load_host_library(path=HOST_LIB_PATH):
+    global _hlib
+    if _hlib is not None:
+        return _hlib
+    if not os.path.exists(path):
+        raise ImportError("%s not built (run __graft_entry__.build())" % path)
+    capi.load_library()          # libgandalf_hip.so first (the host library links against it)
+    lib = C.CDLL(path)
+    for name, (res, args) in HOST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _hlib = lib
+    return lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class Simulation:
+    """GANDALF-style driver: Simulation(paramfile, **overrides); .generate_ic(); .setup(); .main_loop(n)."""
+
+    def __init__(self, paramfile=None, **overrides):
+        self.lib = load_host_library()
+        self.h = self.lib.gah_create()
+        if paramfile is not None:
+            self._chk(self.lib.gah_read_params(self.h, paramfile.encode()))
+        for k, v in overrides.items():
+            self.set_param(k, v)
+
+    def _chk(self, rc):
+        if rc:
+            raise HostError(self.lib.gah_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gah_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, key, value):
+        self._chk(self.lib.gah_set_param(self.h, str(key).encode(), str(value).encode()))
+
+    def get_param(self, key):
+        buf = C.create_string_buffer(256)
+        self._chk(self.lib.gah_get_param(self.h, key.encode(), buf, 256))
+        return buf.value.decode()
+
+    def generate_ic(self):
+        """ProcessParameters + GenerateIC (+ SetComFrame, + InitialSmoothingLengthGuess); host only."""
+        self._chk(self.lib.gah_generate_ic(self.h))
+        n = self.lib.gah_num_particles(self.h)
+        nd = int(self.get_param("ndim"))
+        ic = {"r": np.empty((n, nd)), "v": np.empty((n, nd)), "m": np.empty(n), "h": np.empty(n), "u": np.empty(n)}
+        dp = lambda a: a.ctypes.data_as(_PD)  # noqa: E731
+        self._chk(self.lib.gah_get_ic(self.h, dp(ic["r"]), dp(ic["v"]), dp(ic["m"]), dp(ic["h"]), dp(ic["u"])))
+        ic["initial_h_provided"] = bool(self.lib.gah_initial_h_provided(self.h))
+        return ic
+
+    def post_ic_setup(self):
+        self._chk(self.lib.gah_post_ic_setup(self.h))
+
+    def setup(self):
+        self._chk(self.lib.gah_setup(self.h))
+
+    def main_loop(self, nsteps=1):
+        self._chk(self.lib.gah_main_loop(self.h, nsteps))
+
+    @property
+    def t(self):
+        return self.lib.gah_time(self.h)
+
+    @property
+    def timestep(self):
+        return self.lib.gah_timestep(self.h)
+
+    def device(self):
+        """GandalfHip view (no ownership) of the device context of this simulation."""
+        ctx = self.lib.gah_ctx(self.h)
+        if not ctx:
+            raise HostError("simulation has no device context yet (call setup())")
+        return capi.GandalfHip.borrow(ctx, int(self.get_param("ndim")), int(self.get_param("self_gravity")))

@@ -1,0 +1,82 @@
+// SphSimulation.h -- host shell that keeps GANDALF's driver / operator surface and forwards the hot
+// path to libgandalf_hip through the C ABI (include/gandalf_hip.h).
+//
+// Class and method names follow the reference so that a maintainer finds the same seams:
+//   SimulationBase::SimulationFactory / SetupSimulation / MainLoop / Run  (Simulation.h:95-255, Simulation.cpp:63, 382, 639)
+//   Sph::InitialSmoothingLengthGuess / ZeroAccelerations                   (Sph.cpp:76-140)
+//   SphNeighbourSearch::BuildTree / UpdateAllSphProperties / UpdateAllSphHydroForces / UpdateAllSphForces
+//                                                                          (SphNeighbourSearch.h:76-94)
+//   SphLeapfrogKDK::AdvanceParticles / EndTimestep                          (SphLeapfrogKDK.cpp:76, 219)
+//   Nbody::CalculateDirectGravForces                                        (Nbody.cpp:233-287)
+// Only what the SPH + tree-gravity path needs is here; everything else GANDALF does (units, snapshots,
+// radiation, dust, MFV, sinks, MPI) is out of scope.
+#pragma once
+#include <string>
+#include <vector>
+#include "Parameters.h"
+#include "RandomNumber.h"
+#include "../../include/gandalf_hip.h"
+
+class GandalfError : public std::exception {
+ public:
+  explicit GandalfError(const std::string &m) : msg(m) {}
+  const char *what() const noexcept override { return msg.c_str(); }
+  std::string msg;
+};
+
+// Host copy of the particle data in the caller's order (the reference's AoS GradhSphParticle array,
+// here as SoA vectors: the hot fields only)
+struct HydroParticles {
+  int N = 0, ndim = 3;
+  std::vector<double> r, v, m, h, u;       // r, v: [N][ndim]
+};
+
+class Sph {
+ public:
+  Sph(int ndim, double h_fac, double kernrange) : ndim(ndim), h_fac(h_fac), kernrange(kernrange) {}
+  void AllocateMemory(int N);
+  void InitialSmoothingLengthGuess();      // Sph.cpp:76-119
+  HydroParticles part;
+  int ndim;
+  double h_fac, kernrange;
+  int Ngather = 0;
+};
+
+class SphNeighbourSearch {                 // neib_search = kdtree on the GPU
+ public:
+  explicit SphNeighbourSearch(gh_ctx *ctx) : ctx(ctx) {}
+  void BuildTree();
+  void UpdateAllSphProperties(gh_stats *st = nullptr);
+  void UpdateAllSphHydroForces(gh_stats *st = nullptr);
+  void UpdateAllSphForces(gh_stats *st = nullptr);
+  gh_ctx *ctx;
+};
+
+class SphSimulation {
+ public:
+  static SphSimulation *SimulationFactory(int ndim, const std::string &simtype, Parameters *params);
+  SphSimulation(int ndim, Parameters *params);
+  ~SphSimulation();
+
+  void ProcessParameters();                // SphSimulation.cpp:67 / GradhSphSimulation.cpp:54
+  void EnsureContext();
+  void GenerateIC();                       // SimulationIC.hpp:51 (ic = box | plummer)
+  void SetComFrame();                      // Simulation.cpp:1621
+  void PostInitialConditionsSetup();       // SphSimulation.cpp:204
+  void SetupSimulation();                  // Simulation.cpp:639
+  void MainLoop(int nsteps = 1);           // SphSimulation.cpp:574
+  void Run(int Nadvance = -1);             // Simulation.cpp:382
+  void Download(int field, std::vector<double> &out);
+
+  int ndim;
+  Parameters *simparams;
+  gh_config cfg;
+  gh_ctx *ctx = nullptr;
+  Sph *sph = nullptr;
+  SphNeighbourSearch *sphneib = nullptr;
+  XorshiftRand *randnumb = nullptr;
+  bool initial_h_provided = false;
+  bool setup = false;
+  int Nsteps = 0, Nstepsmax = 0;
+  double t = 0.0, timestep = 0.0, tend = 0.0;
+};

@@ -1,0 +1,62 @@
+// host_capi.cpp -- small extern "C" surface of libgandalf_host.so so that tests / bench.py can drive the
+// C++ host shell (parameter files, IC generators, SetupSimulation / MainLoop) from Python.
+#include "SphSimulation.h"
+#include <cstring>
+#include <string>
+
+struct gah_sim { Parameters params; SphSimulation *sim = nullptr; std::string err; };
+
+#define GAH_TRY(s, body) try { body; return 0; } catch (const std::exception &e) { (s)->err = e.what(); return -1; }
+
+extern "C" {
+
+gah_sim *gah_create(void) { return new gah_sim(); }
+void gah_destroy(gah_sim *s) { if (s) { delete s->sim; delete s; } }
+const char *gah_last_error(gah_sim *s) { return s->err.c_str(); }
+int gah_read_params(gah_sim *s, const char *file) { GAH_TRY(s, s->params.ReadParamsFile(file)) }
+int gah_set_param(gah_sim *s, const char *key, const char *value) { GAH_TRY(s, s->params.SetParameter(key, value)) }
+int gah_get_param(gah_sim *s, const char *key, char *out, int cap)
+{
+  const std::string v = s->params.GetParameter(key);
+  if ((int) v.size() + 1 > cap) return -1;
+  memcpy(out, v.c_str(), v.size() + 1);
+  return 0;
+}
+// ProcessParameters + GenerateIC (+ SetComFrame): host-side only, particles stay on the host
+int gah_generate_ic(gah_sim *s)
+{
+  GAH_TRY(s, {
+    if (!s->sim) s->sim = SphSimulation::SimulationFactory(s->params.intparams["ndim"], s->params.stringparams["sim"], &s->params);
+    s->sim->ProcessParameters();
+    s->sim->GenerateIC();
+    if (s->params.intparams["com_frame"] == 1) s->sim->SetComFrame();
+    if (!s->sim->initial_h_provided) s->sim->sph->InitialSmoothingLengthGuess();
+  })
+}
+int gah_num_particles(gah_sim *s) { return s->sim ? s->sim->sph->part.N : 0; }
+int gah_initial_h_provided(gah_sim *s) { return s->sim && s->sim->initial_h_provided ? 1 : 0; }
+int gah_get_ic(gah_sim *s, double *r, double *v, double *m, double *h, double *u)
+{
+  if (!s->sim) return -1;
+  const HydroParticles &p = s->sim->sph->part;
+  if (r) memcpy(r, p.r.data(), sizeof(double)*p.r.size());
+  if (v) memcpy(v, p.v.data(), sizeof(double)*p.v.size());
+  if (m) memcpy(m, p.m.data(), sizeof(double)*p.m.size());
+  if (h) memcpy(h, p.h.data(), sizeof(double)*p.h.size());
+  if (u) memcpy(u, p.u.data(), sizeof(double)*p.u.size());
+  return 0;
+}
+int gah_post_ic_setup(gah_sim *s) { GAH_TRY(s, s->sim->PostInitialConditionsSetup()) }
+int gah_setup(gah_sim *s)
+{
+  GAH_TRY(s, {
+    if (!s->sim) s->sim = SphSimulation::SimulationFactory(s->params.intparams["ndim"], s->params.stringparams["sim"], &s->params);
+    s->sim->SetupSimulation();
+  })
+}
+int gah_main_loop(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->MainLoop(nsteps)) }
+double gah_time(gah_sim *s) { return s->sim->t; }
+double gah_timestep(gah_sim *s) { return s->sim->timestep; }
+gh_ctx *gah_ctx(gah_sim *s) { return s->sim ? s->sim->ctx : nullptr; }
+
+}
