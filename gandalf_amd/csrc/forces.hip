@@ -241,14 +241,36 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // hydro + self-gravity                                           (GradhSphTree.cpp:444-657)
 // ================================================================================================
 #define GH_MAXLEAF 16
-#define GH_CCAP 256          /* cell-interaction list capacity per flush */
+#define GH_CCAP 128          /* far-field entry list capacity (flushed when more than 64 are pending) */
+
+// far-field entry evaluation: a += m dr/(dr^2+eps)^(3/2), gpot += m/(dr^2+eps)^(1/2).  The reference
+// writes this once with 1/x and sqrt (cells, NeighbourSearch.h:364-372) and once with 1/sqrt(x) (direct
+// particles, GradhSph.cpp:675-681); both are evaluated here with one rsqrt (<= 2 ulp from either).
+template <int ND>
+__device__ __forceinline__ void point_mass(const TargetI &ti, Accum &A, double x, double y, double z, double m)
+{
+  double dr[3] = {0.0, 0.0, 0.0};
+  dr[0] = x - ti.r[0];
+  if (ND > 1) dr[1] = y - ti.r[1];
+  if (ND > 2) dr[2] = z - ti.r[2];
+  double drsqd = dr[0]*dr[0];
+  if (ND > 1) drsqd += dr[1]*dr[1];
+  if (ND > 2) drsqd += dr[2]*dr[2];
+  drsqd += GH_SMALL;
+  const double invdrmag = rsqrt(drsqd);
+  const double invdr3 = invdrmag*invdrmag*invdrmag;
+  A.gpot += m*invdrmag;
+  for (int k = 0; k < ND; k++) A.at[k] += m*dr[k]*invdr3;
+}
 
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
-  __shared__ WalkLDS<int> L;                       // stack of nodes + ring of near-field particle ranges
+  __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];      // leaf mask of every stack entry
+  __shared__ RangeRing s_hyd, s_dir;               // near-field leaves: hydro candidates / direct only
+  __shared__ int s_pre[64];
   __shared__ double s_cx[GH_CCAP], s_cy[GH_CCAP], s_cz[GH_CCAP], s_cm[GH_CCAP];
   __shared__ unsigned short s_cmask[GH_CCAP];
   __shared__ double s_t[T_NF][64];
@@ -268,11 +290,22 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
 
   // leaf geometry of the group (the reference walks per leaf cell with these, Tree.cpp:639-643)
   unsigned int allmask = 0;
-  if (lane < nl) {
-    const CellGrav g = d.cgrav[leafnode0 + lane];
-    for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
-    s_lrmax[lane] = g.rmax;
-    s_lhr[lane] = K::kernrange*g.hmax;
+  const CellGrav gg = d.cgrav[gnode];
+  double Rg = 0.0, Lm = 0.0, Lr = 0.0;               // group-level bounds for the quick classification
+  {
+    double rg = 0.0, lm = 0.0, lr = 0.0;
+    if (lane < nl) {
+      const CellGrav g = d.cgrav[leafnode0 + lane];
+      for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
+      s_lrmax[lane] = g.rmax;
+      s_lhr[lane] = K::kernrange*g.hmax;
+      if (g.N > 0) {
+        double dd = 0.0;
+        for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; dd += dx*dx; }
+        rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
+      }
+    }
+    Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
   int myleaf = 0;
@@ -294,20 +327,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     if (act) {
       for (int c = 0; c < ncell; c++) {
         if ((s_cmask[c] >> myleaf) & 1) {
-          double dr[3] = {0.0, 0.0, 0.0};
-          dr[0] = s_cx[c] - ti.r[0];
-          if (ND > 1) dr[1] = s_cy[c] - ti.r[1];
-          if (ND > 2) dr[2] = s_cz[c] - ti.r[2];
-          double drsqd = dr[0]*dr[0];
-          if (ND > 1) drsqd += dr[1]*dr[1];
-          if (ND > 2) drsqd += dr[2]*dr[2];
-          drsqd += GH_SMALL;
-          const double invdrsqd = 1.0/drsqd;
-          const double invdrmag = sqrt(invdrsqd);
-          const double invdr3 = invdrsqd*invdrmag;
-          const double mc = s_cm[c];
-          A.gpot += mc*invdrmag;
-          for (int k = 0; k < ND; k++) A.at[k] += mc*dr[k]*invdr3;
+          point_mass<ND>(ti, A, s_cx[c], s_cy[c], s_cz[c], s_cm[c]);
           if (COUNT) n_cells++;
         }
       }
@@ -315,8 +335,28 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     __syncthreads();
     ncell = 0;
   };
-  // ---- near-field particles: tag = hydro-candidate leaf mask | direct leaf mask << 16
-  auto tile = [&](bool valid, int j, int tag) {
+  // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
+  auto tile_dir = [&](bool valid, int j, int tag) {
+    {
+      double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
+      if (valid) v = d.posm[j];
+      s_t[T_X][lane] = v.x; s_t[T_Y][lane] = v.y; s_t[T_Z][lane] = v.z; s_t[T_M][lane] = v.w;
+      s_ttag[lane] = valid ? tag : 0;
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll 4
+      for (int c = 0; c < 64; c++) {
+        if ((s_ttag[c] >> myleaf) & 1) {
+          point_mass<ND>(ti, A, s_t[T_X][c], s_t[T_Y][c], s_t[T_Z][c], s_t[T_M][c]);
+          if (COUNT) n_direct++;
+        }
+      }
+    }
+    __syncthreads();
+  };
+  // ---- leaves with hydro candidates: tag = hydro-candidate leaf mask | direct leaf mask << 16
+  auto tile_hyd = [&](bool valid, int j, int tag) {
     {
       const double sh[3] = {0.0, 0.0, 0.0};
       stage_neib(d, ND, s_t, lane, j, sh, valid);
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     __syncthreads();
     unsigned long long mask = 0;
     if (act) {
-#pragma unroll 8
+#pragma unroll 4
       for (int c = 0; c < 64; c++) {
         const int tg = s_ttag[c];
         const bool hydc = (tg >> myleaf) & 1, dirc = (tg >> (16 + myleaf)) & 1;
@@ -341,9 +381,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
           if (sph) mask |= 1ull << c;
           else {
-            // direct Newtonian term                               (GradhSph.cpp:671-686)
-            const double drsqd = r2 + GH_SMALL;
-            const double invdrmag = 1.0/sqrt(drsqd);
+            const double invdrmag = rsqrt(r2 + GH_SMALL);
             const double invdr3 = invdrmag*invdrmag*invdrmag;
             const double mj = s_t[T_M][c];
             for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*invdr3;
@@ -372,14 +410,14 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   };
 
   // ---- depth-first walk with per-leaf masks                       (Tree.cpp:648-731)
-  if (lane == 0) { L.stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
-  RangeState R; R.nrb = 0; R.nslots = 0;
+  if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
+  RangeState Rh, Rd; Rh.nrb = 0; Rh.nslots = 0; Rd.nrb = 0; Rd.nslots = 0;
   __syncthreads();
   int top = 1;
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
     if (ncell > GH_CCAP - 64) flush_cells();
-    const int p = top < 64 ? top : 64;
+    const int p = pop_width(top);
     const int newtop = top - p;
     unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
     int n = 0; bool isleaf = false;
@@ -387,39 +425,53 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     g.first = 0; g.N = 0; g.m = 0.0;
     for (int k = 0; k < 3; k++) g.com[k] = 0.0;
     if (lane < p) {
-      n = L.stack[top - 1 - lane];
+      n = s_stack[top - 1 - lane];
       const unsigned int fm = s_smask[top - 1 - lane];
       g = d.cgrav[n];
       isleaf = n >= leaf0;
       const double khr = K::kernrange*g.hmax;
-      for (int l = 0; l < nl; l++) {
-        if (!((fm >> l) & 1)) continue;
-        double drsqd = 0.0;
-        for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
-        const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
-        const double d2 = s_lrmax[l] + g.rmax + khr;
-        if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
-          if (!isleaf) openm |= 1u << l;
-          else if (g.N > 0) hydm |= 1u << l;
-        }
-        else if (g.N == 0) { }
-        else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
-          if (isleaf && g.N == 1) dirm |= 1u << l;
-          else cellm |= 1u << l;
-        }
-        else {
-          if (!isleaf) openm |= 1u << l;
-          else dirm |= 1u << l;
+      // quick classification of the node against the whole group.  Every leaf centre lies within Rg of
+      // the group centre, so |dr_leaf| >= D - Rg for all leaves; if that lower bound already clears
+      // both the overlap distances and the opening distance, each per-leaf test below would say "cell".
+      double D2 = 0.0;
+      for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; D2 += dx*dx; }
+      const double Dm = (sqrt(D2) - Rg)*(1.0 - 1e-12);
+      const double Tn = g.rmax + fmax(Lm, Lr + khr);
+      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd) {
+        if (isleaf && g.N == 1) dirm = fm; else cellm = fm;
+      }
+      else {
+        for (int l = 0; l < nl; l++) {
+          if (!((fm >> l) & 1)) continue;
+          double drsqd = 0.0;
+          for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
+          const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
+          const double d2 = s_lrmax[l] + g.rmax + khr;
+          if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
+            if (!isleaf) openm |= 1u << l;
+            else if (g.N > 0) hydm |= 1u << l;
+          }
+          else if (g.N == 0) { }
+          else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
+            if (isleaf && g.N == 1) dirm |= 1u << l;
+            else cellm |= 1u << l;
+          }
+          else {
+            if (!isleaf) openm |= 1u << l;
+            else dirm |= 1u << l;
+          }
         }
       }
     }
-    const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0), pm = __ballot((hydm | dirm) != 0);
+    const bool ehyd = hydm != 0, edir = hydm == 0 && dirm != 0;
+    const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0);
+    const unsigned long long hm = __ballot(ehyd), dm = __ballot(edir);
     __syncthreads();
     if (openm) {
       const int pos = newtop + 2*__popcll(om & lt);
       if (pos + 1 < GH_SCAP) {
-        L.stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
-        L.stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
+        s_stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
+        s_stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
       }
     }
     top = newtop + 2*__popcll(om);
@@ -430,17 +482,24 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       s_cmask[pos] = (unsigned short) cellm;
     }
     ncell += __popcll(cm);
-    if (hydm | dirm) {
-      const int pos = R.nrb + __popcll(pm & lt);
-      L.rb_first[pos] = g.first; L.rb_cnt[pos] = g.N; L.rb_tag[pos] = (int) (hydm | (dirm << 16));
+    if (ehyd) {
+      const int pos = Rh.nrb + __popcll(hm & lt);
+      s_hyd.first[pos] = g.first; s_hyd.cnt[pos] = g.N; s_hyd.tag[pos] = (int) (hydm | (dirm << 16));
     }
-    R.nrb += __popcll(pm);
-    R.nslots += wave_sum_i((hydm | dirm) ? g.N : 0);
-    if (R.nslots >= 64 || R.nrb > GH_RBCAP - 64) range_drain(L, R, false, tile);
-    else __syncthreads();
+    if (edir) {
+      const int pos = Rd.nrb + __popcll(dm & lt);
+      s_dir.first[pos] = g.first; s_dir.cnt[pos] = g.N; s_dir.tag[pos] = (int) dirm;
+    }
+    Rh.nrb += __popcll(hm); Rd.nrb += __popcll(dm);
+    Rh.nslots += wave_sum_i(ehyd ? g.N : 0);
+    Rd.nslots += wave_sum_i(edir ? g.N : 0);
+    __syncthreads();
+    if (Rh.nslots >= 64 || Rh.nrb > GH_RBCAP - 64) range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, false, tile_hyd);
+    if (Rd.nslots >= 64 || Rd.nrb > GH_RBCAP - 64) range_drain_raw(s_dir.first, s_dir.cnt, s_dir.tag, s_pre, Rd, false, tile_dir);
   }
   flush_cells();
-  range_drain(L, R, true, tile);
+  range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, true, tile_hyd);
+  range_drain_raw(s_dir.first, s_dir.cnt, s_dir.tag, s_pre, Rd, true, tile_dir);
 
   if (act) {
     // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619

@@ -59,8 +59,20 @@ __device__ __forceinline__ void code_shift(const Domain &dom, int code, double s
 // tree level, the ring by its drain threshold.  (A breadth-first frontier or a stored candidate list
 // overflows for the outlier groups of a Plummer halo, whose search volume covers the whole system.)
 // ------------------------------------------------------------------------------------------------
-#define GH_SCAP 2560         /* stack capacity: > 128 * (ltot + 1) for ltot <= 18 */
-#define GH_RBCAP 192         /* range ring capacity */
+#define GH_SCAP 768          /* stack capacity; pops narrow to GH_NARROW lanes near the top, see pop_width */
+#define GH_NARROW 4
+#define GH_RBCAP 160         /* range ring capacity */
+
+// A 64-wide pop can grow the stack by 64 entries per step; a GH_NARROW-wide pop is nearly a true
+// depth-first descent that needs at most GH_NARROW extra entries per tree level (<= 4*32).  Switching to
+// narrow pops once fewer than 192 slots are free therefore bounds the stack for any search volume.
+__device__ __forceinline__ int pop_width(int top)
+{
+  const int w = top > GH_SCAP - 192 ? GH_NARROW : 64;
+  return top < w ? top : w;
+}
+
+struct RangeRing { int first[GH_RBCAP], cnt[GH_RBCAP], tag[GH_RBCAP]; };
 
 template <typename StackT> struct WalkLDS {
   StackT stack[GH_SCAP];
@@ -78,9 +90,19 @@ __device__ __forceinline__ int wave_sum_i(int v)
 struct RangeState { int nrb, nslots; };
 
 // Hand complete tiles (all of them if `final`) to tile(valid, j, tag): lane's slot holds particle j.
+template <class Tile>
+__device__ void range_drain_raw(int *rb_first, int *rb_cnt, int *rb_tag, int *pre, RangeState &R, bool final, Tile tile);
+
 template <typename StackT, class Tile>
 __device__ void range_drain(WalkLDS<StackT> &L, RangeState &R, bool final, Tile tile)
 {
+  range_drain_raw(L.rb_first, L.rb_cnt, L.rb_tag, L.pre, R, final, tile);
+}
+
+template <class Tile>
+__device__ void range_drain_raw(int *rb_first, int *rb_cnt, int *rb_tag, int *pre, RangeState &R, bool final, Tile tile)
+{
+  struct { int *rb_first, *rb_cnt, *rb_tag, *pre; } L = {rb_first, rb_cnt, rb_tag, pre};
   const int lane = threadIdx.x & 63;
   __syncthreads();
   int pos = 0, used = 0;
@@ -142,7 +164,7 @@ __device__ void walk_dfs_stream(const DevicePtrs &d, WalkLDS<int> &L, unsigned i
   RangeState R; R.nrb = 0; R.nslots = 0;
   __syncthreads();
   while (top > 0) {
-    const int p = top < 64 ? top : 64;
+    const int p = pop_width(top);
     const int newtop = top - p;
     bool open = false, emit = false;
     int n = 0, code = 0, first = 0, cnt = 0;
