@@ -87,7 +87,7 @@ static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
   loc.n_iterations = (int64_t) hs[ST_ITER];
   loc.n_candidates = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_CAND] : (int64_t) hs[ST_PAIRS];
   loc.n_retries = (int64_t) hs[ST_RETRY];
-  loc.n_direct = (int64_t) hs[ST_DIRECT];
+  loc.n_direct = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_PAIRS] : (int64_t) hs[ST_DIRECT];   // density: candidate slots tested
   loc.n_cells = (int64_t) hs[ST_CELLS];
   loc.kernel_ms = ctx->dom_calls[phase] ? ctx->dom_ms[phase]/ctx->dom_calls[phase] : 0.0;
   if (st) *st = loc;

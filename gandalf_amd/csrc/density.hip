@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   bool done = !act;
   double rho = 0.0, omg = 0.0, zet = 0.0;
   double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
-  unsigned long long n_iter = 0, n_cand = 0, n_retry = 0;
+  unsigned long long n_iter = 0, n_cand = 0, n_retry = 0, n_tested = 0;
   // reference cull radius of the first try, for the candidate statistic: kernrange*1.05*hmax(leaf)
   double cullsqd = 0.0;
   if (COUNT) {
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       if (hup < hs) hup = hs;
     }
     const unsigned int codes = image_codes(P.dom, ND, lo, hi);
+    const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
     auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
       const int cn = d.cN[n];
       if (cn == 0) return;
@@ -94,12 +95,19 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       code_shift(P.dom, code, sh);
       const CellBox &b = d.cbox[n];
       bool inside = true;
+      double gap2 = 0.0;                                  // squared distance between the two boxes
       for (int k = 0; k < ND; k++) {
         const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
         if (lo[k] > bmax) return;                         // BoxOverlap, InlineFuncs.h:362-390 (inclusive)
         if (bmin > hi[k]) return;
         if (bmin < lo[k] || bmax > hi[k]) inside = false;
+        const double g1 = bmin - gb.bbmax[k], g2 = gb.bbmin[k] - bmax;
+        const double gk = fmax(fmax(g1, g2), 0.0);
+        gap2 += gk*gk;
       }
+      // no particle of the cell can be within kernrange*hs of any particle of the group: the reference
+      // would list it (box test) and sum zeros for it; skipping it changes nothing
+      if (gap2 > rs2cut) return;
       if (inside || n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; cnt = cn; }
       else open = true;
     };
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           if (invhsqd*r2 < K::kernrangesqd) mask |= 1ull << c;
           if (COUNT) { if (r2 + GH_SMALL <= cullsqd) n_cand++; }
         }
+        if (COUNT) n_tested += 64;
       }
       // phase 2: kernel sums over the lane's own neighbours in this tile
       while (__any(mask != 0ull)) {
@@ -141,10 +150,13 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
-          const double s = sqrt(invhsqd*r2);
-          rho += mj*K::w0(s);
-          omg += mj*invh*K::womega(s);
-          zet += mj*K::wzeta(s);
+          {
+#pragma clang fp contract(fast)
+            const double s = sqrt(invhsqd*r2);
+            rho += mj*K::w0(s);
+            omg += mj*invh*K::womega(s);
+            zet += mj*K::wzeta(s);
+          }
         }
       }
       __syncthreads();
@@ -195,7 +207,8 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   }
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0), c = wave_sum_u64(n_retry);
-    if (lane == 0) { atomicAdd(&stats[ST_ITER], a); atomicAdd(&stats[ST_CAND], b); atomicAdd(&stats[ST_RETRY], c); }
+    const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
+    if (lane == 0) { atomicAdd(&stats[ST_ITER], a); atomicAdd(&stats[ST_CAND], b); atomicAdd(&stats[ST_RETRY], c); atomicAdd(&stats[ST_PAIRS], t); }
   }
 }
 

@@ -46,6 +46,7 @@ template <int ND, bool GRAV>
 __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const double (*s_t)[64], int c,
                                          const double dr_in[3], double r2)
 {
+#pragma clang fp contract(fast)
   typedef M4<ND> K;
   double dr[3] = {dr_in[0], dr_in[1], dr_in[2]};
   double drmag;
@@ -241,14 +242,28 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // hydro + self-gravity                                           (GradhSphTree.cpp:444-657)
 // ================================================================================================
 #define GH_MAXLEAF 16
-#define GH_CCAP 128          /* far-field entry list capacity (flushed when more than 64 are pending) */
+#define GH_CCAP 132          /* far-field entry list capacity (flushed when more than 64 are pending; +4 padding) */
+
+// 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps in FMA form; ends within
+// 1-2 ulp.  (ocml's rsqrt also handles denormals/inf/nan, which cannot occur here: x >= 1e-20.)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5*x;
+  y = y*(1.5 - hx*y*y);
+  y = y*(1.5 - hx*y*y);
+  return y;
+}
 
 // far-field entry evaluation: a += m dr/(dr^2+eps)^(3/2), gpot += m/(dr^2+eps)^(1/2).  The reference
 // writes this once with 1/x and sqrt (cells, NeighbourSearch.h:364-372) and once with 1/sqrt(x) (direct
 // particles, GradhSph.cpp:675-681); both are evaluated here with one rsqrt (<= 2 ulp from either).
+// Branch-free: a lane that does not take the entry passes m = 0.
 template <int ND>
 __device__ __forceinline__ void point_mass(const TargetI &ti, Accum &A, double x, double y, double z, double m)
 {
+#pragma clang fp contract(fast)
   double dr[3] = {0.0, 0.0, 0.0};
   dr[0] = x - ti.r[0];
   if (ND > 1) dr[1] = y - ti.r[1];
@@ -257,10 +272,10 @@ __device__ __forceinline__ void point_mass(const TargetI &ti, Accum &A, double x
   if (ND > 1) drsqd += dr[1]*dr[1];
   if (ND > 2) drsqd += dr[2]*dr[2];
   drsqd += GH_SMALL;
-  const double invdrmag = rsqrt(drsqd);
-  const double invdr3 = invdrmag*invdrmag*invdrmag;
+  const double invdrmag = fast_rsqrt(drsqd);
+  const double minvdr3 = m*(invdrmag*invdrmag*invdrmag);
   A.gpot += m*invdrmag;
-  for (int k = 0; k < ND; k++) A.at[k] += m*dr[k]*invdr3;
+  for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
 }
 
 template <int ND, bool COUNT>
@@ -324,12 +339,17 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   // ---- cells: monopole                                           (NeighbourSearch.h:350-377)
   auto flush_cells = [&]() {
     __syncthreads();
-    if (act) {
-      for (int c = 0; c < ncell; c++) {
-        if ((s_cmask[c] >> myleaf) & 1) {
-          point_mass<ND>(ti, A, s_cx[c], s_cy[c], s_cz[c], s_cm[c]);
-          if (COUNT) n_cells++;
-        }
+    // pad to a multiple of 4 with empty entries so that the loop can be unrolled without a remainder
+    if (lane < 4 && ncell + lane < GH_CCAP) { s_cmask[ncell + lane] = 0; s_cm[ncell + lane] = 0.0; s_cx[ncell + lane] = 1e30; s_cy[ncell + lane] = 1e30; s_cz[ncell + lane] = 1e30; }
+    __syncthreads();
+    const int nc4 = (ncell + 3) & ~3;
+    for (int c0 = 0; c0 < nc4; c0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u;
+        const bool take = (s_cmask[c] >> myleaf) & 1;
+        point_mass<ND>(ti, A, s_cx[c], s_cy[c], s_cz[c], take ? s_cm[c] : 0.0);
+        if (COUNT) n_cells += take ? 1 : 0;
       }
     }
     __syncthreads();
@@ -344,14 +364,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       s_ttag[lane] = valid ? tag : 0;
     }
     __syncthreads();
-    if (act) {
 #pragma unroll 4
-      for (int c = 0; c < 64; c++) {
-        if ((s_ttag[c] >> myleaf) & 1) {
-          point_mass<ND>(ti, A, s_t[T_X][c], s_t[T_Y][c], s_t[T_Z][c], s_t[T_M][c]);
-          if (COUNT) n_direct++;
-        }
-      }
+    for (int c = 0; c < 64; c++) {
+      const bool take = (s_ttag[c] >> myleaf) & 1;
+      point_mass<ND>(ti, A, s_t[T_X][c], s_t[T_Y][c], s_t[T_Z][c], take ? s_t[T_M][c] : 0.0);
+      if (COUNT) n_direct += take ? 1 : 0;
     }
     __syncthreads();
   };
@@ -381,10 +398,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
           if (sph) mask |= 1ull << c;
           else {
-            const double invdrmag = rsqrt(r2 + GH_SMALL);
-            const double invdr3 = invdrmag*invdrmag*invdrmag;
+#pragma clang fp contract(fast)
+            const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
             const double mj = s_t[T_M][c];
-            for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*invdr3;
+            const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
+            for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
             A.gpot += mj*invdrmag;
             if (COUNT) n_direct++;
           }
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   int top = 1;
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
-    if (ncell > GH_CCAP - 64) flush_cells();
+    if (ncell > 64) flush_cells();
     const int p = pop_width(top);
     const int newtop = top - p;
     unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;

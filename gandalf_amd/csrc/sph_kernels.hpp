@@ -2,6 +2,8 @@
 // (reference src/Headers/SmoothingKernel.h:131-240, normalisation src/Hydrodynamics/M4Kernel.cpp:39-53)
 // and of the closed-form EOS used by the configs (src/Thermal/AdiabaticEOS.cpp:69, IsothermalEOS.cpp).
 // Powers are written as products (the reference calls pow(s,n)); the difference is < 1 ulp per term.
+// The kernel polynomials may be contracted to FMAs (they only feed sums; membership tests - which must
+// round like the reference's x86 build - are made by the callers on uncontracted sums of squares).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -19,18 +21,21 @@ template <int ND> struct M4 {
   }
   __device__ static __forceinline__ double w0(double s)
   {
+#pragma clang fp contract(fast)
     if (s < 1.0) return norm()*(1.0 - 1.5*s*s + 0.75*s*s*s);
     else if (s < 2.0) { const double t = 2.0 - s; return 0.25*norm()*(t*t*t); }
     return 0.0;
   }
   __device__ static __forceinline__ double w1(double s)
   {
+#pragma clang fp contract(fast)
     if (s < 1.0) return norm()*(-3.0*s + 2.25*s*s);
     else if (s < 2.0) return -0.75*norm()*(2.0 - s)*(2.0 - s);
     return 0.0;
   }
   __device__ static __forceinline__ double womega(double s)
   {
+#pragma clang fp contract(fast)
     const double nd = (double) ND;
     if (s < 1.0) return norm()*(-nd + 1.5*(nd + 2.0)*s*s - 0.75*(nd + 3.0)*(s*s*s));
     else if (s < 2.0)
@@ -39,6 +44,7 @@ template <int ND> struct M4 {
   }
   __device__ static __forceinline__ double wzeta(double s)
   {
+#pragma clang fp contract(fast)
     const double s2 = s*s;
     if (s < 1.0) return 1.4 - 2.0*s2 + 1.5*(s2*s2) - 0.6*(s2*s2*s);
     else if (s < 2.0) return 1.6 - 4.0*s2 + 4.0*(s2*s) - 1.5*(s2*s2) + 0.2*(s2*s2*s);
@@ -46,6 +52,7 @@ template <int ND> struct M4 {
   }
   __device__ static __forceinline__ double wgrav(double s)
   {
+#pragma clang fp contract(fast)
     const double s2 = s*s;
     if (s < 1.0) return 1.333333333333333333333*s - 1.2*(s2*s) + 0.5*(s2*s2);
     else if (s < 2.0)
@@ -55,6 +62,7 @@ template <int ND> struct M4 {
   }
   __device__ static __forceinline__ double wpot(double s)
   {
+#pragma clang fp contract(fast)
     const double s2 = s*s;
     if (s < 1.0) return 1.4 - 0.666666666666666666666666*s2 + 0.3*(s2*s2) - 0.1*(s2*s2*s);
     else if (s < 2.0)
