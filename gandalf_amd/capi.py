@@ -78,6 +78,13 @@ SYMBOLS = {
     "gh_set_shard": (C.c_int, [_CTX, C.c_int, C.c_int]),
     "gh_shard_range": (C.c_int, [_CTX, C.c_int, _PL, _PL]),
     "gh_field_dev": (C.c_void_p, [_CTX, C.c_int, C.c_int]),
+    "gh_exchange_narrays": (C.c_int, [_CTX, C.c_int]),
+    "gh_shard_pack": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_int64]),
+    "gh_shard_unpack": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "gh_update_hmax": (C.c_int, [_CTX]),
+    "gh_step_begin": (C.c_int, [_CTX]),
+    "gh_step_forces": (C.c_int, [_CTX]),
+    "gh_step_end": (C.c_int, [_CTX, _PD, _PD]),
 }
 
 _lib = None
@@ -325,6 +332,31 @@ class GandalfHip:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.lib.gh_shard_range(self.ctx, rank, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    X_DENSITY, X_FORCES = 0, 1
+
+    def exchange_narrays(self, xset):
+        return int(self.lib.gh_exchange_narrays(self.ctx, xset))
+
+    def shard_pack(self, xset, dst_ptr, stride):
+        self._chk(self.lib.gh_shard_pack(self.ctx, xset, C.c_void_p(dst_ptr), stride))
+
+    def shard_unpack(self, xset, rank, src_ptr, stride):
+        self._chk(self.lib.gh_shard_unpack(self.ctx, xset, rank, C.c_void_p(src_ptr), stride))
+
+    def update_hmax(self):
+        self._chk(self.lib.gh_update_hmax(self.ctx))
+
+    def step_begin(self):
+        self._chk(self.lib.gh_step_begin(self.ctx))
+
+    def step_forces(self):
+        self._chk(self.lib.gh_step_forces(self.ctx))
+
+    def step_end(self):
+        t, dt = C.c_double(), C.c_double()
+        self._chk(self.lib.gh_step_end(self.ctx, C.byref(t), C.byref(dt)))
+        return t.value, dt.value
 
     def field_dev(self, name, k=0):
         return self.lib.gh_field_dev(self.ctx, FIELDS[name], k)

@@ -78,9 +78,14 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
 
 static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
 {
-  unsigned long long hs[ST_COUNT];
+  unsigned long long hs[ST_TOTAL];
   GH_CHECK(ctx, hipMemcpy(hs, ctx->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
   GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(hs)));
+#ifdef GH_STAMPS
+  fprintf(stderr, "[stamps] phase %d:", phase);
+  for (int k = 0; k < 8; k++) fprintf(stderr, " %.4g", (double) hs[ST_COUNT + k]);
+  fprintf(stderr, "\n");
+#endif
   gh_stats loc;
   memset(&loc, 0, sizeof(loc));
   loc.n_particles = ctx->N;
@@ -116,8 +121,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipStreamCreate(&ctx->stream));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->redbuf, sizeof(double)*(256*6 + 8)));
   GH_CHECK(ctx, hipMemset(ctx->redbuf, 0, sizeof(double)*(256*6 + 8)));
-  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_stats, sizeof(unsigned long long)*ST_COUNT));
-  GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long)*ST_COUNT));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_stats, sizeof(unsigned long long)*ST_TOTAL));
+  GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long)*ST_TOTAL));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*2*D_COUNT));
@@ -341,6 +346,7 @@ static int density_and_hmax(gh_ctx *ctx, bool count)
 {
   int rc = gh_density_impl(ctx, count);
   if (rc) return rc;
+  if (ctx->nranks > 1) return GH_OK;                    // h of the other slices arrives with the exchange
   return gh_update_hmax_impl(ctx);                      // tree->UpdateAllHmaxValues, GradhSphTree.cpp:268
 }
 
@@ -561,6 +567,109 @@ extern "C" int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *co
   const int64_t e = g1 < ctx->ngroups ? ctx->h_cfirst[base + g1] : ctx->N;
   if (first) *first = f;
   if (count) *count = e - f;
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: slices, exchange sets, step sections
+// ------------------------------------------------------------------------------------------------
+static int exchange_list(gh_ctx *ctx, int set, int *out)
+{
+  int n = 0;
+  if (set == GH_X_DENSITY) {
+    const int l[] = {D_H, D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD, D_U, D_SOUND, D_PRESSURE, D_DIV_V};
+    for (int v : l) out[n++] = v;
+  }
+  else if (set == GH_X_FORCES) {
+    for (int k = 0; k < ctx->ndim; k++) out[n++] = D_AX + k;
+    for (int k = 0; k < ctx->ndim; k++) out[n++] = D_ATX + k;
+    const int l[] = {D_GPOT, D_GPOT_HYDRO, D_DUDT, D_DIV_V};
+    for (int v : l) out[n++] = v;
+  }
+  return n;
+}
+
+extern "C" int gh_exchange_narrays(gh_ctx *ctx, int set)
+{
+  if (!ctx) return 0;
+  int l[16];
+  return exchange_list(ctx, set, l);
+}
+
+static int shard_copy(gh_ctx *ctx, int set, int rank, void *buf, int64_t stride, bool pack)
+{
+  if (!ctx || !buf) return GH_ERR_INVALID;
+  int64_t first, count;
+  int rc = gh_shard_range(ctx, rank, &first, &count);
+  if (rc) return gh_fail(ctx, rc, "gh_shard_pack/unpack: no tree or bad rank");
+  if (count > stride) return gh_fail(ctx, GH_ERR_INVALID, "gh_shard_pack/unpack: stride smaller than the slice");
+  int l[16];
+  const int n = exchange_list(ctx, set, l);
+  if (n == 0) return gh_fail(ctx, GH_ERR_INVALID, "bad exchange set");
+  double *b = (double*) buf;
+  for (int a = 0; a < n; a++) {
+    double *fld = ctx->fbuf[ctx->cur][l[a]] + first;
+    if (pack) GH_CHECK(ctx, hipMemcpyAsync(b + (size_t) a*stride, fld, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
+    else GH_CHECK(ctx, hipMemcpyAsync(fld, b + (size_t) a*stride, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GH_OK;
+}
+
+extern "C" int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride)
+{
+  return ctx ? shard_copy(ctx, set, ctx->rank, dst_dev, stride, true) : GH_ERR_INVALID;
+}
+
+extern "C" int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride)
+{
+  return shard_copy(ctx, set, rank, const_cast<void*>(src_dev), stride, false);
+}
+
+extern "C" int gh_update_hmax(gh_ctx *ctx)
+{
+  if (!ctx || !ctx->tree_valid) return GH_ERR_INVALID;
+  gh_update_hmax_impl(ctx);
+  return gh_sync_collect(ctx, "gh_update_hmax");
+}
+
+extern "C" int gh_step_begin(gh_ctx *ctx)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  ctx->n++; ctx->Nsteps++;
+  gh_advance_time_impl(ctx);
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);
+  gh_phase_end(ctx, GH_T_KDK);
+  if ((rc = build_tree_timed(ctx))) return rc;
+  if ((rc = density_and_hmax(ctx, false))) return rc;
+  return gh_sync_collect(ctx, "gh_step_begin");
+}
+
+extern "C" int gh_step_forces(gh_ctx *ctx)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  if (ctx->nranks > 1) gh_update_hmax_impl(ctx);
+  gh_zero_acc_impl(ctx);
+  if ((rc = forces_impl(ctx))) return rc;
+  return gh_sync_collect(ctx, "gh_step_forces");
+}
+
+extern "C" int gh_step_end(gh_ctx *ctx, double *t, double *timestep)
+{
+  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_timestep_impl(ctx);
+  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);
+  gh_phase_end(ctx, GH_T_KDK);
+  ctx->n = 0;
+  if ((rc = gh_sync_collect(ctx, "gh_step_end"))) return rc;
+  if ((rc = pull_time(ctx))) return rc;
+  if (t) *t = ctx->t;
+  if (timestep) *timestep = ctx->timestep;
   return GH_OK;
 }
 

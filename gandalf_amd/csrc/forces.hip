@@ -278,10 +278,22 @@ __device__ __forceinline__ void point_mass(const TargetI &ti, Accum &A, double x
   for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
 }
 
+#ifdef GH_STAMPS
+#define STAMP(var) const long long var = clock64()
+#define STAMP_ADD(slot, t0) st_acc[slot] += clock64() - (t0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t0)
+#endif
+
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
+#ifdef GH_STAMPS
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_t0 = clock64();
+#endif
   __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];      // leaf mask of every stack entry
   __shared__ RangeRing s_hyd, s_dir;               // near-field leaves: hydro candidates / direct only
@@ -338,6 +350,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   int ncell = 0;
   // ---- cells: monopole                                           (NeighbourSearch.h:350-377)
   auto flush_cells = [&]() {
+    STAMP(tc0);
     __syncthreads();
     // pad to a multiple of 4 with empty entries so that the loop can be unrolled without a remainder
     if (lane < 4 && ncell + lane < GH_CCAP) { s_cmask[ncell + lane] = 0; s_cm[ncell + lane] = 0.0; s_cx[ncell + lane] = 1e30; s_cy[ncell + lane] = 1e30; s_cz[ncell + lane] = 1e30; }
@@ -354,9 +367,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     }
     __syncthreads();
     ncell = 0;
+    STAMP_ADD(1, tc0);
   };
   // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
   auto tile_dir = [&](bool valid, int j, int tag) {
+    STAMP(td0);
     {
       double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
       if (valid) v = d.posm[j];
@@ -371,9 +386,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       if (COUNT) n_direct += take ? 1 : 0;
     }
     __syncthreads();
+    STAMP_ADD(2, td0);
   };
   // ---- leaves with hydro candidates: tag = hydro-candidate leaf mask | direct leaf mask << 16
   auto tile_hyd = [&](bool valid, int j, int tag) {
+    STAMP(th0);
     {
       const double sh[3] = {0.0, 0.0, 0.0};
       stage_neib(d, ND, s_t, lane, j, sh, valid);
@@ -409,6 +426,8 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         }
       }
     }
+    STAMP_ADD(3, th0);
+    STAMP(tp0);
     while (__any(mask != 0ull)) {
       if (mask != 0ull) {
         const int c = __ffsll((long long) mask) - 1;
@@ -425,6 +444,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       }
     }
     __syncthreads();
+    STAMP_ADD(4, tp0);
   };
 
   // ---- depth-first walk with per-leaf masks                       (Tree.cpp:648-731)
@@ -435,6 +455,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
     if (ncell > 64) flush_cells();
+    STAMP(tw0);
     const int p = pop_width(top);
     const int newtop = top - p;
     unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
@@ -512,8 +533,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     Rh.nslots += wave_sum_i(ehyd ? g.N : 0);
     Rd.nslots += wave_sum_i(edir ? g.N : 0);
     __syncthreads();
+    STAMP_ADD(0, tw0);
+    STAMP(tdr0);
     if (Rh.nslots >= 64 || Rh.nrb > GH_RBCAP - 64) range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, false, tile_hyd);
     if (Rd.nslots >= 64 || Rd.nrb > GH_RBCAP - 64) range_drain_raw(s_dir.first, s_dir.cnt, s_dir.tag, s_pre, Rd, false, tile_dir);
+    STAMP_ADD(5, tdr0);
   }
   flush_cells();
   range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, true, tile_hyd);
@@ -539,6 +563,10 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     const unsigned long long a = wave_sum_u64(act ? n_pairs : 0), b = wave_sum_u64(act ? n_direct : 0), c = wave_sum_u64(act ? n_cells : 0);
     if (lane == 0) { atomicAdd(&stats[ST_PAIRS], a); atomicAdd(&stats[ST_DIRECT], b); atomicAdd(&stats[ST_CELLS], c); }
   }
+#ifdef GH_STAMPS
+  st_acc[6] = clock64() - st_t0;
+  if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&stats[ST_COUNT + k], (unsigned long long) st_acc[k]);
+#endif
 }
 
 static void fill_force_params(gh_ctx *ctx, ForceParams &P)

@@ -127,6 +127,7 @@ enum { FLAG_FRONTIER_OVERFLOW = 1, FLAG_LEAFLIST_OVERFLOW = 2, FLAG_H_NOT_CONVER
 
 // stats slots
 enum { ST_ITER = 0, ST_CAND, ST_RETRY, ST_PAIRS, ST_DIRECT, ST_CELLS, ST_COUNT };
+#define ST_TOTAL (ST_COUNT + 8)   /* + diagnostic cycle stamps (GH_STAMPS builds) */
 
 DevicePtrs gh_dev(gh_ctx *ctx);
 int gh_alloc_particles(gh_ctx *ctx, int64_t N);

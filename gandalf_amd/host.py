@@ -24,6 +24,7 @@ HOST_SYMBOLS = {
     "gah_initial_h_provided": (C.c_int, [_H]),
     "gah_get_ic": (C.c_int, [_H, _PD, _PD, _PD, _PD, _PD]),
     "gah_post_ic_setup": (C.c_int, [_H]),
+    "gah_upload_ic": (C.c_int, [_H]),
     "gah_setup": (C.c_int, [_H]),
     "gah_main_loop": (C.c_int, [_H, C.c_int]),
     "gah_time": (C.c_double, [_H]),
@@ -96,6 +97,12 @@ class Simulation:
         self._chk(self.lib.gah_get_ic(self.h, dp(ic["r"]), dp(ic["v"]), dp(ic["m"]), dp(ic["h"]), dp(ic["u"])))
         ic["initial_h_provided"] = bool(self.lib.gah_initial_h_provided(self.h))
         return ic
+
+    def upload_ic(self):
+        self._chk(self.lib.gah_upload_ic(self.h))
+
+    def initial_h_provided(self):
+        return bool(self.lib.gah_initial_h_provided(self.h))
 
     def post_ic_setup(self):
         self._chk(self.lib.gah_post_ic_setup(self.h))

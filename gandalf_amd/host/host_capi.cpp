@@ -47,6 +47,18 @@ int gah_get_ic(gah_sim *s, double *r, double *v, double *m, double *h, double *u
   return 0;
 }
 int gah_post_ic_setup(gah_sim *s) { GAH_TRY(s, s->sim->PostInitialConditionsSetup()) }
+// create the device context and upload the host particles without running the setup passes
+// (the multi-GPU runner drives those itself, with an exchange after every sliced pass)
+int gah_upload_ic(gah_sim *s)
+{
+  GAH_TRY(s, {
+    s->sim->EnsureContext();
+    const HydroParticles &p = s->sim->sph->part;
+    if (gh_upload_particles(s->sim->ctx, p.N, p.r.data(), p.v.data(), p.m.data(), p.h.data(), p.u.data()))
+      throw GandalfError(gh_last_error(s->sim->ctx));
+    s->sim->setup = true;
+  })
+}
 int gah_setup(gah_sim *s)
 {
   GAH_TRY(s, {

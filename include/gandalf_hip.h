@@ -191,6 +191,26 @@ int gh_reset_timers(gh_ctx *ctx);
 int gh_set_shard(gh_ctx *ctx, int rank, int nranks);
 /* particle range [first, first+count) (tree order) owned by a rank after the last gh_build_tree */
 int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count);
+/* exchange sets: the per-particle outputs a rank produces for its own slice in one phase.
+ * GH_X_DENSITY: h rho invomega zeta hfactor hrangesqd u sound pressure div_v   (10 arrays)
+ * GH_X_FORCES : a[ndim] atree[ndim] gpot gpot_hydro dudt div_v                 (4 + 2 ndim arrays) */
+enum { GH_X_DENSITY = 0, GH_X_FORCES = 1 };
+int gh_exchange_narrays(gh_ctx *ctx, int set);
+/* copy this rank's slice of every array of `set` into dst_dev[a*stride .. ) (device memory, doubles),
+ * a = 0 .. narrays-1; stride >= the largest slice of any rank.  Synchronous. */
+int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride);
+/* copy the slice of rank `rank` from src_dev (same layout) into the particle arrays.  Synchronous. */
+int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride);
+/* replaces: KDTree::UpdateHmaxValues (KDTree.cpp:1128-1208).  gh_update_density calls it itself when
+ * nranks == 1; with nranks > 1 the caller calls it after the density exchange. */
+int gh_update_hmax(gh_ctx *ctx);
+/* the three sections of gh_step between which a multi-GPU caller exchanges slices:
+ * begin  = clock + KDK predict + tree rebuild + density on this rank's slice   (then exchange GH_X_DENSITY)
+ * forces = UpdateHmaxValues + ZeroAccelerations + forces on this rank's slice  (then exchange GH_X_FORCES)
+ * end    = global timestep + KDK correct */
+int gh_step_begin(gh_ctx *ctx);
+int gh_step_forces(gh_ctx *ctx);
+int gh_step_end(gh_ctx *ctx, double *t, double *timestep);
 /* device pointer of a field's tree-ordered storage: component k of a vector field, k=0 for scalars */
 void *gh_field_dev(gh_ctx *ctx, int field, int k);
 
