@@ -1,0 +1,925 @@
+// oracle/gandalf_oracle.cpp -- TEST INFRASTRUCTURE, not product code.
+//
+// CPU restatement of the reference's algorithm for the hot path (GANDALF v0.4.0, double precision,
+// M4 kernel, tabulated_kernel = 0, mon97 viscosity, Nlevels = 1, no stars):
+//   KD-tree build + stocking, periodic ghosts + ghost tree, the density / h pass, the hydro force pass,
+//   the hydro + self-gravity force pass (geometric MAC, monopole), leapfrog KDK and the global timestep.
+// Every function cites the reference file:line it follows and keeps its loop order and arithmetic order
+// (same operand order, pow() where the reference calls pow(), no FMA: build with -ffp-contract=off).
+// It is pinned against the reference's own outputs (tests/golden/*.npz, written from the compiled
+// reference by scripts/make_golden.py) in tests/test_oracle.py.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+// (gandalf_amd/) never does.
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double FLOAT;
+static const FLOAT big_number = 9.9e20;         // Constants.h:72
+static const FLOAT small_number = 1.0e-20;      // Constants.h:73
+static const double small_number_dp = 1.0e-50;  // Constants.h:90
+static const double big_number_dp = 9.9e50;     // Constants.h:89
+static const FLOAT invpi = 0.31830988618379;    // Constants.h:63
+static const FLOAT twothirds = 0.66666666666666666666666;
+static const FLOAT ghost_range = 2.5;           // Hydrodynamics.h:52
+
+enum { F_DEAD = 1, F_ACTIVE = 2 };
+
+struct Part {                                   // Particle.h:133-223 + GradhSphParticle :285-368 (hot fields)
+  int flags, iorig;
+  FLOAT r[3], v[3], a[3], atree[3], r0[3], v0[3], a0[3];
+  FLOAT m, h, hrangesqd, hfactor, sound, rho, pressure, u, u0, dudt0, dudt, gpot, gpot_hydro;
+  double dt, dt_next, tlast;
+  FLOAT div_v, invomega, zeta;
+};
+
+struct Cell {                                   // TreeCellBase, TreeCell.h:16-49 (+ KDTreeCell c1, c2)
+  int cnext, copen, level, ifirst, ilast, N, Nactive, c1, c2;
+  FLOAT cdistsqd, bbmin[3], bbmax[3], hbmin[3], hbmax[3], rcell[3], r[3], v[3], m, rmax, hmax;
+};
+
+struct Params {
+  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads;
+  FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
+  FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
+};
+
+// ---------------------------------------------------------------------------------------------
+// M4 kernel, SmoothingKernel.h:131-240, M4Kernel.cpp:39-53
+// ---------------------------------------------------------------------------------------------
+struct M4 {
+  int ndim; FLOAT kernnorm, kernrange, kernrangesqd;
+  explicit M4(int nd) : ndim(nd), kernrange(2.0), kernrangesqd(4.0) {
+    kernnorm = nd == 1 ? twothirds : (nd == 2 ? invpi*(FLOAT) (10.0/7.0) : invpi);
+  }
+  FLOAT w0(FLOAT s) const {
+    if (s < 1.0) return kernnorm*(1.0 - 1.5*s*s + 0.75*s*s*s);
+    else if (s < 2.0) return 0.25*kernnorm*pow(2.0 - s, 3);
+    else return 0.0;
+  }
+  FLOAT w1(FLOAT s) const {
+    if (s < 1.0) return kernnorm*(-3.0*s + 2.25*s*s);
+    else if (s < 2.0) return -0.75*kernnorm*(2.0 - s)*(2.0 - s);
+    else return 0.0;
+  }
+  FLOAT womega(FLOAT s) const {
+    if (s < 1.0) return kernnorm*(-ndim + 1.5*(ndim + 2.0)*s*s - 0.75*(ndim + 3.0)*pow(s, 3));
+    else if (s < 2.0)
+      return kernnorm*(-2.0*ndim + 3.0*(ndim + 1.0)*s - 1.50*(ndim + 2.0)*s*s + 0.25*(ndim + 3.0)*pow(s, 3));
+    else return 0.0;
+  }
+  FLOAT wzeta(FLOAT s) const {
+    if (s < 1.0) return 1.4 - 2.0*s*s + 1.5*pow(s, 4) - 0.6*pow(s, 5);
+    else if (s < 2.0) return 1.6 - 4.0*s*s + 4.0*pow(s, 3) - 1.5*pow(s, 4) + 0.2*pow(s, 5);
+    else return 0.0;
+  }
+  FLOAT wgrav(FLOAT s) const {
+    if (s < 1.0) return 1.333333333333333333333*s - 1.2*pow(s, 3) + 0.5*pow(s, 4);
+    else if (s < 2.0)
+      return 2.6666666666666666667*s - 3.0*s*s + 1.2*pow(s, 3) - 0.166666666666666666667*pow(s, 4) -
+             0.06666666666666666667/(s*s);
+    else return 1.0/(s*s);
+  }
+  FLOAT wpot(FLOAT s) const {
+    if (s < 1.0) return 1.4 - 0.666666666666666666666666*s*s + 0.3*pow(s, 4) - 0.1*pow(s, 5);
+    else if (s < 2.0)
+      return -1.0/(15.0*s) + 1.6 - 1.33333333333333333333333333*s*s + pow(s, 3) - 0.3*pow(s, 4) +
+             (1.0/30.0)*pow(s, 5);
+    else return 1.0/s;
+  }
+};
+
+static inline FLOAT Dot(const FLOAT *a, const FLOAT *b, int nd)   // InlineFuncs.h:46-54
+{
+  if (nd == 1) return a[0]*b[0];
+  else if (nd == 2) return a[0]*b[0] + a[1]*b[1];
+  return a[0]*b[0] + a[1]*b[1] + a[2]*b[2];
+}
+
+static inline bool BoxOverlap(int nd, const FLOAT *b1min, const FLOAT *b1max, const FLOAT *b2min, const FLOAT *b2max)
+{                                                                   // InlineFuncs.h:362-390
+  for (int k = 0; k < nd; k++) {
+    if (b1min[k] > b2max[k]) return false;
+    if (b2min[k] > b1max[k]) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KD-tree, KDTree.cpp
+// ---------------------------------------------------------------------------------------------
+struct KDTree {
+  const Params *P; FLOAT kernrange;
+  int Ntot = 0, ltot = 0, gtot = 0, Ncell = 0, ifirst = -1, ilast = -1;
+  std::vector<Cell> cell;
+  std::vector<int> ids, inext;
+
+  void ComputeTreeSize() {                                          // KDTree.cpp:322-352
+    ltot = 0;
+    while (P->Nleafmax*pow(2, ltot) < Ntot) ltot++;
+    gtot = (int) pow(2, ltot);
+    Ncell = 2*gtot - 1;
+  }
+  void CreateTreeStructure() {                                      // KDTree.cpp:362-433
+    std::vector<int> c2L(ltot + 1), cNL(ltot + 1);
+    for (int l = 0; l < ltot; l++) { c2L[l] = (int) pow(2, ltot - l); cNL[l] = 2*c2L[l] - 1; }
+    cell.assign(Ncell, Cell());
+    for (int c = 0; c < Ncell; c++) {
+      Cell &x = cell[c];
+      memset(&x, 0, sizeof(Cell));
+      x.copen = -1; x.cnext = -1; x.c1 = -1; x.c2 = -1; x.ifirst = -1; x.ilast = -1;
+    }
+    cell[0].level = 0;
+    for (int c = 0; c < Ncell; c++) {
+      if (cell[c].level == ltot) cell[c].cnext = c + 1;
+      else {
+        cell[c + 1].level = cell[c].level + 1;
+        cell[c].copen = c + 1; cell[c].c1 = c + 1; cell[c].c2 = c + c2L[cell[c].level];
+        cell[cell[c].c2].level = cell[c].level + 1;
+        cell[c].cnext = c + cNL[cell[c].level];
+      }
+    }
+  }
+  FLOAT QuickSelect(int left, int right, int jpivot, int k, const std::vector<Part> &p) {   // KDTree.cpp:682-750
+    int j, jguess, jtemp; FLOAT rpivot;
+    do {
+      jguess = (left + right)/2;
+      rpivot = p[ids[jguess]].r[k];
+      jtemp = ids[jguess]; ids[jguess] = ids[right]; ids[right] = jtemp;
+      jguess = left;
+      for (j = left; j < right; j++) {
+        if (p[ids[j]].r[k] <= rpivot) { jtemp = ids[j]; ids[j] = ids[jguess]; ids[jguess] = jtemp; jguess++; }
+      }
+      jtemp = ids[right]; ids[right] = ids[jguess]; ids[jguess] = jtemp;
+      if (jguess < jpivot) left = jguess + 1;
+      else if (jguess > jpivot) right = jguess - 1;
+    } while (jguess != jpivot);
+    return rpivot;
+  }
+  void StockCellProperties(Cell &c, const std::vector<Part> &p) {   // KDTree.cpp:808-1083 (monopole, geometric MAC)
+    const int nd = P->ndim;
+    FLOAT dr[3];
+    c.Nactive = 0; c.N = 0; c.m = 0.0; c.hmax = 0.0; c.rmax = 0.0; c.cdistsqd = big_number;
+    for (int k = 0; k < nd; k++) { c.r[k] = 0.0; c.v[k] = 0.0; c.rcell[k] = 0.0; c.bbmin[k] = big_number; c.bbmax[k] = -big_number;
+                                   c.hbmin[k] = big_number; c.hbmax[k] = -big_number; }
+    if (c.level == ltot) {
+      int i = c.ifirst;
+      while (i != -1) {
+        c.N++;
+        if (p[i].flags & F_ACTIVE) c.Nactive++;
+        c.hmax = std::max(c.hmax, p[i].h);
+        c.m += p[i].m;
+        for (int k = 0; k < nd; k++) c.r[k] += p[i].m*p[i].r[k];
+        for (int k = 0; k < nd; k++) c.v[k] += p[i].m*p[i].v[k];
+        for (int k = 0; k < nd; k++) {
+          if (p[i].r[k] < c.bbmin[k]) c.bbmin[k] = p[i].r[k];
+          if (p[i].r[k] > c.bbmax[k]) c.bbmax[k] = p[i].r[k];
+          if (p[i].r[k] - kernrange*p[i].h < c.hbmin[k]) c.hbmin[k] = p[i].r[k] - kernrange*p[i].h;
+          if (p[i].r[k] + kernrange*p[i].h > c.hbmax[k]) c.hbmax[k] = p[i].r[k] + kernrange*p[i].h;
+        }
+        if (i == c.ilast) break;
+        i = inext[i];
+      }
+      if (c.m > 0) { for (int k = 0; k < nd; k++) c.r[k] /= c.m; for (int k = 0; k < nd; k++) c.v[k] /= c.m; }
+      if (c.N > 0) {
+        for (int k = 0; k < nd; k++) c.rcell[k] = 0.5*(c.bbmin[k] + c.bbmax[k]);
+        for (int k = 0; k < nd; k++) dr[k] = 0.5*(c.bbmax[k] - c.bbmin[k]);
+        c.cdistsqd = std::max(Dot(dr, dr, nd), c.hmax*c.hmax)/P->thetamaxsqd;
+        c.rmax = sqrt(Dot(dr, dr, nd));
+      }
+    }
+    else {
+      const Cell &c1 = cell[c.copen], &c2 = cell[cell[c.copen].cnext];
+      const Cell *ch[2] = {&c1, &c2};
+      for (int q = 0; q < 2; q++) {
+        if (ch[q]->N > 0) {
+          for (int k = 0; k < nd; k++) { c.bbmin[k] = std::min(ch[q]->bbmin[k], c.bbmin[k]); c.bbmax[k] = std::max(ch[q]->bbmax[k], c.bbmax[k]);
+                                         c.hbmin[k] = std::min(ch[q]->hbmin[k], c.hbmin[k]); c.hbmax[k] = std::max(ch[q]->hbmax[k], c.hbmax[k]); }
+          c.hmax = std::max(c.hmax, ch[q]->hmax);
+        }
+      }
+      c.N = c1.N + c2.N; c.Nactive = c1.Nactive + c2.Nactive; c.m = c1.m + c2.m;
+      if (c.m > 0) {
+        for (int k = 0; k < nd; k++) c.r[k] = (c1.m*c1.r[k] + c2.m*c2.r[k])/c.m;
+        for (int k = 0; k < nd; k++) c.v[k] = (c1.m*c1.v[k] + c2.m*c2.v[k])/c.m;
+      }
+      if (c.N > 0) {
+        for (int k = 0; k < nd; k++) c.rcell[k] = 0.5*(c.bbmin[k] + c.bbmax[k]);
+        for (int k = 0; k < nd; k++) dr[k] = 0.5*(c.bbmax[k] - c.bbmin[k]);
+        c.cdistsqd = std::max(Dot(dr, dr, nd), c.hmax*c.hmax)/P->thetamaxsqd;
+        c.rmax = sqrt(Dot(dr, dr, nd));
+      }
+    }
+  }
+  void DivideTreeCell(int first, int last, const std::vector<Part> &p, Cell &c) {   // KDTree.cpp:442-595
+    const int nd = P->ndim;
+    if (c.level == ltot) {
+      if (c.N > 0) {
+        for (int j = c.ifirst; j < c.ilast; j++) inext[ids[j]] = ids[j + 1];
+        c.ifirst = ids[c.ifirst]; c.ilast = ids[c.ilast];
+      }
+      else { c.ifirst = -1; c.ilast = -1; }
+      StockCellProperties(c, p);
+      return;
+    }
+    int k_divide = 0; FLOAT rkmax = 0.0;
+    for (int k = 0; k < nd; k++) if (c.bbmax[k] - c.bbmin[k] > rkmax) { rkmax = c.bbmax[k] - c.bbmin[k]; k_divide = k; }
+    const FLOAT rdivide = QuickSelect(c.ifirst, c.ilast, c.ifirst + c.N/2, k_divide, p);
+    Cell &a = cell[c.c1], &b = cell[c.c2];
+    for (int k = 0; k < nd; k++) { a.bbmin[k] = c.bbmin[k]; a.bbmax[k] = c.bbmax[k]; b.bbmin[k] = c.bbmin[k]; b.bbmax[k] = c.bbmax[k]; }
+    a.bbmax[k_divide] = rdivide; a.N = c.N/2;
+    if (a.N != 0) { a.ifirst = first; a.ilast = first + c.N/2 - 1; }
+    b.bbmin[k_divide] = rdivide; b.N = c.N - a.N;
+    if (b.N != 0) { b.ifirst = first + c.N/2; b.ilast = last; }
+    DivideTreeCell(first, first + c.N/2 - 1, p, a);
+    DivideTreeCell(first + c.N/2, last, p, b);
+    if (a.N > 0) { c.ifirst = a.ifirst; inext[a.ilast] = b.ifirst; }
+    else c.ifirst = b.ifirst;
+    c.ilast = b.ilast;
+    StockCellProperties(c, p);
+  }
+  void BuildTree(int _ifirst, int Npart, const std::vector<Part> &p) {              // KDTree.cpp:220-313
+    const int nd = P->ndim;
+    Ntot = Npart;
+    ComputeTreeSize();
+    CreateTreeStructure();
+    if ((int) ids.size() < (int) p.size()) { ids.resize(p.size()); inext.resize(p.size()); }
+    FLOAT bbmin[3], bbmax[3];
+    for (int k = 0; k < nd; k++) { bbmin[k] = big_number; bbmax[k] = -big_number; }
+    if (Npart > 0) {
+      ifirst = _ifirst; ilast = _ifirst + Npart - 1;
+      for (int i = ifirst; i <= ilast; i++)
+        for (int k = 0; k < nd; k++) {
+          bbmax[k] = std::max(bbmax[k], p[i].r[k] + kernrange*p[i].h);
+          bbmin[k] = std::min(bbmin[k], p[i].r[k] - kernrange*p[i].h);
+        }
+      for (int i = ifirst; i <= ilast; i++) ids[i] = i;
+      for (int i = ifirst; i < ilast; i++) inext[i] = i + 1;
+      inext[ilast] = -1;
+    }
+    else { ifirst = -1; ilast = -1; }
+    cell[0].N = Ntot; cell[0].ifirst = ifirst; cell[0].ilast = ilast; cell[0].hmax = 0;
+    for (int k = 0; k < nd; k++) { cell[0].bbmin[k] = bbmin[k]; cell[0].bbmax[k] = bbmax[k]; }
+    if (Ntot > 0) DivideTreeCell(ifirst, ilast, p, cell[0]);
+  }
+  void UpdateHmaxValues(Cell &c, const std::vector<Part> &p) {      // KDTree.cpp:1128-1208
+    const int nd = P->ndim;
+    if (c.level != ltot) { UpdateHmaxValues(cell[c.c1], p); UpdateHmaxValues(cell[c.c2], p); }
+    c.hmax = 0.0;
+    for (int k = 0; k < nd; k++) { c.hbmin[k] = big_number; c.hbmax[k] = -big_number; }
+    if (c.level == ltot) {
+      int i = c.ifirst;
+      while (i != -1) {
+        c.hmax = std::max(c.hmax, p[i].h);
+        for (int k = 0; k < nd; k++) {
+          if (p[i].r[k] - kernrange*p[i].h < c.hbmin[k]) c.hbmin[k] = p[i].r[k] - kernrange*p[i].h;
+          if (p[i].r[k] + kernrange*p[i].h > c.hbmax[k]) c.hbmax[k] = p[i].r[k] + kernrange*p[i].h;
+        }
+        if (i == c.ilast) break;
+        i = inext[i];
+      }
+    }
+    else {
+      const Cell *ch[2] = {&cell[c.c1], &cell[c.c2]};
+      for (int q = 0; q < 2; q++) if (ch[q]->N > 0) {
+        c.hmax = std::max(c.hmax, ch[q]->hmax);
+        for (int k = 0; k < nd; k++) { c.hbmin[k] = std::min(ch[q]->hbmin[k], c.hbmin[k]); c.hbmax[k] = std::max(ch[q]->hbmax[k], c.hbmax[k]); }
+      }
+    }
+  }
+  // Tree::ComputeGatherNeighbourList (cell version), Tree.cpp:291-381
+  void GatherList(const Cell &c, const std::vector<Part> &p, FLOAT hmax, std::vector<int> &list) const {
+    if (Ncell == 0 || Ntot == 0) return;
+    const int nd = P->ndim;
+    const size_t start = list.size();
+    FLOAT gmin[3], gmax[3];
+    const FLOAT hrangemaxsqd = pow(c.rmax + kernrange*hmax, 2);
+    for (int k = 0; k < nd; k++) { gmin[k] = c.bbmin[k] - kernrange*hmax; gmax[k] = c.bbmax[k] + kernrange*hmax; }
+    int cc = 0;
+    while (cc < Ncell) {
+      if (BoxOverlap(nd, gmin, gmax, cell[cc].bbmin, cell[cc].bbmax)) {
+        if (cell[cc].copen != -1) cc = cell[cc].copen;
+        else if (cell[cc].N == 0) cc = cell[cc].cnext;
+        else {
+          int i = cell[cc].ifirst;
+          while (i != -1) { list.push_back(i); if (i == cell[cc].ilast) break; i = inext[i]; }
+          cc = cell[cc].cnext;
+        }
+      }
+      else cc = cell[cc].cnext;
+    }
+    size_t keep = start;
+    FLOAT dr[3];
+    for (size_t j = start; j < list.size(); j++) {
+      const int i = list[j];
+      for (int k = 0; k < nd; k++) dr[k] = p[i].r[k] - c.rcell[k];
+      if (Dot(dr, dr, nd) < hrangemaxsqd) list[keep++] = i;
+    }
+    list.resize(keep);
+  }
+  // Tree::ComputeGatherNeighbourList (point version), Tree.cpp:208-280
+  void GatherPoint(const FLOAT *rp, FLOAT rsearch, const std::vector<Part> &p, std::vector<int> &list) const {
+    if (Ncell == 0 || Ntot == 0) return;
+    const int nd = P->ndim;
+    const FLOAT rsearchsqd = rsearch*rsearch;
+    FLOAT dr[3];
+    int cc = 0;
+    while (cc < Ncell) {
+      for (int k = 0; k < nd; k++) dr[k] = cell[cc].rcell[k] - rp[k];
+      if (Dot(dr, dr, nd) < (rsearch + cell[cc].rmax)*(rsearch + cell[cc].rmax)) {
+        if (cell[cc].copen != -1) cc = cell[cc].copen;
+        else if (cell[cc].N == 0) cc = cell[cc].cnext;
+        else {
+          int i = cell[cc].ifirst;
+          while (i != -1) {
+            for (int k = 0; k < nd; k++) dr[k] = p[i].r[k] - rp[k];
+            if (Dot(dr, dr, nd) < rsearchsqd) list.push_back(i);
+            if (i == cell[cc].ilast) break;
+            i = inext[i];
+          }
+          cc = cell[cc].cnext;
+        }
+      }
+      else cc = cell[cc].cnext;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct Oracle {
+  Params P; M4 kern; FLOAT invndim;
+  std::vector<Part> p;          // [0,Nhydro) real, then periodic ghosts
+  int Nhydro = 0, Nghost = 0;
+  KDTree tree, ghosttree;
+  int n = 0, Nsteps = 0; double t = 0.0, timestep = 0.0;
+  std::string err;
+  explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim), invndim(1.0/pp.ndim) {
+    tree.P = &P; ghosttree.P = &P; tree.kernrange = kern.kernrange; ghosttree.kernrange = kern.kernrange;
+  }
+  FLOAT h_rho_func(FLOAT m, FLOAT rho) const { return P.h_fac*pow(m/rho, invndim); }   // Sph.h:259
+  FLOAT h_rho_deriv(FLOAT h, FLOAT rho) const { return -invndim*h/rho; }               // Sph.h:264
+  bool any_periodic() const { return P.periodic[0] || P.periodic[1] || P.periodic[2]; }
+
+  // ---- ghosts: HydroTree::SearchBoundaryGhostParticles HydroTree.cpp:495-543, Tree.cpp:1098-1149,
+  //      Hydrodynamics.cpp:217-289
+  void CheckBoundaryGhostParticle(int i, int j) {
+    const FLOAT r = p[i].r[j], h = p[i].h;
+    if (r < P.boxmin[j] + ghost_range*kern.kernrange*h && P.periodic[j]) CreateGhost(i, j, r + P.boxsize[j]);
+    if (r > P.boxmax[j] - ghost_range*kern.kernrange*h && P.periodic[j]) CreateGhost(i, j, r - P.boxsize[j]);
+  }
+  void CreateGhost(int i, int k, FLOAT rk) {
+    Part g = p[i];
+    g.r[k] = rk; g.flags &= ~F_ACTIVE; g.iorig = i;
+    p.push_back(g);
+    Nghost++;
+  }
+  void SearchBoundaryGhostParticles() {
+    p.resize(Nhydro); Nghost = 0;
+    if (!any_periodic()) return;
+    const FLOAT grange = ghost_range*kern.kernrange;
+    int Ntot = Nhydro;
+    for (int j = 0; j < P.ndim; j++) {
+      if (!P.periodic[j]) continue;
+      int c = 0;
+      while (c < tree.Ncell) {                                       // Tree::GenerateBoundaryGhostParticles (tghost = 0)
+        const Cell &x = tree.cell[c];
+        if (x.bbmin[j] < P.boxmin[j] + grange*x.hmax || x.bbmax[j] > P.boxmax[j] - grange*x.hmax) {
+          if (x.copen != -1) c = x.copen;
+          else if (x.N == 0) c = x.cnext;
+          else {
+            int i = x.ifirst;
+            while (i != -1) { CheckBoundaryGhostParticle(i, j); if (i == x.ilast) break; i = tree.inext[i]; }
+            c = x.cnext;
+          }
+        }
+        else c = x.cnext;
+      }
+      if (j > 0) for (int i = Nhydro; i < Ntot; i++) CheckBoundaryGhostParticle(i, j);
+      Ntot = Nhydro + Nghost;
+    }
+  }
+  void BuildTree() { p.resize(Nhydro); Nghost = 0; tree.BuildTree(0, Nhydro, p); }
+  void BuildGhostTree() { ghosttree.BuildTree(Nhydro, Nghost, p); }
+
+  // ---- GradhSph::ComputeH, GradhSph.cpp:142-326 (no sinks, no stars) + ComputeThermalProperties :335-347
+  int ComputeH(Part &pi, FLOAT hmax, const std::vector<int> &ngb2) const {
+    const int nd = P.ndim;
+    int iteration = 0; const int iteration_max = 30;
+    FLOAT dr[3], h_lower_bound = 0.0, h_upper_bound = hmax, invh, invhsqd, ssqd;
+    const int Nneib = (int) ngb2.size();
+    do {
+      iteration++;
+      invh = 1.0/pi.h;
+      pi.rho = 0.0; pi.invomega = 0.0; pi.zeta = 0.0;
+      pi.hfactor = pow(invh, nd);
+      invhsqd = invh*invh;
+      for (int j = 0; j < Nneib; j++) {
+        const Part &ngb = p[ngb2[j]];
+        for (int k = 0; k < nd; k++) dr[k] = ngb.r[k] - pi.r[k];
+        ssqd = invhsqd*Dot(dr, dr, nd);
+        const FLOAT s = sqrt(ssqd);                                  // w0_s2 = w0(sqrt(s)), SmoothingKernel.h:78-80
+        pi.rho += ngb.m*kern.w0(s);
+        pi.invomega += ngb.m*invh*kern.womega(s);
+        pi.zeta += ngb.m*kern.wzeta(s);
+      }
+      pi.rho *= pi.hfactor; pi.invomega *= pi.hfactor; pi.zeta *= invhsqd;
+      if (pi.rho > 0.0 && pi.h > h_lower_bound && fabs(pi.h - h_rho_func(pi.m, pi.rho))*invh < P.h_converge) break;
+      if (iteration < iteration_max) pi.h = h_rho_func(pi.m, pi.rho);
+      else if (iteration == iteration_max) pi.h = 0.5*(h_lower_bound + h_upper_bound);
+      else if (iteration < 5*iteration_max) {
+        if (pi.rho < small_number || pi.h > h_rho_func(pi.m, pi.rho)) h_upper_bound = pi.h;
+        else h_lower_bound = pi.h;
+        pi.h = 0.5*(h_lower_bound + h_upper_bound);
+      }
+      else return -2;
+      if (pi.h > hmax) return 0;
+    } while (pi.h > h_lower_bound && pi.h < h_upper_bound);
+    pi.h = std::max(h_rho_func(pi.m, pi.rho), h_lower_bound);
+    invh = 1/pi.h;
+    pi.hfactor = pow(invh, nd + 1);
+    pi.hrangesqd = kern.kernrangesqd*pi.h*pi.h;
+    pi.div_v = 0.0;
+    pi.invomega = 1.0 - h_rho_deriv(pi.h, pi.rho)*pi.invomega;
+    pi.invomega = 1.0/pi.invomega;
+    pi.zeta = h_rho_deriv(pi.h, pi.rho)*pi.zeta*pi.invomega;
+    // energy_eqn EOS: AdiabaticEOS.cpp:69-82, EOS.h:156
+    pi.sound = sqrt(P.gamma*(P.gamma - 1.0)*pi.u);
+    pi.pressure = (P.gamma - 1.0)*pi.rho*pi.u;
+    return pi.h <= hmax ? 1 : -1;
+  }
+
+  std::vector<int> ActiveLeafCells() const {                         // Tree::ComputeActiveCellList, Tree.cpp:91-115
+    std::vector<int> out;
+    for (int c = 0; c < tree.Ncell; c++)
+      if (tree.cell[c].N <= P.Nleafmax && tree.cell[c].copen == -1 && tree.cell[c].Nactive > 0) out.push_back(c);
+    return out;
+  }
+  int ActiveParticles(const Cell &c, int *list) const {              // Tree.cpp:60-81
+    int i = c.ifirst, N = 0;
+    while (i != -1) {
+      if (i < Nhydro && (p[i].flags & F_ACTIVE)) list[N++] = i;
+      if (i == c.ilast) break;
+      i = tree.inext[i];
+    }
+    return N;
+  }
+
+  // ---- GradhSphTree::UpdateAllSphProperties, GradhSphTree.cpp:83-271
+  int UpdateAllSphProperties() {
+    const std::vector<int> cl = ActiveLeafCells();
+    const int nd = P.ndim;
+    int bad = 0;
+#pragma omp parallel for schedule(guided) reduction(+:bad) num_threads(P.nthreads)
+    for (int cc = 0; cc < (int) cl.size(); cc++) {
+      const Cell cellc = tree.cell[cl[cc]];
+      std::vector<int> neiblist, ngb2;
+      int activelist[64]; Part activepart[64];
+      FLOAT hmax = cellc.hmax;
+      int celldone, Nactive;
+      do {
+        hmax = 1.05*hmax;
+        celldone = 1;
+        Nactive = ActiveParticles(cellc, activelist);
+        for (int j = 0; j < Nactive; j++) activepart[j] = p[activelist[j]];
+        neiblist.clear();
+        tree.GatherList(cellc, p, hmax, neiblist);
+        ghosttree.GatherList(cellc, p, hmax, neiblist);
+        for (int j = 0; j < Nactive; j++) {
+          const FLOAT hrangesqd = kern.kernrangesqd*hmax*hmax;
+          ngb2.clear();
+          FLOAT draux[3];
+          for (size_t jj = 0; jj < neiblist.size(); jj++) {
+            for (int k = 0; k < nd; k++) draux[k] = p[neiblist[jj]].r[k] - activepart[j].r[k];
+            const FLOAT drsqdaux = Dot(draux, draux, nd) + small_number;
+            if (drsqdaux <= hrangesqd) ngb2.push_back(neiblist[jj]);
+          }
+          const int ok = ComputeH(activepart[j], hmax, ngb2);
+          if (ok == -2) bad++;
+          if (ok == 0) { celldone = 0; break; }
+        }
+      } while (celldone == 0);
+      // the write-back only touches fields ComputeH changes (the reference copies whole particles, :244)
+      for (int j = 0; j < Nactive; j++) p[activelist[j]] = activepart[j];
+    }
+    tree.UpdateHmaxValues(tree.cell[0], p);                         // :268
+    return bad;
+  }
+
+  void ZeroAccelerations() {                                        // Sph.cpp:126-140
+    for (int i = 0; i < Nhydro; i++) {
+      if (!(p[i].flags & F_ACTIVE)) continue;
+      p[i].div_v = 0.0; p[i].dudt = 0.0; p[i].gpot = 0.0; p[i].gpot_hydro = 0.0;
+      for (int k = 0; k < 3; k++) { p[i].a[k] = 0.0; p[i].atree[k] = 0.0; }
+    }
+  }
+
+  // nearest periodic image helpers, GhostNeighbours.hpp:119-166, 343-357
+  bool NearestPeriodicVector(FLOAT *dr) const {
+    bool any = false;
+    for (int k = 0; k < P.ndim; k++) if (P.periodic[k]) {
+      if (dr[k] > P.boxhalf[k]) { dr[k] -= P.boxsize[k]; any = true; }
+      else if (dr[k] < -P.boxhalf[k]) { dr[k] += P.boxsize[k]; any = true; }
+    }
+    return any;
+  }
+  void MakePeriodicGhost(Part &q, const FLOAT *centre) const {
+    FLOAT dr[3];
+    for (int k = 0; k < P.ndim; k++) dr[k] = q.r[k] - centre[k];
+    if (NearestPeriodicVector(dr)) for (int k = 0; k < P.ndim; k++) q.r[k] = centre[k] + dr[k];
+  }
+  void ApplyPeriodicDistanceCorrection(FLOAT *r, FLOAT *dr) const {
+    for (int k = 0; k < P.ndim; k++) if (P.periodic[k]) {
+      if (dr[k] > P.boxhalf[k]) { dr[k] += -P.boxsize[k]; r[k] += -P.boxsize[k]; }
+      else if (dr[k] < -P.boxhalf[k]) { dr[k] += P.boxsize[k]; r[k] += P.boxsize[k]; }
+    }
+  }
+  bool PeriodicBoxOverlap(const FLOAT *b1min, const FLOAT *b1max, const FLOAT *b2min, const FLOAT *b2max) const {
+    const int nd = P.ndim;                                          // GhostNeighbours.hpp:202-226
+    if (!any_periodic()) return BoxOverlap(nd, b1min, b1max, b2min, b2max);
+    FLOAT dr[3], corr[3] = {0, 0, 0}; bool any = false;
+    for (int k = 0; k < nd; k++) dr[k] = 0.5*((b2max[k] + b2min[k]) - (b1max[k] + b1min[k]));
+    for (int k = 0; k < nd; k++) if (P.periodic[k]) {
+      if (dr[k] > P.boxhalf[k]) { corr[k] = -P.boxsize[k]; any = true; }
+      else if (dr[k] < -P.boxhalf[k]) { corr[k] = P.boxsize[k]; any = true; }
+      else corr[k] = 0;
+    }
+    if (any) {
+      FLOAT pmin[3], pmax[3];
+      for (int k = 0; k < nd; k++) { pmin[k] = b2min[k] + corr[k]; pmax[k] = b2max[k] + corr[k]; }
+      return BoxOverlap(nd, b1min, b1max, pmin, pmax);
+    }
+    return BoxOverlap(nd, b1min, b1max, b2min, b2max);
+  }
+
+  // ---- one SPH pair of ComputeSphHydroForces (GradhSph.cpp:384-448) / ComputeSphHydroGravForces (:498-572)
+  template <bool GRAV> void SphPair(Part &pi, const Part &nb, const FLOAT *r_nb) const {
+    const int nd = P.ndim;
+    const FLOAT invh_i = 1/pi.h, invrho_i = 1/pi.rho, invh_j = 1/nb.h, invrho_j = 1/nb.rho;
+    FLOAT dr[3], dv[3], drmag, dvdr, wkerni, wkernj, paux;
+    for (int k = 0; k < nd; k++) dr[k] = r_nb[k] - pi.r[k];
+    if (GRAV) {
+      for (int k = 0; k < nd; k++) dv[k] = nb.v[k] - pi.v[k];
+      drmag = sqrt(Dot(dr, dr, nd) + small_number);
+      const FLOAT invdrmag = 1.0/drmag;
+      for (int k = 0; k < nd; k++) dr[k] *= invdrmag;
+      dvdr = Dot(dv, dr, nd);
+    }
+    else {
+      drmag = sqrt(Dot(dr, dr, nd));
+      if (drmag > 0) for (int k = 0; k < nd; k++) dr[k] /= drmag;
+      dvdr = Dot(nb.v, dr, nd);
+      dvdr -= Dot(pi.v, dr, nd);
+    }
+    wkerni = pi.hfactor*kern.w1(drmag*invh_i);
+    wkernj = nb.hfactor*kern.w1(drmag*invh_j);
+    if (!GRAV) pi.div_v -= nb.m*dvdr*wkerni;
+    paux = ((pi.pressure*pi.invomega)/(pi.rho*pi.rho))*wkerni + ((nb.pressure*nb.invomega)/(nb.rho*nb.rho))*wkernj;
+    if (dvdr < 0.0) {
+      const FLOAT winvrho = 0.25*(wkerni + wkernj)*(invrho_i + invrho_j);
+      const FLOAT vsignal = pi.sound + nb.sound - P.beta_visc*P.alpha_visc*dvdr;      // mon97
+      paux -= P.alpha_visc*vsignal*dvdr*winvrho;
+      pi.dudt -= 0.5*nb.m*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;
+    }
+    for (int k = 0; k < nd; k++) pi.a[k] += nb.m*dr[k]*paux;
+    if (GRAV) {
+      const FLOAT invhsqdi = invh_i*invh_i;
+      paux = 0.5*(invhsqdi*kern.wgrav(drmag*invh_i) + pi.zeta*wkerni + invh_j*invh_j*kern.wgrav(drmag*invh_j) + nb.zeta*wkernj);
+      for (int k = 0; k < nd; k++) pi.atree[k] += nb.m*dr[k]*paux;
+      pi.gpot += 0.5*nb.m*(invh_i*kern.wpot(drmag*invh_i) + invh_j*kern.wpot(drmag*invh_j));
+      pi.div_v -= nb.m*dvdr*wkerni;
+    }
+  }
+
+  // ---- GradhSphTree::UpdateAllSphHydroForces (GradhSphTree.cpp:280-435) and UpdateAllSphForces (:444-657)
+  template <bool GRAV> void UpdateForces() {
+    const std::vector<int> cl = ActiveLeafCells();
+    const int nd = P.ndim;
+#pragma omp parallel for schedule(guided) num_threads(P.nthreads)
+    for (int cc = 0; cc < (int) cl.size(); cc++) {
+      const Cell cellc = tree.cell[cl[cc]];
+      int activelist[64]; Part activepart[64];
+      const int Nactive = ActiveParticles(cellc, activelist);
+      for (int j = 0; j < Nactive; j++) {
+        activepart[j] = p[activelist[j]];
+        activepart[j].div_v = 0.0; activepart[j].dudt = 0.0;
+        activepart[j].gpot = GRAV ? (activepart[j].m/activepart[j].h)*kern.wpot(0.0) : 0.0;
+        for (int k = 0; k < 3; k++) { activepart[j].a[k] = 0.0; if (GRAV) activepart[j].atree[k] = 0.0; }
+      }
+      // ---- walks: Tree::ComputeNeighbourAndGhostList Tree.cpp:562-617 /
+      //             Tree::ComputeGravityInteractionAndGhostList Tree.cpp:628-735
+      std::vector<int> tempperneib, tempdirectneib;
+      struct MP { FLOAT r[3], m; };
+      std::vector<MP> gravcell;
+      {
+        const FLOAT hrangemax = kern.kernrange*cellc.hmax, rmax = cellc.rmax;
+        int c = 0; FLOAT dr[3];
+        while (c < tree.Ncell) {
+          const Cell &o = tree.cell[c];
+          bool near;
+          FLOAT drsqd = 0.0;
+          if (GRAV) {
+            for (int k = 0; k < nd; k++) dr[k] = o.rcell[k] - cellc.rcell[k];
+            NearestPeriodicVector(dr);
+            drsqd = Dot(dr, dr, nd);
+            near = drsqd <= pow(o.rmax + rmax + hrangemax, 2) || drsqd <= pow(rmax + o.rmax + kern.kernrange*o.hmax, 2);
+          }
+          else near = PeriodicBoxOverlap(cellc.bbmin, cellc.bbmax, o.hbmin, o.hbmax) ||
+                      PeriodicBoxOverlap(cellc.hbmin, cellc.hbmax, o.bbmin, o.bbmax);
+          if (near) {
+            if (o.copen != -1) c = o.copen;
+            else if (o.N == 0) c = o.cnext;
+            else {
+              int i = o.ifirst;
+              while (i != -1) { tempperneib.push_back(i); if (i == o.ilast) break; i = tree.inext[i]; }
+              c = o.cnext;
+            }
+          }
+          else if (!GRAV) c = o.cnext;
+          else if (o.N == 0) c = o.cnext;
+          else if (!(drsqd < o.cdistsqd)) {                          // !open_cell_for_gravity, Tree.h:413-432 (geometric)
+            if (o.copen == -1 && o.N == 1) tempdirectneib.push_back(o.ifirst);
+            else { MP m; for (int k = 0; k < 3; k++) m.r[k] = o.r[k]; m.m = o.m; gravcell.push_back(m); }
+            c = o.cnext;
+          }
+          else {
+            if (o.copen != -1) c = o.copen;
+            else {
+              int i = o.ifirst;
+              while (i != -1) { tempdirectneib.push_back(i); if (i == o.ilast) break; i = tree.inext[i]; }
+              c = o.cnext;
+            }
+          }
+        }
+      }
+      // ---- NeighbourManager::_EndSearch, NeighbourManager.h:368-474
+      std::vector<Part> neibdata; std::vector<int> neiblist, directlist;
+      {
+        const FLOAT hrangemaxsqd = pow(cellc.rmax + kern.kernrange*cellc.hmax, 2), rmax = cellc.rmax;
+        FLOAT dr[3];
+        if (GRAV) for (size_t ii = 0; ii < tempdirectneib.size(); ii++) {
+          neibdata.push_back(p[tempdirectneib[ii]]);
+          if (any_periodic()) MakePeriodicGhost(neibdata.back(), cellc.rcell);
+          directlist.push_back((int) neibdata.size() - 1);
+        }
+        for (size_t ii = 0; ii < tempperneib.size(); ii++) {
+          Part q = p[tempperneib[ii]];
+          if (any_periodic()) MakePeriodicGhost(q, cellc.rcell);
+          for (int k = 0; k < nd; k++) dr[k] = q.r[k] - cellc.rcell[k];
+          const FLOAT drsqd = Dot(dr, dr, nd);
+          const FLOAT h2 = rmax + kern.kernrange*q.h;
+          if (drsqd < hrangemaxsqd || drsqd < h2*h2) { neibdata.push_back(q); neiblist.push_back((int) neibdata.size() - 1); }
+          else if (GRAV) { neibdata.push_back(q); directlist.push_back((int) neibdata.size() - 1); }
+        }
+      }
+      const size_t NCellDirectNeib = directlist.size();
+      // ---- per particle: TrimNeighbourLists NeighbourManager.h:483-543, then the force operators
+      for (int j = 0; j < Nactive; j++) {
+        Part &pi = activepart[j];
+        std::vector<int> culled;
+        directlist.resize(NCellDirectNeib);
+        FLOAT draux[3];
+        for (size_t jj = 0; jj < neiblist.size(); jj++) {
+          Part &nb = neibdata[neiblist[jj]];
+          for (int k = 0; k < nd; k++) draux[k] = nb.r[k] - pi.r[k];
+          if (any_periodic()) ApplyPeriodicDistanceCorrection(nb.r, draux);
+          const FLOAT drsqd = Dot(draux, draux, nd);
+          if (drsqd >= pi.hrangesqd && drsqd >= nb.hrangesqd) { if (GRAV) directlist.push_back(neiblist[jj]); }
+          else culled.push_back(neiblist[jj]);
+        }
+        for (size_t jj = 0; jj < culled.size(); jj++) SphPair<GRAV>(pi, neibdata[culled[jj]], neibdata[culled[jj]].r);
+        const FLOAT invrho_i = 1/pi.rho;
+        pi.div_v *= invrho_i;                                         // GradhSph.cpp:452-453 / 577-578
+        pi.dudt -= pi.pressure*pi.div_v*invrho_i*pi.invomega;
+        if (GRAV) {
+          // ComputeDirectGravForces, GradhSph.cpp:657-690
+          for (size_t jj = 0; jj < directlist.size(); jj++) {
+            const Part &g = neibdata[directlist[jj]];
+            FLOAT dr[3];
+            for (int k = 0; k < nd; k++) dr[k] = g.r[k] - pi.r[k];
+            const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+            const FLOAT invdrmag = 1.0/sqrt(drsqd);
+            const FLOAT invdr3 = invdrmag*invdrmag*invdrmag;
+            for (int k = 0; k < nd; k++) pi.atree[k] += g.m*dr[k]*invdr3;
+            pi.gpot += g.m*invdrmag;
+          }
+          // ComputeCellMonopoleForces, NeighbourSearch.h:350-377
+          for (size_t jj = 0; jj < gravcell.size(); jj++) {
+            FLOAT dr[3];
+            for (int k = 0; k < nd; k++) dr[k] = gravcell[jj].r[k] - pi.r[k];
+            const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+            const FLOAT invdrsqd = 1.0/drsqd;
+            const FLOAT invdrmag = sqrt(invdrsqd);
+            const FLOAT invdr3 = invdrsqd*invdrmag;
+            pi.gpot += gravcell[jj].m*invdrmag;
+            for (int k = 0; k < nd; k++) pi.atree[k] += gravcell[jj].m*dr[k]*invdr3;
+          }
+          pi.gpot_hydro = pi.gpot;
+        }
+      }
+      for (int j = 0; j < Nactive; j++) {                             // GradhSphTree.cpp:396-404 / 610-619
+        const int i = activelist[j];
+        for (int k = 0; k < nd; k++) p[i].a[k] += activepart[j].a[k];
+        if (GRAV) {
+          for (int k = 0; k < nd; k++) p[i].a[k] += activepart[j].atree[k];
+          for (int k = 0; k < nd; k++) p[i].atree[k] += activepart[j].atree[k];
+          p[i].gpot_hydro += activepart[j].gpot_hydro;
+        }
+        p[i].gpot += activepart[j].gpot;
+        p[i].dudt += activepart[j].dudt;
+        p[i].div_v += activepart[j].div_v;
+      }
+    }
+  }
+  void Forces() { if (P.self_gravity) UpdateForces<true>(); else UpdateForces<false>(); }
+
+  // ---- time integration: SphLeapfrogKDK.cpp:76-127, Integration.cpp (CheckBoundaries), SphIntegration.cpp:81-134,
+  //      Simulation.cpp:1669-1754, SphLeapfrogKDK.cpp:219-272
+  void AdvanceParticles() {
+    for (int i = 0; i < Nhydro; i++) {
+      Part &q = p[i];
+      const FLOAT dt = t - q.tlast;
+      for (int k = 0; k < P.ndim; k++) q.r[k] = q.r0[k] + q.v0[k]*dt + 0.5*q.a0[k]*dt*dt;
+      for (int k = 0; k < P.ndim; k++) q.v[k] = q.v0[k] + q.a0[k]*dt;
+      if (P.energy_integration) q.u = q.u0 + q.dudt0*dt;
+      q.flags |= F_ACTIVE;
+    }
+    for (int i = 0; i < Nhydro; i++) for (int k = 0; k < P.ndim; k++) if (P.periodic[k]) {
+      if (p[i].r[k] < P.boxmin[k]) { p[i].r[k] += P.boxsize[k]; p[i].r0[k] += P.boxsize[k]; }
+      if (p[i].r[k] > P.boxmax[k]) { p[i].r[k] -= P.boxsize[k]; p[i].r0[k] -= P.boxsize[k]; }
+    }
+  }
+  double Timestep(const Part &q) const {
+    double ts = P.courant_mult*q.h/(q.sound + q.h*fabs(q.div_v) + small_number_dp);
+    const double amag = sqrt(Dot(q.a, q.a, P.ndim));
+    ts = std::min(ts, P.accel_mult*sqrt(q.h/(amag + small_number_dp)));
+    if (P.energy_integration) ts = std::min(ts, P.energy_mult*(double) (q.u/(fabs(q.dudt) + small_number)));
+    return ts;
+  }
+  void ComputeGlobalTimestep() {
+    double dt_min = big_number_dp;
+    for (int i = 0; i < Nhydro; i++) { p[i].dt_next = Timestep(p[i]); dt_min = std::min(dt_min, p[i].dt_next); }
+    timestep = dt_min; n = 0;
+    for (int i = 0; i < Nhydro; i++) p[i].dt_next = timestep;
+  }
+  void EndTimestep() {
+    for (int i = 0; i < Nhydro; i++) {
+      Part &q = p[i];
+      for (int k = 0; k < P.ndim; k++) q.v[k] += 0.5*q.dt*(q.a[k] - q.a0[k]);
+      for (int k = 0; k < P.ndim; k++) { q.r0[k] = q.r[k]; q.v0[k] = q.v[k]; q.a0[k] = q.a[k]; }
+      if (P.energy_integration) {
+        q.u += 0.5*(q.dudt - q.dudt0)*q.dt;
+        if (q.u <= 0.0) q.u = q.u0 + q.dudt0*q.dt;
+        q.u0 = q.u; q.dudt0 = q.dudt;
+      }
+      q.tlast = t; q.dt = q.dt_next; q.dt_next = 0; q.flags &= ~F_ACTIVE;
+    }
+  }
+  void DensityPass() { SearchBoundaryGhostParticles(); BuildGhostTree(); UpdateAllSphProperties(); }
+  void Setup(int h_provided) {                                       // SphSimulation.cpp:204-565 (see gh_setup)
+    for (int i = 0; i < Nhydro; i++) p[i].flags |= F_ACTIVE;
+    const int npass = h_provided ? 2 : 3;
+    for (int q = 0; q < npass; q++) { BuildTree(); DensityPass(); }
+    ZeroAccelerations(); Forces();
+    t = 0.0; n = 0;
+    ComputeGlobalTimestep(); EndTimestep();
+  }
+  void MainLoop() {                                                  // SphSimulation.cpp:574-880
+    n++; Nsteps++; t = t + timestep;
+    AdvanceParticles();
+    BuildTree(); DensityPass();
+    ZeroAccelerations(); Forces();
+    ComputeGlobalTimestep(); EndTimestep();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// C ABI for ctypes
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+struct orc_params {
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads;
+  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult;
+};
+
+Oracle *orc_create(const orc_params *q)
+{
+  Params P;
+  P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
+  P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
+  for (int k = 0; k < 3; k++) {
+    P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
+    P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];
+  }
+  P.h_fac = q->h_fac; P.h_converge = q->h_converge; P.alpha_visc = q->alpha_visc; P.beta_visc = q->beta_visc; P.gamma = q->gamma_eos;
+  P.thetamaxsqd = q->thetamaxsqd; P.courant_mult = q->courant_mult; P.accel_mult = q->accel_mult; P.energy_mult = q->energy_mult;
+  return new Oracle(P);
+}
+void orc_destroy(Oracle *o) { delete o; }
+
+void orc_set_particles(Oracle *o, int N, const double *r, const double *v, const double *m, const double *h, const double *u)
+{
+  const int nd = o->P.ndim;
+  o->p.assign(N, Part());
+  o->Nhydro = N; o->Nghost = 0;
+  for (int i = 0; i < N; i++) {
+    Part &q = o->p[i];
+    memset(&q, 0, sizeof(Part));
+    q.flags = F_ACTIVE; q.iorig = i;
+    for (int k = 0; k < nd; k++) { q.r[k] = r[i*nd + k]; q.r0[k] = q.r[k]; q.v[k] = v ? v[i*nd + k] : 0.0; q.v0[k] = q.v[k]; }
+    q.m = m[i]; q.h = h[i]; q.u = u ? u[i] : 0.0; q.u0 = q.u;
+  }
+  o->t = 0.0; o->timestep = 0.0; o->n = 0; o->Nsteps = 0;
+}
+
+static double *field_ptr(Part &q, const char *name, int *ncomp)
+{
+  *ncomp = 1;
+#define V(nm) if (!strcmp(name, #nm)) { *ncomp = 3; return q.nm; }
+#define S(nm) if (!strcmp(name, #nm)) return &q.nm;
+  V(r) V(v) V(a) V(atree) V(r0) V(v0) V(a0)
+  S(m) S(h) S(hrangesqd) S(hfactor) S(sound) S(rho) S(pressure) S(u) S(u0) S(dudt0) S(dudt) S(gpot) S(gpot_hydro)
+  S(dt) S(dt_next) S(tlast) S(div_v) S(invomega) S(zeta)
+#undef V
+#undef S
+  return nullptr;
+}
+int orc_get(Oracle *o, const char *name, double *out)
+{
+  const int nd = o->P.ndim;
+  for (int i = 0; i < o->Nhydro; i++) {
+    int nc; double *f = field_ptr(o->p[i], name, &nc);
+    if (!f) return -1;
+    if (nc == 3) for (int k = 0; k < nd; k++) out[i*nd + k] = f[k]; else out[i] = *f;
+  }
+  return 0;
+}
+int orc_set(Oracle *o, const char *name, const double *in)
+{
+  const int nd = o->P.ndim;
+  for (int i = 0; i < o->Nhydro; i++) {
+    int nc; double *f = field_ptr(o->p[i], name, &nc);
+    if (!f) return -1;
+    if (nc == 3) for (int k = 0; k < nd; k++) f[k] = in[i*nd + k]; else *f = in[i];
+  }
+  return 0;
+}
+void orc_set_time(Oracle *o, double t, double timestep) { o->t = t; o->timestep = timestep; }
+double orc_time(Oracle *o) { return o->t; }
+double orc_timestep(Oracle *o) { return o->timestep; }
+void orc_set_all_active(Oracle *o) { for (int i = 0; i < o->Nhydro; i++) o->p[i].flags |= F_ACTIVE; }
+
+void orc_build_tree(Oracle *o) { o->BuildTree(); }
+void orc_tree_size(Oracle *o, int *Ncell, int *ltot, int *gtot) { *Ncell = o->tree.Ncell; *ltot = o->tree.ltot; *gtot = o->tree.gtot; }
+void orc_export_tree(Oracle *o, int *level, int *ifirst, int *ilast, int *N, int *inext, double *bbmin, double *bbmax,
+                     double *hbmin, double *hbmax, double *rcell, double *com, double *m, double *rmax, double *hmax, double *cdistsqd)
+{
+  const int nd = o->P.ndim;
+  for (int c = 0; c < o->tree.Ncell; c++) {
+    const Cell &x = o->tree.cell[c];
+    level[c] = x.level; ifirst[c] = x.ifirst; ilast[c] = x.ilast; N[c] = x.N;
+    for (int k = 0; k < nd; k++) { bbmin[c*nd + k] = x.bbmin[k]; bbmax[c*nd + k] = x.bbmax[k]; hbmin[c*nd + k] = x.hbmin[k];
+                                   hbmax[c*nd + k] = x.hbmax[k]; rcell[c*nd + k] = x.rcell[k]; com[c*nd + k] = x.r[k]; }
+    m[c] = x.m; rmax[c] = x.rmax; hmax[c] = x.hmax; cdistsqd[c] = x.cdistsqd;
+  }
+  for (int i = 0; i < o->Nhydro; i++) inext[i] = o->tree.inext[i];
+}
+int orc_density(Oracle *o) { return o->DensityPass(), 0; }
+void orc_zero_accelerations(Oracle *o) { o->ZeroAccelerations(); }
+void orc_forces(Oracle *o) { o->Forces(); }
+void orc_setup(Oracle *o, int h_provided) { o->Setup(h_provided); }
+void orc_step(Oracle *o, int nsteps) { for (int s = 0; s < nsteps; s++) o->MainLoop(); }
+int orc_num_ghosts(Oracle *o) { return o->Nghost; }
+
+// HydroTree::GetGatherNeighbourList for every particle (real + ghost trees; ghost ids mapped to their real
+// parent), CSR.  Needs the ghost tree of the last density pass.  Returns total count (ids may be NULL).
+long orc_gather_neighbours(Oracle *o, long *offsets, int *ids)
+{
+  long tot = 0;
+  std::vector<int> list;
+  offsets[0] = 0;
+  for (int i = 0; i < o->Nhydro; i++) {
+    list.clear();
+    o->tree.GatherPoint(o->p[i].r, o->kern.kernrange*o->p[i].h, o->p, list);
+    o->ghosttree.GatherPoint(o->p[i].r, o->kern.kernrange*o->p[i].h, o->p, list);
+    for (size_t k = 0; k < list.size(); k++) {
+      int j = list[k];
+      while (j >= o->Nhydro) j = o->p[j].iorig;
+      if (ids) ids[tot + k] = j;
+    }
+    tot += (long) list.size();
+    offsets[i + 1] = tot;
+  }
+  return tot;
+}
+
+}

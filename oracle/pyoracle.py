@@ -1,0 +1,168 @@
+"""ctypes binding of oracle/libgandalf_oracle.so (TEST INFRASTRUCTURE - see gandalf_oracle.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgandalf_oracle.so")
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+_lib = None
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("ndim", C.c_int32), ("Nleafmax", C.c_int32), ("self_gravity", C.c_int32), ("periodic", C.c_int32*3),
+                ("energy_integration", C.c_int32), ("nthreads", C.c_int32),
+                ("boxmin", C.c_double*3), ("boxmax", C.c_double*3), ("h_fac", C.c_double), ("h_converge", C.c_double),
+                ("alpha_visc", C.c_double), ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("thetamaxsqd", C.c_double),
+                ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise ImportError("%s not built (make -C oracle)" % _PATH)
+        L = C.CDLL(_PATH)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OrcParams)]
+        L.orc_time.restype = C.c_double
+        L.orc_timestep.restype = C.c_double
+        L.orc_gather_neighbours.restype = C.c_long
+        for name in ("orc_destroy", "orc_set_particles", "orc_get", "orc_set", "orc_set_time", "orc_time", "orc_timestep",
+                     "orc_set_all_active", "orc_build_tree", "orc_tree_size", "orc_export_tree", "orc_density",
+                     "orc_zero_accelerations", "orc_forces", "orc_setup", "orc_step", "orc_num_ghosts", "orc_gather_neighbours"):
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+VEC = {"r", "v", "a", "atree", "r0", "v0", "a0"}
+
+
+class Oracle:
+    def __init__(self, p, nthreads=None):
+        """p: dict with the reference's parameter-file keys"""
+        L = lib()
+        q = OrcParams()
+        q.ndim = int(p.get("ndim", 3))
+        q.Nleafmax = int(p.get("Nleafmax", 6))
+        q.self_gravity = int(p.get("self_gravity", 0))
+        q.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
+        q.nthreads = nthreads or min(os.cpu_count() or 1, 16)
+        for k in range(3):
+            q.periodic[k] = 1 if p.get("boundary_lhs[%d]" % k, "open") == "periodic" else 0
+            q.boxmin[k] = float(p.get("boxmin[%d]" % k, 0.0))
+            q.boxmax[k] = float(p.get("boxmax[%d]" % k, 0.0))
+        q.h_fac = float(p.get("h_fac", 1.2)); q.h_converge = float(p.get("h_converge", 0.01))
+        q.alpha_visc = float(p.get("alpha_visc", 1.0)); q.beta_visc = float(p.get("beta_visc", 2.0))
+        q.gamma_eos = float(p.get("gamma_eos", 1.66666666666666)); q.thetamaxsqd = float(p.get("thetamaxsqd", 0.1))
+        q.courant_mult = float(p.get("courant_mult", 0.15)); q.accel_mult = float(p.get("accel_mult", 0.3))
+        q.energy_mult = float(p.get("energy_mult", 0.4))
+        assert p.get("kernel", "m4") == "m4" and int(p.get("tabulated_kernel", 0)) == 0
+        assert p.get("avisc", "mon97") == "mon97" and p.get("acond", "none") == "none"
+        self.L, self.ndim, self.N = L, q.ndim, 0
+        self.h = C.c_void_p(L.orc_create(C.byref(q)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _dp(a):
+        return a.ctypes.data_as(_PD) if a is not None else None
+
+    def set_particles(self, r, m, h, v=None, u=None):
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1, self.ndim)
+        self.N = r.shape[0]
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        v, m, h, u = c(v), c(m), c(h), c(u)
+        self.L.orc_set_particles(self.h, self.N, self._dp(r), self._dp(v), self._dp(m), self._dp(h), self._dp(u))
+
+    def get(self, name):
+        out = np.empty((self.N, self.ndim) if name in VEC else (self.N,))
+        rc = self.L.orc_get(self.h, name.encode(), self._dp(out))
+        assert rc == 0, name
+        return out
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        assert self.L.orc_set(self.h, name.encode(), self._dp(arr)) == 0, name
+
+    def set_time(self, t, dt):
+        self.L.orc_set_time(self.h, C.c_double(t), C.c_double(dt))
+
+    @property
+    def t(self):
+        return self.L.orc_time(self.h)
+
+    @property
+    def timestep(self):
+        return self.L.orc_timestep(self.h)
+
+    def set_all_active(self):
+        self.L.orc_set_all_active(self.h)
+
+    def build_tree(self):
+        self.L.orc_build_tree(self.h)
+
+    def export_tree(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_tree_size(self.h, C.byref(a), C.byref(b), C.byref(c))
+        nc, nd = a.value, self.ndim
+        t = {"Ncell": nc, "ltot": b.value, "gtot": c.value}
+        for k in ("level", "ifirst", "ilast", "N"):
+            t[k] = np.zeros(nc, dtype=np.int32)
+        t["inext"] = np.zeros(self.N, dtype=np.int32)
+        for k in ("bbmin", "bbmax", "hboxmin", "hboxmax", "rcell", "com"):
+            t[k] = np.zeros((nc, nd))
+        for k in ("m", "rmax", "hmax", "cdistsqd"):
+            t[k] = np.zeros(nc)
+        ip = lambda x: x.ctypes.data_as(_PI)  # noqa: E731
+        self.L.orc_export_tree(self.h, ip(t["level"]), ip(t["ifirst"]), ip(t["ilast"]), ip(t["N"]), ip(t["inext"]),
+                               self._dp(t["bbmin"]), self._dp(t["bbmax"]), self._dp(t["hboxmin"]), self._dp(t["hboxmax"]),
+                               self._dp(t["rcell"]), self._dp(t["com"]), self._dp(t["m"]), self._dp(t["rmax"]),
+                               self._dp(t["hmax"]), self._dp(t["cdistsqd"]))
+        return t
+
+    def density(self):
+        self.L.orc_density(self.h)
+
+    def zero_accelerations(self):
+        self.L.orc_zero_accelerations(self.h)
+
+    def forces(self):
+        self.L.orc_forces(self.h)
+
+    def setup(self, h_provided=True):
+        self.L.orc_setup(self.h, 1 if h_provided else 0)
+
+    def step(self, n=1):
+        self.L.orc_step(self.h, n)
+
+    def num_ghosts(self):
+        return int(self.L.orc_num_ghosts(self.h))
+
+    def gather_neighbours(self):
+        offs = np.zeros(self.N + 1, dtype=np.int64)
+        tot = self.L.orc_gather_neighbours(self.h, offs.ctypes.data_as(C.POINTER(C.c_long)), None)
+        ids = np.zeros(max(tot, 1), dtype=np.int32)
+        self.L.orc_gather_neighbours(self.h, offs.ctypes.data_as(C.POINTER(C.c_long)), ids.ctypes.data_as(_PI))
+        return offs, ids[:tot]
+
+
+def smoke_check(sim, g):
+    """used by __graft_entry__.smoke(): the HIP density against the CPU restatement on the same inputs"""
+    from gandalf_amd.params import read_params_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    o = Oracle(read_params_file(os.path.join(root, "tests", "params", "plummer_4k.dat")))
+    o.set_particles(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    o.build_tree()
+    o.density()
+    e = np.max(np.abs(sim.download("rho") - o.get("rho"))/o.get("rho"))
+    assert e < 1e-12, e
+    return "(vs CPU restatement: rho %.1e)" % e

@@ -1,0 +1,83 @@
+"""The CPU restatement (oracle/gandalf_oracle.cpp) pinned against the reference's own outputs.
+
+tests/golden/*.npz were written by scripts/make_golden.py from the compiled reference (oracle/ref.mk +
+oracle/ref_dump.cpp); the restatement must reproduce them BIT FOR BIT: tree (cells, linked lists),
+densities, neighbour lists, forces, and three full steps."""
+import numpy as np
+import pytest
+
+from conftest import PARAMS, load_golden
+from gandalf_amd.params import read_params_file
+from oracle.pyoracle import Oracle
+
+CASES = ["box3d_4k", "plummer_4k"]
+
+
+def make(case, g):
+    o = Oracle(read_params_file("%s/%s.dat" % (PARAMS, case)), nthreads=4)
+    o.set_particles(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    return o
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tree_bitwise(case):
+    g = load_golden(case + "_passes")
+    o = make(case, g)
+    o.build_tree()
+    t = o.export_tree()
+    assert (t["Ncell"], t["ltot"], t["gtot"]) == tuple(int(x) for x in g["tree_tree_Ncell_ltot_gtot_Ntot_Nleafmax"][:3])
+    for mine, ref in [("level", "cell_level"), ("N", "cell_N"), ("ifirst", "cell_ifirst"), ("ilast", "cell_ilast"),
+                      ("bbmin", "cell_bbmin"), ("bbmax", "cell_bbmax"), ("hboxmin", "cell_hboxmin"),
+                      ("hboxmax", "cell_hboxmax"), ("rcell", "cell_rcell"), ("com", "cell_r"), ("m", "cell_m"),
+                      ("rmax", "cell_rmax"), ("hmax", "cell_hmax"), ("cdistsqd", "cell_cdistsqd")]:
+        assert np.array_equal(t[mine], g["tree_" + ref]), mine
+    assert np.array_equal(t["inext"], g["tree_inext"][:o.N])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_density_and_forces_bitwise(case):
+    g = load_golden(case + "_passes")
+    o = make(case, g)
+    o.build_tree()
+    o.density()
+    for k in ["h", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound", "pressure", "u", "div_v"]:
+        assert np.array_equal(o.get(k), g["dens_" + k]), k
+    t = o.export_tree()
+    assert np.array_equal(t["hmax"], g["dens_cell_hmax"])
+    assert np.array_equal(t["hboxmin"], g["dens_cell_hboxmin"]) and np.array_equal(t["hboxmax"], g["dens_cell_hboxmax"])
+    offs, ids = o.gather_neighbours()
+    assert np.array_equal(offs, g["dens_gather_offsets"]) and np.array_equal(ids, g["dens_gather_ids"])
+    o.zero_accelerations()
+    o.forces()
+    for k in ["a", "atree", "gpot", "gpot_hydro", "dudt", "div_v"]:
+        assert np.array_equal(o.get(k), g["force_" + k]), k
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_steps_bitwise(case):
+    g = load_golden(case + "_steps")
+    o = Oracle(read_params_file("%s/%s.dat" % (PARAMS, case)), nthreads=4)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    o.set_particles(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
+        o.set(k, s(k))
+    t0, dt0 = s("t_timestep")
+    o.set_time(float(t0), float(dt0))
+    o.step(int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ["r", "v", "a", "h", "rho", "u", "dudt"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
+
+
+def test_setup_from_ic_matches_reference_setup():
+    """whole PostInitialConditionsSetup from the raw IC (box: h provided by the IC generator)"""
+    from gandalf_amd.host import Simulation
+    g = load_golden("box3d_4k_steps")
+    sim = Simulation("%s/box3d_4k.dat" % PARAMS)
+    ic = sim.generate_ic()
+    o = Oracle(read_params_file("%s/box3d_4k.dat" % PARAMS), nthreads=4)
+    o.set_particles(ic["r"], ic["m"], ic["h"], v=ic["v"], u=ic["u"])
+    o.setup(h_provided=ic["initial_h_provided"])
+    for k in ["h", "rho", "a", "dudt", "dt"]:
+        assert np.array_equal(o.get(k), g["setup_" + k]), k
+    assert o.timestep == g["setup_t_timestep"][1]
