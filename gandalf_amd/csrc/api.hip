@@ -141,9 +141,9 @@ static void free_particles(gh_ctx *ctx)
     if (ctx->W[k]) (void) hipFree(ctx->W[k]); ctx->W[k] = nullptr;
     if (ctx->Wpre[k]) (void) hipFree(ctx->Wpre[k]); ctx->Wpre[k] = nullptr;
   }
-  void *ptrs[] = {ctx->posm, ctx->side, ctx->sortkeys_out, ctx->sortvals};
+  void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals};
   for (void *p : ptrs) if (p) (void) hipFree(p);
-  ctx->posm = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
+  ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
 }
 
 extern "C" void gh_destroy(gh_ctx *ctx)
@@ -151,7 +151,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->cfirst, ctx->cN, ctx->cbox, ctx->cgrav, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -183,6 +183,7 @@ int gh_alloc_particles(gh_ctx *ctx, int64_t N)
     GH_CHECK(ctx, hipMalloc((void**) &ctx->Wpre[k], sizeof(unsigned int)*nwords));
   }
   GH_CHECK(ctx, hipMalloc((void**) &ctx->posm, sizeof(double4)*n));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->hrec, sizeof(double4)*4*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->side, n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortvals, sizeof(int)*n));
@@ -306,9 +307,13 @@ extern "C" int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_fi
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int Nc = ctx->Ncell, nd = ctx->ndim;
   std::vector<CellBox> hb(Nc);
-  std::vector<CellGrav> hg(Nc);
+  std::vector<CellH> hh(Nc);
+  std::vector<CellGeo> hg(Nc);
+  std::vector<CellCom> hc(Nc);
   GH_CHECK(ctx, hipMemcpy(hb.data(), ctx->cbox, sizeof(CellBox)*Nc, hipMemcpyDeviceToHost));
-  GH_CHECK(ctx, hipMemcpy(hg.data(), ctx->cgrav, sizeof(CellGrav)*Nc, hipMemcpyDeviceToHost));
+  GH_CHECK(ctx, hipMemcpy(hh.data(), ctx->ch, sizeof(CellH)*Nc, hipMemcpyDeviceToHost));
+  GH_CHECK(ctx, hipMemcpy(hg.data(), ctx->cgeo, sizeof(CellGeo)*Nc, hipMemcpyDeviceToHost));
+  GH_CHECK(ctx, hipMemcpy(hc.data(), ctx->ccom, sizeof(CellCom)*Nc, hipMemcpyDeviceToHost));
   // heap index -> reference pre-order id: child1 = c+1, child2 = c + 2^(ltot-level)  (KDTree.cpp:412-417)
   std::vector<int> pre(Nc), lev(Nc);
   pre[0] = 0; lev[0] = 0;
@@ -325,14 +330,14 @@ extern "C" int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_fi
     for (int k = 0; k < nd; k++) {
       if (bbmin) bbmin[c*nd + k] = hb[n].bbmin[k];
       if (bbmax) bbmax[c*nd + k] = hb[n].bbmax[k];
-      if (hboxmin) hboxmin[c*nd + k] = hb[n].hbmin[k];
-      if (hboxmax) hboxmax[c*nd + k] = hb[n].hbmax[k];
+      if (hboxmin) hboxmin[c*nd + k] = hh[n].hbmin[k];
+      if (hboxmax) hboxmax[c*nd + k] = hh[n].hbmax[k];
       if (rcell) rcell[c*nd + k] = hg[n].rcell[k];
-      if (com) com[c*nd + k] = hg[n].com[k];
+      if (com) com[c*nd + k] = hc[n].com[k];
     }
-    if (mass) mass[c] = hg[n].m;
+    if (mass) mass[c] = hc[n].m;
     if (rmax) rmax[c] = hg[n].rmax;
-    if (hmax) hmax[c] = hg[n].hmax;
+    if (hmax) hmax[c] = hh[n].hmax;
     if (cdistsqd) cdistsqd[c] = hg[n].cdistsqd;
   }
   if (order) GH_CHECK(ctx, hipMemcpy(order, ctx->iorig[ctx->cur], sizeof(int)*(size_t) ctx->N, hipMemcpyDeviceToHost));
@@ -714,16 +719,16 @@ __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain d
   long long cnt = 0;
   const long long base = pass ? offsets[myorig] : 0;
   auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &c) {
-    const int cn = d.cN[n];
+    const CellBox b = d.cbox[n];
+    const int cn = b.N;
     if (cn == 0) return;
     double sh[3];
     code_shift(dom, code, sh);
-    const CellBox &b = d.cbox[n];
     for (int k = 0; k < d.ndim; k++) {
       if (lo[k] > b.bbmax[k] + sh[k]) return;
       if (b.bbmin[k] + sh[k] > hi[k]) return;
     }
-    if (n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; c = cn; }
+    if (n >= d.gtot - 1) { emit = true; first = b.first; c = cn; }
     else open = true;
   };
   auto tile = [&](bool valid, int j, int code) {

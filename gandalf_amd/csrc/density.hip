@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   const double mi = d.f[D_M][i];
   double ui = d.f[D_U][i];
   const CellBox gb = d.cbox[gnode];
-  const double hfirst = 1.05*d.cgrav[gnode].hmax;      // the reference's first search radius (hmax*1.05)
+  const double hfirst = 1.05*d.ch[gnode].hmax;      // the reference's first search radius (hmax*1.05)
 
   // per-lane iteration state (GradhSph.cpp:148-158)
   double h = d.f[D_H][i], hlo = 0.0, hup = hfirst;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   if (COUNT) {
     int n = gnode;
     while (n < d.gtot - 1) { const int c2 = 2*n + 2; n = (i >= d.cfirst[c2]) ? c2 : 2*n + 1; }
-    const double hm = 1.05*d.cgrav[n].hmax;
+    const double hm = 1.05*d.ch[n].hmax;
     cullsqd = K::kernrangesqd*hm*hm;
   }
 
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
     const unsigned int codes = image_codes(P.dom, ND, lo, hi);
     const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
     auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
-      const int cn = d.cN[n];
+      const CellBox b = d.cbox[n];
+      const int cn = b.N;
       if (cn == 0) return;
       double sh[3];
       code_shift(P.dom, code, sh);
-      const CellBox &b = d.cbox[n];
       bool inside = true;
       double gap2 = 0.0;                                  // squared distance between the two boxes
       for (int k = 0; k < ND; k++) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       // no particle of the cell can be within kernrange*hs of any particle of the group: the reference
       // would list it (box test) and sum zeros for it; skipping it changes nothing
       if (gap2 > rs2cut) return;
-      if (inside || n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; cnt = cn; }
+      if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = cn; }
       else open = true;
     };
     auto tile = [&](bool valid, int j, int code) {

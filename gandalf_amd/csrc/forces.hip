@@ -108,33 +108,39 @@ __device__ __forceinline__ void load_target(const DevicePtrs &d, int i, int ND, 
   t.u = d.f[D_U][i];
 }
 
+// The neighbour record of the force tiles, 16 doubles = one 128-byte line per particle, in T_* order.
+// Built once per force pass (k_pack_hydro) from the SoA arrays so that staging a tile is four 32-byte
+// loads per lane instead of sixteen scattered ones plus three divisions.
+__global__ void k_pack_hydro(DevicePtrs d)
+{
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= d.N) return;
+  const double h = d.f[D_H][j], rho = d.f[D_RHO][j], press = d.f[D_PRESSURE][j];
+  double4 q0, q1, q2, q3;
+  q0.x = d.f[D_RX][j]; q0.y = d.ndim > 1 ? d.f[D_RY][j] : 0.0; q0.z = d.ndim > 2 ? d.f[D_RZ][j] : 0.0; q0.w = d.f[D_M][j];
+  q1.x = d.f[D_VX][j]; q1.y = d.ndim > 1 ? d.f[D_VY][j] : 0.0; q1.z = d.ndim > 2 ? d.f[D_VZ][j] : 0.0; q1.w = d.f[D_HRANGESQD][j];
+  q2.x = 1.0/h; q2.y = d.f[D_HFACTOR][j]; q2.z = (press*d.f[D_INVOMEGA][j])/(rho*rho); q2.w = 1.0/rho;
+  q3.x = d.f[D_SOUND][j]; q3.y = d.f[D_ZETA][j]; q3.z = d.f[D_U][j]; q3.w = press;
+  d.hrec[4*(size_t) j + 0] = q0; d.hrec[4*(size_t) j + 1] = q1; d.hrec[4*(size_t) j + 2] = q2; d.hrec[4*(size_t) j + 3] = q3;
+}
+
 // stage particle j (tree-order index) with image shift sh into tile slot `slot`
 __device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (*s_t)[64], int slot, int j, const double sh[3], bool valid)
 {
+  double4 q0, q1, q2, q3;
+  q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
+  q1.x = 0.0; q1.y = 0.0; q1.z = 0.0; q1.w = 0.0;
+  q2.x = 1.0; q2.y = 0.0; q2.z = 0.0; q2.w = 1.0;
+  q3.x = 0.0; q3.y = 0.0; q3.z = 0.0; q3.w = 0.0;
   if (valid) {
-    const double h = d.f[D_H][j], rho = d.f[D_RHO][j], press = d.f[D_PRESSURE][j];
-    s_t[T_X][slot] = d.f[D_RX][j] + sh[0];
-    s_t[T_Y][slot] = ND > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
-    s_t[T_Z][slot] = ND > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
-    s_t[T_M][slot] = d.f[D_M][j];
-    s_t[T_VX][slot] = d.f[D_VX][j];
-    s_t[T_VY][slot] = ND > 1 ? d.f[D_VY][j] : 0.0;
-    s_t[T_VZ][slot] = ND > 2 ? d.f[D_VZ][j] : 0.0;
-    s_t[T_HR2][slot] = d.f[D_HRANGESQD][j];
-    s_t[T_INVH][slot] = 1.0/h;
-    s_t[T_HFAC][slot] = d.f[D_HFACTOR][j];
-    s_t[T_PFAC][slot] = (press*d.f[D_INVOMEGA][j])/(rho*rho);
-    s_t[T_INVRHO][slot] = 1.0/rho;
-    s_t[T_SOUND][slot] = d.f[D_SOUND][j];
-    s_t[T_ZETA][slot] = d.f[D_ZETA][j];
-    s_t[T_U][slot] = d.f[D_U][j];
-    s_t[T_PRESS][slot] = press;
+    const double4 *r = d.hrec + 4*(size_t) j;
+    q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3];
+    q0.x += sh[0]; q0.y += sh[1]; q0.z += sh[2];
   }
-  else {
-    for (int f = 0; f < T_NF; f++) s_t[f][slot] = 0.0;
-    s_t[T_X][slot] = 1e30; s_t[T_Y][slot] = 1e30; s_t[T_Z][slot] = 1e30;
-    s_t[T_INVH][slot] = 1.0; s_t[T_INVRHO][slot] = 1.0;
-  }
+  s_t[T_X][slot] = q0.x; s_t[T_Y][slot] = q0.y; s_t[T_Z][slot] = q0.z; s_t[T_M][slot] = q0.w;
+  s_t[T_VX][slot] = q1.x; s_t[T_VY][slot] = q1.y; s_t[T_VZ][slot] = q1.z; s_t[T_HR2][slot] = q1.w;
+  s_t[T_INVH][slot] = q2.x; s_t[T_HFAC][slot] = q2.y; s_t[T_PFAC][slot] = q2.z; s_t[T_INVRHO][slot] = q2.w;
+  s_t[T_SOUND][slot] = q3.x; s_t[T_ZETA][slot] = q3.y; s_t[T_U][slot] = q3.z; s_t[T_PRESS][slot] = q3.w;
 }
 
 // ================================================================================================
@@ -162,28 +168,30 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 
   // candidate cells: overlap(cell.bb, other.hbox) || overlap(cell.hbox, other.bb)   (Tree.cpp:579-580)
   const CellBox gb = d.cbox[gnode];
-  const double hr_root = M4<ND>::kernrange*d.cgrav[0].hmax;
+  const CellH gh = d.ch[gnode];
+  const double hr_root = M4<ND>::kernrange*d.ch[0].hmax;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) {
-    lo[k] = k < ND ? fmin(gb.hbmin[k], gb.bbmin[k] - hr_root) : -1e300;
-    hi[k] = k < ND ? fmax(gb.hbmax[k], gb.bbmax[k] + hr_root) : 1e300;
+    lo[k] = k < ND ? fmin(gh.hbmin[k], gb.bbmin[k] - hr_root) : -1e300;
+    hi[k] = k < ND ? fmax(gh.hbmax[k], gb.bbmax[k] + hr_root) : 1e300;
   }
   const unsigned int codes = image_codes(P.dom, ND, lo, hi);
   auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
-    const int cn = d.cN[n];
+    const CellBox b = d.cbox[n];
+    const int cn = b.N;
     if (cn == 0) return;
     double sh[3];
     code_shift(P.dom, code, sh);
-    const CellBox &b = d.cbox[n];
+    const CellH bh = d.ch[n];
     bool o1 = true, o2 = true, inside = true;
     for (int k = 0; k < ND; k++) {
       const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
-      if (gb.bbmin[k] > b.hbmax[k] + sh[k] || b.hbmin[k] + sh[k] > gb.bbmax[k]) o1 = false;
-      if (gb.hbmin[k] > bmax || bmin > gb.hbmax[k]) o2 = false;
-      if (bmin < gb.hbmin[k] || bmax > gb.hbmax[k]) inside = false;
+      if (gb.bbmin[k] > bh.hbmax[k] + sh[k] || bh.hbmin[k] + sh[k] > gb.bbmax[k]) o1 = false;
+      if (gh.hbmin[k] > bmax || bmin > gh.hbmax[k]) o2 = false;
+      if (bmin < gh.hbmin[k] || bmax > gh.hbmax[k]) inside = false;
     }
     if (!(o1 || o2)) return;
-    if (inside || n >= d.gtot - 1) { emit = true; first = d.cfirst[n]; cnt = cn; }
+    if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = cn; }
     else open = true;
   };
   auto tile = [&](bool valid, int j, int code) {
@@ -317,12 +325,12 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
 
   // leaf geometry of the group (the reference walks per leaf cell with these, Tree.cpp:639-643)
   unsigned int allmask = 0;
-  const CellGrav gg = d.cgrav[gnode];
+  const CellGeo gg = d.cgeo[gnode];
   double Rg = 0.0, Lm = 0.0, Lr = 0.0;               // group-level bounds for the quick classification
   {
     double rg = 0.0, lm = 0.0, lr = 0.0;
     if (lane < nl) {
-      const CellGrav g = d.cgrav[leafnode0 + lane];
+      const CellGeo g = d.cgeo[leafnode0 + lane];
       for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
       s_lrmax[lane] = g.rmax;
       s_lhr[lane] = K::kernrange*g.hmax;
@@ -460,13 +468,12 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     const int newtop = top - p;
     unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
     int n = 0; bool isleaf = false;
-    CellGrav g;
-    g.first = 0; g.N = 0; g.m = 0.0;
-    for (int k = 0; k < 3; k++) g.com[k] = 0.0;
+    CellGeo g;
+    g.first = 0; g.N = 0;
     if (lane < p) {
       n = s_stack[top - 1 - lane];
       const unsigned int fm = s_smask[top - 1 - lane];
-      g = d.cgrav[n];
+      g = d.cgeo[n];
       isleaf = n >= leaf0;
       const double khr = K::kernrange*g.hmax;
       // quick classification of the node against the whole group.  Every leaf centre lies within Rg of
@@ -517,7 +524,8 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     if (top > GH_SCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); top = GH_SCAP; }
     if (cellm) {
       const int pos = ncell + __popcll(cm & lt);
-      s_cx[pos] = g.com[0]; s_cy[pos] = g.com[1]; s_cz[pos] = g.com[2]; s_cm[pos] = g.m;
+      const CellCom cm_ = d.ccom[n];
+      s_cx[pos] = cm_.com[0]; s_cy[pos] = cm_.com[1]; s_cz[pos] = cm_.com[2]; s_cm[pos] = cm_.m;
       s_cmask[pos] = (unsigned short) cellm;
     }
     ncell += __popcll(cm);
@@ -590,6 +598,7 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_)                                                                                               \
@@ -619,6 +628,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_)                                                                                              \

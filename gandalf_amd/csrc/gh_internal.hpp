@@ -4,7 +4,7 @@
 //   * particles: structure of arrays, one double array per scalar / vector component, stored in
 //     TREE ORDER (leaf cells contiguous), double-buffered so that a tree rebuild is one gather pass;
 //   * derived per-pass packs (posm = x,y,z,m as 32-byte records) for the LDS tiles;
-//   * KD-tree cells in heap order (children of n are 2n+1, 2n+2), two 96-byte records per cell.
+//   * KD-tree cells in heap order (children of n are 2n+1, 2n+2), four records per cell split by consumer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -25,28 +25,40 @@ enum FieldD {
   D_TLAST, D_COUNT
 };
 
-// KD-tree cell records (heap order).  Field meanings follow TreeCellBase (reference TreeCell.h:16-49).
-struct alignas(32) CellBox {       // 96 B
+// KD-tree cell records (heap order), split by consumer so that every walk touches one 64-byte line per
+// node.  Field meanings follow TreeCellBase (reference TreeCell.h:16-49).
+struct alignas(64) CellBox {       // density / gather walks
   double bbmin[3], bbmax[3];       // tight bounding box of particle positions
-  double hbmin[3], hbmax[3];       // bounding box of r -/+ kernrange*h
-};
-struct alignas(32) CellGrav {      // 96 B
-  double rcell[3];                 // centre of bb
-  double rmax;                     // half diagonal of bb
-  double hmax;                     // max h in cell
-  double cdistsqd;                 // max(rmax^2, hmax^2)/thetamaxsqd at stock time
-  double com[3];                   // centre of mass
-  double m;                        // mass
   int first, N;                    // particle range in tree order
   double pad;
+};
+struct alignas(64) CellH {         // hydro walk (with CellBox); the only record UpdateHmaxValues rewrites
+  double hbmin[3], hbmax[3];       // bounding box of r -/+ kernrange*h
+  double hmax;                     // max h in cell
+  double pad;
+};
+struct alignas(64) CellGeo {       // gravity walk
+  double rcell[3];                 // centre of bb
+  double rmax;                     // half diagonal of bb
+  double cdistsqd;                 // max(rmax^2, hmax^2)/thetamaxsqd at stock time
+  double hmax;                     // copy of CellH::hmax
+  int first, N;
+  double pad;
+};
+struct alignas(32) CellCom {       // accepted cells only
+  double com[3];                   // centre of mass
+  double m;                        // mass
 };
 
 struct DevicePtrs {                // everything a kernel needs, passed by value
   double *f[D_COUNT];              // current particle arrays (tree order)
   int *iorig;                      // caller-order id of each particle
   double4 *posm;                   // (x,y,z,m) pack
+  double4 *hrec;                   // 4 x double4 per particle: the force tiles' neighbour record
   CellBox *cbox;
-  CellGrav *cgrav;
+  CellH *ch;
+  CellGeo *cgeo;
+  CellCom *ccom;
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
 };
@@ -63,6 +75,7 @@ struct gh_ctx {
   int *iorig[2] = {};
   int cur = 0;
   double4 *posm = nullptr;
+  double4 *hrec = nullptr;
   double **d_ptrtab = nullptr;     // device table of 2*D_COUNT pointers for the permute kernel
 
   // tree
@@ -71,7 +84,9 @@ struct gh_ctx {
   std::vector<int> h_cfirst, h_cN;
   int *cfirst = nullptr, *cN = nullptr;
   CellBox *cbox = nullptr;
-  CellGrav *cgrav = nullptr;
+  CellH *ch = nullptr;
+  CellGeo *cgeo = nullptr;
+  CellCom *ccom = nullptr;
   double *dbbmin = nullptr, *dbbmax = nullptr;   // divide-time boxes [Ncell][3]
   int *kdiv = nullptr;
   int *P[2][3] = {};               // presorted permutations, double buffered

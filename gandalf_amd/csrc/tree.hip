@@ -139,26 +139,30 @@ __global__ void k_ballot_words(DevicePtrs d, LevelArgs a)
   }
 }
 
-// level step 4: exclusive prefix sum of the popcounts of the words (one block per axis)
-__global__ void k_scan_words(LevelArgs a)
+// level step 4: exclusive prefix sum of the popcounts of the words (one block per axis): per-thread run of
+// consecutive words, wave shuffle scan, 16 wave totals through LDS - two barriers in all
+__global__ __launch_bounds__(1024) void k_scan_words(LevelArgs a)
 {
   const int k = blockIdx.x;
   const unsigned long long *W = a.W[k];
   unsigned int *pre = a.Wpre[k];
-  __shared__ unsigned int s[1024];
+  __shared__ unsigned int s_wave[16];
   const int per = (a.nwords + 1023)/1024;
   const int lo = threadIdx.x*per, hi = min(lo + per, a.nwords);
   unsigned int sum = 0;
   for (int i = lo; i < hi; i++) sum += __popcll(W[i]);
-  s[threadIdx.x] = sum;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int inc = sum;
+  for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+  if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    unsigned int v = ((int) threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += v;
-    __syncthreads();
+  if (threadIdx.x < 16) {
+    unsigned int v = s_wave[threadIdx.x], w = v;
+    for (int off = 1; off < 16; off <<= 1) { const unsigned int t = __shfl_up(w, off, 64); if ((int) threadIdx.x >= off) w += t; }
+    s_wave[threadIdx.x] = w - v;
   }
-  unsigned int run = s[threadIdx.x] - sum;
+  __syncthreads();
+  unsigned int run = s_wave[wave] + inc - sum;
   for (int i = lo; i < hi; i++) { pre[i] = run; run += __popcll(W[i]); }
 }
 
@@ -217,7 +221,7 @@ __global__ void k_pack_posm(DevicePtrs d)
 // ------------------------------------------------------------------------------------------------
 // stocking                                                    (KDTree.cpp:808-1083, 1128-1208)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finish_cell(const DevicePtrs &d, CellBox &b, CellGrav &g, double thetamaxsqd)
+__device__ __forceinline__ void finish_cell(const DevicePtrs &d, const CellBox &b, CellGeo &g, double hmax, double thetamaxsqd)
 {
   double dr2 = 0.0;
   for (int k = 0; k < d.ndim; k++) {
@@ -225,7 +229,7 @@ __device__ __forceinline__ void finish_cell(const DevicePtrs &d, CellBox &b, Cel
     const double dr = 0.5*(b.bbmax[k] - b.bbmin[k]);
     dr2 += dr*dr;
   }
-  g.cdistsqd = fmax(dr2, g.hmax*g.hmax)/thetamaxsqd;
+  g.cdistsqd = fmax(dr2, hmax*hmax)/thetamaxsqd;
   g.rmax = sqrt(dr2);
 }
 
@@ -236,77 +240,90 @@ __global__ void k_stock_leaves(DevicePtrs d, double kernrange, double thetamaxsq
   if (g >= d.gtot) return;
   const int n = d.gtot - 1 + g;
   const int first = d.cfirst[n], cnt = d.cN[n];
-  CellBox b = d.cbox[n];
-  CellGrav c = d.cgrav[n];
-  c.hmax = 0.0;
-  for (int k = 0; k < 3; k++) { b.hbmin[k] = BIG; b.hbmax[k] = -BIG; }
+  CellH hh;
+  hh.hmax = 0.0; hh.pad = 0.0;
+  for (int k = 0; k < 3; k++) { hh.hbmin[k] = BIG; hh.hbmax[k] = -BIG; }
+  CellBox b; CellGeo c; CellCom cm;
   if (!hmax_only) {
-    c.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG;
-    for (int k = 0; k < 3; k++) { c.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
-    c.first = first; c.N = cnt; c.pad = 0.0;
+    cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.pad = 0.0; b.pad = 0.0;
+    for (int k = 0; k < 3; k++) { cm.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
+    c.first = first; c.N = cnt; b.first = first; b.N = cnt;
   }
   for (int i = first; i < first + cnt; i++) {
     const double h = d.f[D_H][i];
-    c.hmax = fmax(c.hmax, h);
+    hh.hmax = fmax(hh.hmax, h);
     const double m = d.f[D_M][i];
-    if (!hmax_only) c.m += m;
+    if (!hmax_only) cm.m += m;
     for (int k = 0; k < d.ndim; k++) {
       const double x = d.f[D_RX + k][i];
       if (!hmax_only) {
-        c.com[k] += m*x;
+        cm.com[k] += m*x;
         if (x < b.bbmin[k]) b.bbmin[k] = x;
         if (x > b.bbmax[k]) b.bbmax[k] = x;
       }
-      if (x - kernrange*h < b.hbmin[k]) b.hbmin[k] = x - kernrange*h;
-      if (x + kernrange*h > b.hbmax[k]) b.hbmax[k] = x + kernrange*h;
+      if (x - kernrange*h < hh.hbmin[k]) hh.hbmin[k] = x - kernrange*h;
+      if (x + kernrange*h > hh.hbmax[k]) hh.hbmax[k] = x + kernrange*h;
     }
   }
+  d.ch[n] = hh;
   if (!hmax_only) {
-    if (c.m > 0) for (int k = 0; k < d.ndim; k++) c.com[k] /= c.m;
-    if (cnt > 0) finish_cell(d, b, c, thetamaxsqd);
+    if (cm.m > 0) for (int k = 0; k < d.ndim; k++) cm.com[k] /= cm.m;
+    if (cnt > 0) finish_cell(d, b, c, hh.hmax, thetamaxsqd);
+    c.hmax = hh.hmax;
+    d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
   }
-  d.cbox[n] = b;
-  d.cgrav[n] = c;
+  else d.cgeo[n].hmax = hh.hmax;
+}
+
+__device__ __forceinline__ void stock_internal(const DevicePtrs &d, int n, double thetamaxsqd, int hmax_only)
+{
+  const int c1 = 2*n + 1, c2 = 2*n + 2;
+  const int N1 = d.cN[c1], N2 = d.cN[c2];
+  CellH hh;
+  hh.hmax = 0.0; hh.pad = 0.0;
+  for (int k = 0; k < 3; k++) { hh.hbmin[k] = BIG; hh.hbmax[k] = -BIG; }
+  const CellH h1 = d.ch[c1], h2 = d.ch[c2];
+  if (N1 > 0) {
+    for (int k = 0; k < d.ndim; k++) { hh.hbmin[k] = fmin(h1.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(h1.hbmax[k], hh.hbmax[k]); }
+    hh.hmax = fmax(hh.hmax, h1.hmax);
+  }
+  if (N2 > 0) {
+    for (int k = 0; k < d.ndim; k++) { hh.hbmin[k] = fmin(h2.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(h2.hbmax[k], hh.hbmax[k]); }
+    hh.hmax = fmax(hh.hmax, h2.hmax);
+  }
+  d.ch[n] = hh;
+  if (hmax_only) { d.cgeo[n].hmax = hh.hmax; return; }
+  CellBox b; CellGeo c; CellCom cm;
+  cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.pad = 0.0; b.pad = 0.0;
+  for (int k = 0; k < 3; k++) { cm.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
+  c.first = d.cfirst[n]; c.N = d.cN[n]; b.first = c.first; b.N = c.N;
+  const CellBox b1 = d.cbox[c1], b2 = d.cbox[c2];
+  const CellCom m1 = d.ccom[c1], m2 = d.ccom[c2];
+  if (N1 > 0) for (int k = 0; k < d.ndim; k++) { b.bbmin[k] = fmin(b1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b1.bbmax[k], b.bbmax[k]); }
+  if (N2 > 0) for (int k = 0; k < d.ndim; k++) { b.bbmin[k] = fmin(b2.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b2.bbmax[k], b.bbmax[k]); }
+  cm.m = m1.m + m2.m;
+  if (cm.m > 0) for (int k = 0; k < d.ndim; k++) cm.com[k] = (m1.m*m1.com[k] + m2.m*m2.com[k])/cm.m;
+  if (c.N > 0) finish_cell(d, b, c, hh.hmax, thetamaxsqd);
+  c.hmax = hh.hmax;
+  d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
 }
 
 __global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only)
 {
   const int j = blockIdx.x*blockDim.x + threadIdx.x;
   if (j >= (1 << level)) return;
-  const int n = (1 << level) - 1 + j;
-  const int c1 = 2*n + 1, c2 = 2*n + 2;
-  CellBox b = d.cbox[n];
-  CellGrav c = d.cgrav[n];
-  c.hmax = 0.0;
-  for (int k = 0; k < 3; k++) { b.hbmin[k] = BIG; b.hbmax[k] = -BIG; }
-  if (!hmax_only) {
-    c.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG;
-    for (int k = 0; k < 3; k++) { c.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
-    c.first = d.cfirst[n]; c.N = d.cN[n]; c.pad = 0.0;
+  stock_internal(d, (1 << level) - 1 + j, thetamaxsqd, hmax_only);
+}
+
+// levels ltop .. 0 in one launch of one workgroup (<= 1023 cells): the top of the tree is launch-latency,
+// not bandwidth
+__global__ void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only)
+{
+  for (int level = ltop; level >= 0; level--) {
+    for (int j = threadIdx.x; j < (1 << level); j += blockDim.x) stock_internal(d, (1 << level) - 1 + j, thetamaxsqd, hmax_only);
+    __threadfence_block();
+    __syncthreads();
   }
-  const CellGrav g1 = d.cgrav[c1], g2 = d.cgrav[c2];
-  const CellBox b1 = d.cbox[c1], b2 = d.cbox[c2];
-  if (g1.N > 0) {
-    for (int k = 0; k < d.ndim; k++) {
-      if (!hmax_only) { b.bbmin[k] = fmin(b1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b1.bbmax[k], b.bbmax[k]); }
-      b.hbmin[k] = fmin(b1.hbmin[k], b.hbmin[k]); b.hbmax[k] = fmax(b1.hbmax[k], b.hbmax[k]);
-    }
-    c.hmax = fmax(c.hmax, g1.hmax);
-  }
-  if (g2.N > 0) {
-    for (int k = 0; k < d.ndim; k++) {
-      if (!hmax_only) { b.bbmin[k] = fmin(b2.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b2.bbmax[k], b.bbmax[k]); }
-      b.hbmin[k] = fmin(b2.hbmin[k], b.hbmin[k]); b.hbmax[k] = fmax(b2.hbmax[k], b.hbmax[k]);
-    }
-    c.hmax = fmax(c.hmax, g2.hmax);
-  }
-  if (!hmax_only) {
-    c.m = g1.m + g2.m;
-    if (c.m > 0) for (int k = 0; k < d.ndim; k++) c.com[k] = (g1.m*g1.com[k] + g2.m*g2.com[k])/c.m;
-    if (c.N > 0) finish_cell(d, b, c, thetamaxsqd);
-  }
-  d.cbox[n] = b;
-  d.cgrav[n] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -317,8 +334,8 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   DevicePtrs d;
   for (int f = 0; f < D_COUNT; f++) d.f[f] = ctx->fbuf[ctx->cur][f];
   d.iorig = ctx->iorig[ctx->cur];
-  d.posm = ctx->posm;
-  d.cbox = ctx->cbox; d.cgrav = ctx->cgrav;
+  d.posm = ctx->posm; d.hrec = ctx->hrec;
+  d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom;
   d.cfirst = ctx->cfirst; d.cN = ctx->cN;
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
@@ -354,14 +371,18 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cN, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cbox, sizeof(CellBox)*Ncell));
-  GH_CHECK(ctx, re((void**) &ctx->cgrav, sizeof(CellGrav)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->dbbmin, sizeof(double)*3*(Ncell + 2)));
   GH_CHECK(ctx, re((void**) &ctx->dbbmax, sizeof(double)*3*(Ncell + 2)));
   GH_CHECK(ctx, re((void**) &ctx->kdiv, sizeof(int)*Ncell));
   GH_CHECK(ctx, hipMemcpyAsync(ctx->cfirst, ctx->h_cfirst.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
   GH_CHECK(ctx, hipMemcpyAsync(ctx->cN, ctx->h_cN.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
   GH_CHECK(ctx, hipMemsetAsync(ctx->cbox, 0, sizeof(CellBox)*Ncell, ctx->stream));
-  GH_CHECK(ctx, hipMemsetAsync(ctx->cgrav, 0, sizeof(CellGrav)*Ncell, ctx->stream));
+  GH_CHECK(ctx, hipMemsetAsync(ctx->ch, 0, sizeof(CellH)*Ncell, ctx->stream));
+  GH_CHECK(ctx, hipMemsetAsync(ctx->cgeo, 0, sizeof(CellGeo)*Ncell, ctx->stream));
+  GH_CHECK(ctx, hipMemsetAsync(ctx->ccom, 0, sizeof(CellCom)*Ncell, ctx->stream));
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->tree_layout_N = N;
   return GH_OK;
@@ -380,9 +401,12 @@ static int stock_tree(gh_ctx *ctx, int hmax_only)
   const double kr = KERNRANGE_OF(ctx->cfg);
   hipLaunchKernelGGL(k_stock_leaves, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, d, kr,
                      ctx->cfg.thetamaxsqd, hmax_only);
-  for (int l = ctx->ltot - 1; l >= 0; l--)
+  const int ltop = std::min(ctx->ltot - 1, 9);
+  for (int l = ctx->ltot - 1; l > ltop; l--)
     hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << l, 256)), dim3(256), 0, ctx->stream, d, l,
                        ctx->cfg.thetamaxsqd, hmax_only);
+  if (ltop >= 0)
+    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(512), 0, ctx->stream, d, ltop, ctx->cfg.thetamaxsqd, hmax_only);
   return GH_OK;
 }
 
