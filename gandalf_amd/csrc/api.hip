@@ -125,7 +125,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMemset(ctx->d_stats, 0, sizeof(unsigned long long)*ST_TOTAL));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
-  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*2*D_COUNT));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
   return GH_OK;
 }
 
@@ -187,6 +187,13 @@ int gh_alloc_particles(gh_ctx *ctx, int64_t N)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->side, n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortvals, sizeof(int)*n));
+  {
+    // permute tables: [0] = gather buffer 0 -> 1, [1] = gather buffer 1 -> 0 (src pointers then dst pointers)
+    double *tab[4*D_COUNT];
+    for (int c = 0; c < 2; c++)
+      for (int f = 0; f < D_COUNT; f++) { tab[c*2*D_COUNT + f] = ctx->fbuf[c][f]; tab[c*2*D_COUNT + D_COUNT + f] = ctx->fbuf[c ^ 1][f]; }
+    GH_CHECK(ctx, hipMemcpy(ctx->d_ptrtab, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
   ctx->Ncap = N; ctx->N = N;
   return GH_OK;
 }

@@ -26,12 +26,17 @@ struct DensityParams {
   int group0;        // first group of this rank's shard
 };
 
+#define DB 4      /* candidate tiles per phase-2 batch */
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
   __shared__ WalkLDS<int> L;
-  __shared__ double s_x[64], s_y[64], s_z[64], s_m[64];
+  __shared__ double s_x[DB*64], s_y[DB*64], s_z[DB*64], s_m[DB*64];   // a batch of DB candidate tiles
+  __shared__ unsigned long long s_mask[DB][64];                       // per tile, per lane: entries in support
+  __shared__ __attribute__((aligned(8))) float s_fx[64], s_fy[64], s_fz[64];  // current tile, fp32, relative to the group centre
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
@@ -48,6 +53,10 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   double ui = d.f[D_U][i];
   const CellBox gb = d.cbox[gnode];
   const double hfirst = 1.05*d.ch[gnode].hmax;      // the reference's first search radius (hmax*1.05)
+  double gc[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < ND; k++) gc[k] = 0.5*(gb.bbmin[k] + gb.bbmax[k]);
+  float tf[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < ND; k++) tf[k] = (float) (ri[k] - gc[k]);
 
   // per-lane iteration state (GradhSph.cpp:148-158)
   double h = d.f[D_H][i], hlo = 0.0, hup = hfirst;
@@ -111,36 +120,23 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = cn; }
       else open = true;
     };
-    auto tile = [&](bool valid, int j, int code) {
-      {
-        double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
-        if (valid) {
-          const double4 v = d.posm[j];
-          double sh[3];
-          code_shift(P.dom, code, sh);
-          x = v.x + sh[0]; y = v.y + sh[1]; z = v.z + sh[2]; m = v.w;
-        }
-        s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_m[lane] = m;
-      }
-      __syncthreads();
-      // phase 1: support mask
-      unsigned long long mask = 0;
-      if (running) {
-#pragma unroll 16
-        for (int c = 0; c < 64; c++) {
-          double r2 = 0.0;
-          { const double dx = s_x[c] - ri[0]; r2 = dx*dx; }
-          if (ND > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
-          if (ND > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
-          if (invhsqd*r2 < K::kernrangesqd) mask |= 1ull << c;
-          if (COUNT) { if (r2 + GH_SMALL <= cullsqd) n_cand++; }
-        }
-        if (COUNT) n_tested += 64;
-      }
-      // phase 2: kernel sums over the lane's own neighbours in this tile
-      while (__any(mask != 0ull)) {
+    // fp32 cull threshold: a superset of {invhsqd*r2 < kernrangesqd}.  Coordinates relative to the group
+    // centre are exact to 6e-8*Rmax in fp32, so distances are off by < 1e-6*Rmax + 1e-6*d; phase 2
+    // re-evaluates every survivor in fp64, and W(s >= 2) = 0 exactly, so extra survivors add zeros.
+    double Rmax = 0.0;
+    for (int k = 0; k < ND; k++) Rmax = fmax(Rmax, 0.5*(gb.bbmax[k] - gb.bbmin[k]) + K::kernrange*hs);
+    const float thr = running ? (float) ((K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(1.0 + 1e-6)) : -1.0f;
+    int nb = 0;                                          // tiles in the current batch
+    auto process_batch = [&]() {
+      // phase 2: every lane walks its own masks over the whole batch (lane balance: a lane's in-support
+      // entries per batch vary far less than per tile)
+      int b = 0;
+      unsigned long long mask = nb > 0 ? s_mask[0][lane] : 0ull;
+      for (;;) {
+        while (mask == 0ull && b + 1 < nb) mask = s_mask[++b][lane];
+        if (!__any(mask != 0ull)) break;
         if (mask != 0ull) {
-          const int c = __ffsll((long long) mask) - 1;
+          const int c = b*64 + __ffsll((long long) mask) - 1;
           mask &= mask - 1ull;
           double dr[3] = {0.0, 0.0, 0.0};
           dr[0] = s_x[c] - ri[0];
@@ -160,8 +156,57 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
         }
       }
       __syncthreads();
+      nb = 0;
+    };
+    auto tile = [&](bool valid, int j, int code) {
+      const int o = nb*64;
+      {
+        double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
+        if (valid) {
+          const double4 v = d.posm[j];
+          double sh[3];
+          code_shift(P.dom, code, sh);
+          x = v.x + sh[0]; y = v.y + sh[1]; z = v.z + sh[2]; m = v.w;
+        }
+        s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
+        s_fx[lane] = (float) (x - gc[0]); s_fy[lane] = ND > 1 ? (float) (y - gc[1]) : 0.f; s_fz[lane] = ND > 2 ? (float) (z - gc[2]) : 0.f;
+      }
+      __syncthreads();
+      // phase 1: support mask, packed fp32 (two candidates per instruction)
+      unsigned int mlo = 0, mhi = 0;
+      {
+        const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]};
+        const float2_t *fx = (const float2_t*) s_fx, *fy = (const float2_t*) s_fy, *fz = (const float2_t*) s_fz;
+#pragma unroll
+        for (int c2 = 0; c2 < 32; c2++) {
+          const float2_t dx = fx[c2] - tx;
+          float2_t r2 = dx*dx;
+          if (ND > 1) { const float2_t dy = fy[c2] - ty; r2 = dy*dy + r2; }
+          if (ND > 2) { const float2_t dz = fz[c2] - tz; r2 = dz*dz + r2; }
+          const int c = 2*c2;
+          if (c < 32) { mlo |= (r2.x < thr) ? (1u << c) : 0u; mlo |= (r2.y < thr) ? (2u << c) : 0u; }
+          else { mhi |= (r2.x < thr) ? (1u << (c - 32)) : 0u; mhi |= (r2.y < thr) ? (2u << (c - 32)) : 0u; }
+        }
+      }
+      s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);
+      if (COUNT) {
+        if (running) {
+          for (int c = 0; c < 64; c++) {
+            double r2 = 0.0;
+            { const double dx = s_x[o + c] - ri[0]; r2 = dx*dx; }
+            if (ND > 1) { const double dy = s_y[o + c] - ri[1]; r2 += dy*dy; }
+            if (ND > 2) { const double dz = s_z[o + c] - ri[2]; r2 += dz*dz; }
+            if (r2 + GH_SMALL <= cullsqd) n_cand++;
+          }
+          n_tested += 64;
+        }
+      }
+      nb++;
+      if (nb == DB) process_batch();
+      else __syncthreads();
     };
     walk_dfs_stream(d, L, codes, cls, tile, flags);
+    process_batch();
 
     if (running) {
       rho *= hfactor; omg *= hfactor; zet *= invhsqd;

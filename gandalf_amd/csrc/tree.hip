@@ -460,17 +460,12 @@ int gh_tree_build_impl(gh_ctx *ctx)
     pb ^= 1;
   }
 
-  // gather every particle array into tree order (perm[new] = old position)
+  // gather every particle array into tree order (perm[new] = old position).  The two pointer tables
+  // (buffer 0 -> 1 and 1 -> 0) live in device memory since allocation: no host synchronisation here.
   const int *perm = ctx->P[pb][0];
-  {
-    double *tab[2*D_COUNT];
-    for (int f = 0; f < D_COUNT; f++) { tab[f] = ctx->fbuf[ctx->cur][f]; tab[D_COUNT + f] = ctx->fbuf[ctx->cur ^ 1][f]; }
-    GH_CHECK(ctx, hipMemcpyAsync(ctx->d_ptrtab, tab, sizeof(tab), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), D_COUNT), dim3(256), 0, s, ctx->d_ptrtab, perm, N);
-    hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
-    GH_CHECK(ctx, hipStreamSynchronize(s));   // tab[] lives on this stack frame
-    ctx->cur ^= 1;
-  }
+  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), D_COUNT), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, N);
+  hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
+  ctx->cur ^= 1;
   stock_tree(ctx, 0);
   gh_pack_posm(ctx);
   GH_CHECK(ctx, hipGetLastError());
