@@ -39,11 +39,13 @@ def cpu_baseline(workload, verbose=False):
     if not os.path.exists(exe):
         return None
     cores = min(os.cpu_count() or 1, int(os.environ.get("GH_CPU_THREADS", "16")))
+    # bounded samples of the same workload shape: ~10-30 s of CPU work in all (the 1M Plummer setup alone
+    # takes the reference ~500 s on 8 cores because of its first density pass)
     if workload.startswith("plummer"):
-        par, n, steps, warm = "plummer_4k.dat", 32768, 6, 1
+        par, n, steps, warm = "plummer_4k.dat", 131072, 8, 1
         shape = "Plummer gas sphere self-gravity theta=0.5 monopole"
     else:
-        par, n, steps, warm = "box3d_4k.dat", 65536, 6, 1
+        par, n, steps, warm = "box3d_4k.dat", 262144, 10, 1
         shape = "uniform-random periodic box, hydro only"
     with tempfile.TemporaryDirectory() as tmp:
         src = open(os.path.join(ROOT, "tests", "params", par)).read().replace("Nhydro = 4096", "Nhydro = %d" % n)

@@ -128,29 +128,39 @@ __global__ void k_mark_side(DevicePtrs d, LevelArgs a)
   a.cellnode_next[p] = 2*n + 1 + right;
 }
 
-// level step 3: one 64-bit word of "is left" flags per wave per axis
-__global__ void k_ballot_words(DevicePtrs d, LevelArgs a)
+// level step 3: one 64-bit word of "is left" flags per wave per axis, plus the count of left flags of
+// every 256-particle block (what the prefix scan runs over: 16x less data than the words)
+__global__ __launch_bounds__(256) void k_ballot_words(DevicePtrs d, LevelArgs a)
 {
+  __shared__ unsigned int s_cnt[3][4];
   const int p = blockIdx.x*blockDim.x + threadIdx.x;
   for (int k = 0; k < d.ndim; k++) {
     const int flag = (p < d.N) ? (a.side[a.P[k][p]] == 0) : 0;
     const unsigned long long w = __ballot(flag);
-    if ((threadIdx.x & 63) == 0 && (p >> 6) < a.nwords) a.W[k][p >> 6] = w;
+    if ((threadIdx.x & 63) == 0) {
+      if ((p >> 6) < a.nwords) a.W[k][p >> 6] = w;
+      s_cnt[k][threadIdx.x >> 6] = __popcll(w);
+    }
+  }
+  __syncthreads();
+  if ((int) threadIdx.x < d.ndim) {
+    const int k = threadIdx.x;
+    a.Wpre[k][blockIdx.x] = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
   }
 }
 
-// level step 4: exclusive prefix sum of the popcounts of the words (one block per axis): per-thread run of
-// consecutive words, wave shuffle scan, 16 wave totals through LDS - two barriers in all
+// level step 4: in-place exclusive prefix sum of the block counts (one workgroup per axis): per-thread run,
+// wave shuffle scan, 16 wave totals through LDS - two barriers in all
 __global__ __launch_bounds__(1024) void k_scan_words(LevelArgs a)
 {
   const int k = blockIdx.x;
-  const unsigned long long *W = a.W[k];
   unsigned int *pre = a.Wpre[k];
+  const int nblk = (a.nwords + 3)/4;
   __shared__ unsigned int s_wave[16];
-  const int per = (a.nwords + 1023)/1024;
-  const int lo = threadIdx.x*per, hi = min(lo + per, a.nwords);
+  const int per = (nblk + 1023)/1024;
+  const int lo = threadIdx.x*per, hi = min(lo + per, nblk);
   unsigned int sum = 0;
-  for (int i = lo; i < hi; i++) sum += __popcll(W[i]);
+  for (int i = lo; i < hi; i++) sum += pre[i];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned int inc = sum;
   for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
@@ -163,14 +173,17 @@ __global__ __launch_bounds__(1024) void k_scan_words(LevelArgs a)
   }
   __syncthreads();
   unsigned int run = s_wave[wave] + inc - sum;
-  for (int i = lo; i < hi; i++) { pre[i] = run; run += __popcll(W[i]); }
+  for (int i = lo; i < hi; i++) { const unsigned int c = pre[i]; pre[i] = run; run += c; }
 }
 
+// number of left flags in [0, p): block prefix + whole words of the block before p + bits of p's word
 __device__ __forceinline__ unsigned int rank_left(const unsigned long long *W, const unsigned int *pre, int p)
 {
   const int w = p >> 6, b = p & 63;
+  unsigned int r = pre[p >> 8];
+  for (int i = (w & ~3); i < w; i++) r += __popcll(W[i]);
   const unsigned long long m = b ? (W[w] & ((1ull << b) - 1ull)) : 0ull;
-  return pre[w] + __popcll(m);
+  return r + __popcll(m);
 }
 
 // level step 5: stable partition of every cell segment of every axis list
