@@ -61,11 +61,18 @@ void Parameters::SetDefaultValues()
     floatparams["boxmin" + idx] = 0.0;
     floatparams["boxmax" + idx] = 0.0;
     intparams["Nlattice1" + idx] = 1;
+    intparams["Nlattice2" + idx] = 1;
+    floatparams["vfluid1" + idx] = 0.0;
+    floatparams["vfluid2" + idx] = 0.0;
   }
   // initial conditions
   intparams["Nhydro"] = 0;
   intparams["Nstar"] = 0;
   stringparams["particle_distribution"] = "cubic_lattice";
+  floatparams["rhofluid1"] = 1.0;
+  floatparams["rhofluid2"] = 1.0;
+  floatparams["press1"] = 1.0;
+  floatparams["press2"] = 1.0;
   floatparams["mplummer"] = 1.0;
   floatparams["rplummer"] = 1.0;
   floatparams["radius"] = 1.0;

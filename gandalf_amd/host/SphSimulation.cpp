@@ -138,8 +138,8 @@ void SphSimulation::GenerateIC()
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
   const int N = ip["Nhydro"];
-  if (N <= 0) throw GandalfError("Nhydro must be positive");
-  sph->AllocateMemory(N);
+  if (N <= 0 && ic != "shocktube") throw GandalfError("Nhydro must be positive");
+  sph->AllocateMemory(std::max(N, 1));
   HydroParticles &p = sph->part;
   if (ic == "box") {
     if (ip["dimensionless"] == 0) throw GandalfError("dimensionless units required");
@@ -197,6 +197,36 @@ void SphSimulation::GenerateIC()
       p.u[i] = p.u[i]*(mplummer/rplummer);
     }
     initial_h_provided = false;
+  }
+  else if (ic == "shocktube") {
+    // ShocktubeIc::Generate (ShocktubeIc.cpp:55-200), 1-D: two cubic lattices (Ic::AddCubicLattice,
+    // Ic.cpp:629-664) left and right of x = 0; u from the pressure (EOS::InternalEnergyFromPressure, EOS.h:164)
+    if (ndim != 1) throw GandalfError("shocktube is built for ndim = 1");
+    if (ip["dimensionless"] == 0) throw GandalfError("dimensionless units required");
+    const int Nbox1 = ip["Nlattice1[0]"], Nbox2 = ip["Nlattice2[0]"];
+    const double gammaone = fp["gamma_eos"] - 1.0;
+    const double rho[2] = {fp["rhofluid1"], fp["rhofluid2"]}, press[2] = {fp["press1"], fp["press2"]};
+    const double vf[2] = {fp["vfluid1[0]"], fp["vfluid2[0]"]};
+    const double bmin[2] = {cfg.boxmin[0], 0.0}, bmax[2] = {0.0, cfg.boxmax[0]};
+    const int Nb[2] = {Nbox1, Nbox2};
+    sph->AllocateMemory(Nbox1 + Nbox2);
+    HydroParticles &q = sph->part;
+    int off = 0;
+    for (int side = 0; side < 2; side++) {
+      const double spacing = (bmax[side] - bmin[side])/(double) Nb[side];
+      const double volume = bmax[side] - bmin[side];
+      const double u = sp["gas_eos"] == "isothermal" ? fp["temp0"]/gammaone/fp["mu_bar"] : press[side]/(rho[side]*gammaone);
+      for (int ii = 0; ii < Nb[side]; ii++) {
+        const int i = off + ii;
+        q.r[i] = bmin[side] + ((double) ii + 0.5)*spacing;
+        q.v[i] = vf[side];
+        q.m[i] = rho[side]*volume/(double) Nb[side];
+        q.h[i] = cfg.h_fac*pow(q.m[i]/rho[side], 1.0);
+        q.u[i] = u;
+      }
+      off += Nb[side];
+    }
+    initial_h_provided = true;
   }
   else throw GandalfError("Unrecognised parameter : ic = " + ic);
 }

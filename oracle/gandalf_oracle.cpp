@@ -98,6 +98,10 @@ struct M4 {
   }
 };
 
+// pow(x, n) with a compile-time integer exponent as the reference's templates see it: g++ folds
+// pow(x,1) -> x and pow(x,2) -> x*x (exactly rounded) even without -ffast-math, higher powers stay libm calls
+static inline FLOAT pow_ref(FLOAT x, int n) { return n == 1 ? x : (n == 2 ? x*x : pow(x, (FLOAT) n)); }
+
 static inline FLOAT Dot(const FLOAT *a, const FLOAT *b, int nd)   // InlineFuncs.h:46-54
 {
   if (nd == 1) return a[0]*b[0];
@@ -420,7 +424,7 @@ struct Oracle {
       iteration++;
       invh = 1.0/pi.h;
       pi.rho = 0.0; pi.invomega = 0.0; pi.zeta = 0.0;
-      pi.hfactor = pow(invh, nd);
+      pi.hfactor = pow_ref(invh, nd);
       invhsqd = invh*invh;
       for (int j = 0; j < Nneib; j++) {
         const Part &ngb = p[ngb2[j]];
@@ -445,7 +449,7 @@ struct Oracle {
     } while (pi.h > h_lower_bound && pi.h < h_upper_bound);
     pi.h = std::max(h_rho_func(pi.m, pi.rho), h_lower_bound);
     invh = 1/pi.h;
-    pi.hfactor = pow(invh, nd + 1);
+    pi.hfactor = pow_ref(invh, nd + 1);
     pi.hrangesqd = kern.kernrangesqd*pi.h*pi.h;
     pi.div_v = 0.0;
     pi.invomega = 1.0 - h_rho_deriv(pi.h, pi.rho)*pi.invomega;

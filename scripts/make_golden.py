@@ -37,7 +37,11 @@ def run(args, cwd):
     subprocess.run([REF] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, env=env)
 
 
-def passes(name, nsteps=3):
+NSTEPS = {"adsod_1d": 20}
+
+
+def passes(name, nsteps=None):
+    nsteps = nsteps or NSTEPS.get(name, 3)
     par = os.path.join(ROOT, "tests", "params", name + ".dat")
     with tempfile.TemporaryDirectory() as tmp:
         run(["passes", par, os.path.join(tmp, "p")], tmp)
@@ -79,5 +83,5 @@ def passes(name, nsteps=3):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    for cfg in (sys.argv[1:] or ["box3d_4k", "plummer_4k"]):
+    for cfg in (sys.argv[1:] or ["box3d_4k", "plummer_4k", "adsod_1d"]):
         passes(cfg)

@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["box3d_4k", "plummer_4k"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d"]
 
 
 def make(case):
@@ -132,6 +132,7 @@ def test_steps_match_reference(case):
     assert abs(t - tf) <= 1e-12*abs(tf)
     assert abs(dt - dtf) <= 1e-9*abs(dtf)
     assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-11*np.abs(g["final_r"]).max()
+    assert np.max(np.abs(sim.download("v") - g["final_v"])) < 1e-10*max(np.abs(g["final_v"]).max(), 1e-3)
     assert relerr(sim.download("h"), g["final_h"]) < 1e-10
     assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
     assert vec_err(sim.download("a"), g["final_a"]) < 1e-9

@@ -57,7 +57,7 @@ def test_params_grammar_and_defaults():
     assert sim2.get_param("Nhydro") == "128" and sim2.get_param("boundary_lhs[0]") == "periodic"
 
 
-@pytest.mark.parametrize("case", ["box3d_4k", "plummer_4k"])
+@pytest.mark.parametrize("case", ["box3d_4k", "plummer_4k", "adsod_1d"])
 def test_ic_generators_bitwise(case):
     from gandalf_amd.host import Simulation
     g = load_golden(case + "_passes")
@@ -66,4 +66,4 @@ def test_ic_generators_bitwise(case):
     assert np.array_equal(ic["m"], g["in_m"])
     assert np.array_equal(ic["u"], g["in_u"])
     assert np.array_equal(ic["v"], g["in_v"])
-    assert ic["initial_h_provided"] == (case == "box3d_4k")
+    assert ic["initial_h_provided"] == (case != "plummer_4k")
