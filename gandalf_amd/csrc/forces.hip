@@ -41,9 +41,20 @@ struct Accum {
   double dudt, div_v, gpot;
 };
 
+// neighbour record in registers (same 16 fields, same order as the T_* tile / hrec layout)
+struct Neib { double x, y, z, m, vx, vy, vz, hr2, invh, hfac, pfac, invrho, sound, zeta, u, press; };
+
+__device__ __forceinline__ void neib_from_tile(Neib &n, const double (*s_t)[64], int c)
+{
+  n.x = s_t[T_X][c]; n.y = s_t[T_Y][c]; n.z = s_t[T_Z][c]; n.m = s_t[T_M][c];
+  n.vx = s_t[T_VX][c]; n.vy = s_t[T_VY][c]; n.vz = s_t[T_VZ][c]; n.hr2 = s_t[T_HR2][c];
+  n.invh = s_t[T_INVH][c]; n.hfac = s_t[T_HFAC][c]; n.pfac = s_t[T_PFAC][c]; n.invrho = s_t[T_INVRHO][c];
+  n.sound = s_t[T_SOUND][c]; n.zeta = s_t[T_ZETA][c]; n.u = s_t[T_U][c]; n.press = s_t[T_PRESS][c];
+}
+
 // one SPH pair, particle i <- neighbour j               (GradhSph.cpp:384-448 / 498-572)
 template <int ND, bool GRAV>
-__device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const double (*s_t)[64], int c,
+__device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const Neib &nb,
                                          const double dr_in[3], double r2)
 {
 #pragma clang fp contract(fast)
@@ -59,35 +70,35 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
     drmag = sqrt(r2);
     if (drmag > 0.0) { const double inv = 1.0/drmag; for (int k = 0; k < ND; k++) dr[k] *= inv; }
   }
-  const double mj = s_t[T_M][c];
-  const double invh_j = s_t[T_INVH][c];
+  const double mj = nb.m;
+  const double invh_j = nb.invh;
   const double wkerni = ti.hfactor*K::w1(drmag*ti.invh);
-  const double wkernj = s_t[T_HFAC][c]*K::w1(drmag*invh_j);
+  const double wkernj = nb.hfac*K::w1(drmag*invh_j);
   double dvdr = 0.0;
   {
-    dvdr = (s_t[T_VX][c] - ti.v[0])*dr[0];
-    if (ND > 1) dvdr += (s_t[T_VY][c] - ti.v[1])*dr[1];
-    if (ND > 2) dvdr += (s_t[T_VZ][c] - ti.v[2])*dr[2];
+    dvdr = (nb.vx - ti.v[0])*dr[0];
+    if (ND > 1) dvdr += (nb.vy - ti.v[1])*dr[1];
+    if (ND > 2) dvdr += (nb.vz - ti.v[2])*dr[2];
   }
   A.div_v -= mj*dvdr*wkerni;
-  double paux = ti.pfac*wkerni + s_t[T_PFAC][c]*wkernj;
+  double paux = ti.pfac*wkerni + nb.pfac*wkernj;
   if (dvdr < 0.0) {
-    const double invrho_j = s_t[T_INVRHO][c];
+    const double invrho_j = nb.invrho;
     const double winvrho = 0.25*(wkerni + wkernj)*(ti.invrho + invrho_j);
     if (P.avisc == GH_AVISC_MON97) {
-      const double vsignal = ti.sound + s_t[T_SOUND][c] - P.beta_visc*P.alpha_visc*dvdr;
+      const double vsignal = ti.sound + nb.sound - P.beta_visc*P.alpha_visc*dvdr;
       paux -= P.alpha_visc*vsignal*dvdr*winvrho;
       A.dudt -= 0.5*mj*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;
     }
     if (P.acond == GH_ACOND_WADSLEY2008)
-      A.dudt += mj*dvdr*(s_t[T_U][c] - ti.u)*(ti.invrho*wkerni + invrho_j*wkernj);
+      A.dudt += mj*dvdr*(nb.u - ti.u)*(ti.invrho*wkerni + invrho_j*wkernj);
     else if (P.acond == GH_ACOND_PRICE2008)
-      A.dudt += 0.5*mj*(ti.u - s_t[T_U][c])*winvrho*(ti.invrho + invrho_j)*sqrt(fabs(ti.press - s_t[T_PRESS][c]));
+      A.dudt += 0.5*mj*(ti.u - nb.u)*winvrho*(ti.invrho + invrho_j)*sqrt(fabs(ti.press - nb.press));
   }
   for (int k = 0; k < ND; k++) A.a[k] += mj*dr[k]*paux;
   if (GRAV) {
     const double pg = 0.5*(ti.invhsqd*K::wgrav(drmag*ti.invh) + ti.zeta*wkerni +
-                           invh_j*invh_j*K::wgrav(drmag*invh_j) + s_t[T_ZETA][c]*wkernj);
+                           invh_j*invh_j*K::wgrav(drmag*invh_j) + nb.zeta*wkernj);
     for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*pg;
     A.gpot += 0.5*mj*(ti.invh*K::wpot(drmag*ti.invh) + invh_j*K::wpot(drmag*invh_j));
   }
@@ -224,7 +235,9 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         double r2 = dr[0]*dr[0];
         if (ND > 1) r2 += dr[1]*dr[1];
         if (ND > 2) r2 += dr[2]*dr[2];
-        sph_pair<ND, false>(P, ti, A, s_t, c, dr, r2);
+        Neib nbr;
+        neib_from_tile(nbr, s_t, c);
+        sph_pair<ND, false>(P, ti, A, nbr, dr, r2);
         if (COUNT) n_pairs++;
       }
     }
@@ -251,6 +264,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // ================================================================================================
 #define GH_MAXLEAF 16
 #define GH_CCAP 132          /* far-field entry list capacity (flushed when more than 64 are pending; +4 padding) */
+#define GH_NDCAP 160         /* per-leaf list of direct-only near leaves */
+#define GH_NHCAP 96          /* per-leaf list of near leaves with hydro candidates */
 
 // 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps in FMA form; ends within
 // 1-2 ulp.  (ocml's rsqrt also handles denormals/inf/nan, which cannot occur here: x >= 1e-20.)
@@ -294,6 +309,9 @@ __device__ __forceinline__ void point_mass(const TargetI &ti, Accum &A, double x
 #define STAMP_ADD(slot, t0)
 #endif
 
+// near-list entry: first particle (27 bits) | count << 27
+__device__ __forceinline__ int near_entry(int first, int n) { return first | (n << 27); }
+
 template <int ND, bool COUNT>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
@@ -304,12 +322,13 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
 #endif
   __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];      // leaf mask of every stack entry
-  __shared__ RangeRing s_hyd, s_dir;               // near-field leaves: hydro candidates / direct only
-  __shared__ int s_pre[64];
   __shared__ double s_cx[GH_CCAP], s_cy[GH_CCAP], s_cz[GH_CCAP], s_cm[GH_CCAP];
   __shared__ unsigned short s_cmask[GH_CCAP];
-  __shared__ double s_t[T_NF][64];
-  __shared__ int s_ttag[64];
+  // near field: the reference's interaction list is per LEAF CELL, and the near-field leaves of the 16
+  // leaves of a group overlap only partly (a lane needs ~1/5 of their union).  So each leaf keeps its
+  // own lists of near leaves and every lane streams exactly its leaf's particles.
+  __shared__ int s_ndir[GH_MAXLEAF][GH_NDCAP], s_nhyd[GH_MAXLEAF][GH_NHCAP];
+  __shared__ int s_nlen[2][GH_MAXLEAF];
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
@@ -340,6 +359,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
       }
     }
+    if (lane < GH_MAXLEAF) { s_nlen[0][lane] = 0; s_nlen[1][lane] = 0; }
     Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
@@ -354,12 +374,12 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   A.dudt = 0.0; A.div_v = 0.0;
   A.gpot = (d.f[D_M][i]/d.f[D_H][i])*K::wpot(0.0);      // self term, GradhSphTree.cpp:512
   unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
+  const int occ = d.leafocc;
 
   int ncell = 0;
   // ---- cells: monopole                                           (NeighbourSearch.h:350-377)
   auto flush_cells = [&]() {
     STAMP(tc0);
-    __syncthreads();
     // pad to a multiple of 4 with empty entries so that the loop can be unrolled without a remainder
     if (lane < 4 && ncell + lane < GH_CCAP) { s_cmask[ncell + lane] = 0; s_cm[ncell + lane] = 0.0; s_cx[ncell + lane] = 1e30; s_cy[ncell + lane] = 1e30; s_cz[ncell + lane] = 1e30; }
     __syncthreads();
@@ -377,92 +397,79 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     ncell = 0;
     STAMP_ADD(1, tc0);
   };
-  // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
-  auto tile_dir = [&](bool valid, int j, int tag) {
-    STAMP(td0);
-    {
-      double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
-      if (valid) v = d.posm[j];
-      s_t[T_X][lane] = v.x; s_t[T_Y][lane] = v.y; s_t[T_Z][lane] = v.z; s_t[T_M][lane] = v.w;
-      s_ttag[lane] = valid ? tag : 0;
-    }
+  // ---- near field: every lane streams the particles of its own leaf's near leaves
+  auto flush_near = [&]() {
     __syncthreads();
-#pragma unroll 4
-    for (int c = 0; c < 64; c++) {
-      const bool take = (s_ttag[c] >> myleaf) & 1;
-      point_mass<ND>(ti, A, s_t[T_X][c], s_t[T_Y][c], s_t[T_Z][c], take ? s_t[T_M][c] : 0.0);
-      if (COUNT) n_direct += take ? 1 : 0;
-    }
-    __syncthreads();
-    STAMP_ADD(2, td0);
-  };
-  // ---- leaves with hydro candidates: tag = hydro-candidate leaf mask | direct leaf mask << 16
-  auto tile_hyd = [&](bool valid, int j, int tag) {
-    STAMP(th0);
-    {
-      const double sh[3] = {0.0, 0.0, 0.0};
-      stage_neib(d, ND, s_t, lane, j, sh, valid);
-      s_ttag[lane] = valid ? tag : 0;
-    }
-    __syncthreads();
-    unsigned long long mask = 0;
-    if (act) {
-#pragma unroll 4
-      for (int c = 0; c < 64; c++) {
-        const int tg = s_ttag[c];
-        const bool hydc = (tg >> myleaf) & 1, dirc = (tg >> (16 + myleaf)) & 1;
-        if (hydc || dirc) {
-          double dr[3] = {0.0, 0.0, 0.0};
-          dr[0] = s_t[T_X][c] - ti.r[0];
-          if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
-          if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
-          double r2 = dr[0]*dr[0];
-          if (ND > 1) r2 += dr[1]*dr[1];
-          if (ND > 2) r2 += dr[2]*dr[2];
-          // hydro candidate that is a real SPH neighbour, NeighbourManager.h:521-533
-          const bool sph = hydc && !(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c]);
-          if (sph) mask |= 1ull << c;
-          else {
-#pragma clang fp contract(fast)
-            const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
-            const double mj = s_t[T_M][c];
-            const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
-            for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
-            A.gpot += mj*invdrmag;
-            if (COUNT) n_direct++;
-          }
-        }
+    STAMP(tn0);
+    const int Ld = s_nlen[0][myleaf], Lh = s_nlen[1][myleaf];
+    int maxd = 0, maxh = 0;
+    for (int l = 0; l < nl; l++) { maxd = max(maxd, s_nlen[0][l]); maxh = max(maxh, s_nlen[1][l]); }
+    // direct-only leaves: Newtonian particle terms                  (GradhSph.cpp:671-686)
+    for (int e = 0; e < maxd; e++) {
+      const int ent = e < Ld ? s_ndir[myleaf][e] : 0;
+      const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
+      double4 v[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { v[k].x = 1e30; v[k].y = 1e30; v[k].z = 1e30; v[k].w = 0.0; if (k < cnt) v[k] = d.posm[first + k]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        if (k < occ) point_mass<ND>(ti, A, v[k].x, v[k].y, v[k].z, v[k].w);
       }
+      if (COUNT) n_direct += cnt;
     }
-    STAMP_ADD(3, th0);
-    STAMP(tp0);
-    while (__any(mask != 0ull)) {
-      if (mask != 0ull) {
-        const int c = __ffsll((long long) mask) - 1;
-        mask &= mask - 1ull;
+    STAMP_ADD(2, tn0);
+    STAMP(th0);
+    // leaves with hydro candidates: per pair SPH neighbour or direct  (NeighbourManager.h:521-533)
+    for (int e = 0; e < maxh; e++) {
+      const int ent = e < Lh ? s_nhyd[myleaf][e] : 0;
+      const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
+      for (int k = 0; k < occ; k++) {
+        const bool valid = k < cnt;
+        Neib nb;
+        {
+          double4 q0, q1, q2, q3;
+          q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
+          q1.x = 0.0; q1.y = 0.0; q1.z = 0.0; q1.w = 0.0;
+          q2.x = 1.0; q2.y = 0.0; q2.z = 0.0; q2.w = 1.0;
+          q3.x = 0.0; q3.y = 0.0; q3.z = 0.0; q3.w = 0.0;
+          if (valid) { const double4 *r = d.hrec + 4*(size_t) (first + k); q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+          nb.x = q0.x; nb.y = q0.y; nb.z = q0.z; nb.m = q0.w; nb.vx = q1.x; nb.vy = q1.y; nb.vz = q1.z; nb.hr2 = q1.w;
+          nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
+        }
         double dr[3] = {0.0, 0.0, 0.0};
-        dr[0] = s_t[T_X][c] - ti.r[0];
-        if (ND > 1) dr[1] = s_t[T_Y][c] - ti.r[1];
-        if (ND > 2) dr[2] = s_t[T_Z][c] - ti.r[2];
+        dr[0] = nb.x - ti.r[0];
+        if (ND > 1) dr[1] = nb.y - ti.r[1];
+        if (ND > 2) dr[2] = nb.z - ti.r[2];
         double r2 = dr[0]*dr[0];
         if (ND > 1) r2 += dr[1]*dr[1];
         if (ND > 2) r2 += dr[2]*dr[2];
-        sph_pair<ND, true>(P, ti, A, s_t, c, dr, r2);
-        if (COUNT) n_pairs++;
+        const bool sph = valid && !(r2 >= ti.hr2 && r2 >= nb.hr2);
+        if (sph) { sph_pair<ND, true>(P, ti, A, nb, dr, r2); if (COUNT) n_pairs++; }
+        else {
+#pragma clang fp contract(fast)
+          const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
+          const double minvdr3 = nb.m*(invdrmag*invdrmag*invdrmag);     // nb.m = 0 for an empty slot
+          for (int kk = 0; kk < ND; kk++) A.at[kk] += dr[kk]*minvdr3;
+          A.gpot += nb.m*invdrmag;
+          if (COUNT) n_direct += valid ? 1 : 0;
+        }
       }
     }
     __syncthreads();
-    STAMP_ADD(4, tp0);
+    if (lane < GH_MAXLEAF) { s_nlen[0][lane] = 0; s_nlen[1][lane] = 0; }
+    __syncthreads();
+    STAMP_ADD(3, th0);
   };
 
   // ---- depth-first walk with per-leaf masks                       (Tree.cpp:648-731)
   if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
-  RangeState Rh, Rd; Rh.nrb = 0; Rh.nslots = 0; Rd.nrb = 0; Rd.nslots = 0;
   __syncthreads();
   int top = 1;
+  int maxlen_d = 0, maxlen_h = 0;                     // wave-uniform upper bounds of the near-list lengths
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
     if (ncell > 64) flush_cells();
+    if (maxlen_d > GH_NDCAP - 64 || maxlen_h > GH_NHCAP - 64) { flush_near(); maxlen_d = 0; maxlen_h = 0; }
     STAMP(tw0);
     const int p = pop_width(top);
     const int newtop = top - p;
@@ -509,9 +516,8 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         }
       }
     }
-    const bool ehyd = hydm != 0, edir = hydm == 0 && dirm != 0;
     const unsigned long long om = __ballot(openm != 0), cm = __ballot(cellm != 0);
-    const unsigned long long hm = __ballot(ehyd), dm = __ballot(edir);
+    const bool anynear = __any((hydm | dirm) != 0);
     __syncthreads();
     if (openm) {
       const int pos = newtop + 2*__popcll(om & lt);
@@ -529,27 +535,35 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       s_cmask[pos] = (unsigned short) cellm;
     }
     ncell += __popcll(cm);
-    if (ehyd) {
-      const int pos = Rh.nrb + __popcll(hm & lt);
-      s_hyd.first[pos] = g.first; s_hyd.cnt[pos] = g.N; s_hyd.tag[pos] = (int) (hydm | (dirm << 16));
+    if (anynear) {
+      // append this step's near leaves to the lists of the target leaves they belong to
+      const int ent = near_entry(g.first, g.N);
+      int md = 0, mh = 0;
+      for (int l = 0; l < nl; l++) {
+        const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
+        const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
+        if (mh_) {
+          const int base = s_nlen[1][l];
+          if (bh) { const int pos = base + __popcll(mh_ & lt); if (pos < GH_NHCAP) s_nhyd[l][pos] = ent; }
+          const int nn = base + __popcll(mh_);
+          mh = max(mh, nn);
+          if (lane == 0) s_nlen[1][l] = nn;
+        }
+        if (md_) {
+          const int base = s_nlen[0][l];
+          if (bd) { const int pos = base + __popcll(md_ & lt); if (pos < GH_NDCAP) s_ndir[l][pos] = ent; }
+          const int nn = base + __popcll(md_);
+          md = max(md, nn);
+          if (lane == 0) s_nlen[0][l] = nn;
+        }
+      }
+      maxlen_d = max(maxlen_d, md); maxlen_h = max(maxlen_h, mh);
     }
-    if (edir) {
-      const int pos = Rd.nrb + __popcll(dm & lt);
-      s_dir.first[pos] = g.first; s_dir.cnt[pos] = g.N; s_dir.tag[pos] = (int) dirm;
-    }
-    Rh.nrb += __popcll(hm); Rd.nrb += __popcll(dm);
-    Rh.nslots += wave_sum_i(ehyd ? g.N : 0);
-    Rd.nslots += wave_sum_i(edir ? g.N : 0);
     __syncthreads();
     STAMP_ADD(0, tw0);
-    STAMP(tdr0);
-    if (Rh.nslots >= 64 || Rh.nrb > GH_RBCAP - 64) range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, false, tile_hyd);
-    if (Rd.nslots >= 64 || Rd.nrb > GH_RBCAP - 64) range_drain_raw(s_dir.first, s_dir.cnt, s_dir.tag, s_pre, Rd, false, tile_dir);
-    STAMP_ADD(5, tdr0);
   }
   flush_cells();
-  range_drain_raw(s_hyd.first, s_hyd.cnt, s_hyd.tag, s_pre, Rh, true, tile_hyd);
-  range_drain_raw(s_dir.first, s_dir.cnt, s_dir.tag, s_pre, Rd, true, tile_dir);
+  flush_near();
 
   if (act) {
     // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619
