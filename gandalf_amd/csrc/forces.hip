@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // ================================================================================================
 #define GH_MAXLEAF 16
 #define GH_CCAP 132          /* far-field entry list capacity (flushed when more than 64 are pending; +4 padding) */
-#define GH_NDCAP 160         /* per-leaf list of direct-only near leaves */
+#define GH_NDCAP 72          /* per-leaf list of direct-only near leaves (rare: only opened, non-overlapping leaves) */
 #define GH_NHCAP 96          /* per-leaf list of near leaves with hydro candidates */
 
 // 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps in FMA form; ends within
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   // own lists of near leaves and every lane streams exactly its leaf's particles.
   __shared__ int s_ndir[GH_MAXLEAF][GH_NDCAP], s_nhyd[GH_MAXLEAF][GH_NHCAP];
   __shared__ int s_nlen[2][GH_MAXLEAF];
+  __shared__ unsigned int s_sphbits[(GH_NHCAP*6 + 31)/32][64];   // per lane: which streamed candidates are SPH neighbours
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
@@ -359,7 +360,6 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
       }
     }
-    if (lane < GH_MAXLEAF) { s_nlen[0][lane] = 0; s_nlen[1][lane] = 0; }
     Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
@@ -376,6 +376,10 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
   const int occ = d.leafocc;
 
+  int maxlen_d = 0, maxlen_h = 0;                     // wave-uniform maxima of the near-list lengths
+  int len_d[GH_MAXLEAF], len_h[GH_MAXLEAF];
+#pragma unroll
+  for (int l = 0; l < GH_MAXLEAF; l++) { len_d[l] = 0; len_h[l] = 0; }
   int ncell = 0;
   // ---- cells: monopole                                           (NeighbourSearch.h:350-377)
   auto flush_cells = [&]() {
@@ -399,65 +403,121 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   };
   // ---- near field: every lane streams the particles of its own leaf's near leaves
   auto flush_near = [&]() {
-    __syncthreads();
     STAMP(tn0);
+    if (lane == 0) {
+#pragma unroll
+      for (int l = 0; l < GH_MAXLEAF; l++) { s_nlen[0][l] = len_d[l]; s_nlen[1][l] = len_h[l]; }
+    }
+    __syncthreads();
     const int Ld = s_nlen[0][myleaf], Lh = s_nlen[1][myleaf];
-    int maxd = 0, maxh = 0;
-    for (int l = 0; l < nl; l++) { maxd = max(maxd, s_nlen[0][l]); maxh = max(maxh, s_nlen[1][l]); }
-    // direct-only leaves: Newtonian particle terms                  (GradhSph.cpp:671-686)
-    for (int e = 0; e < maxd; e++) {
-      const int ent = e < Ld ? s_ndir[myleaf][e] : 0;
-      const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
-      double4 v[6];
+    const int maxd = maxlen_d, maxh = maxlen_h;
+    // direct-only leaves: Newtonian particle terms                  (GradhSph.cpp:671-686).
+    // Software pipeline: the records of entry e+1 are in flight while entry e is evaluated.
+    {
+      auto dload = [&](int e, double4 (&v)[6], int &cnt) {
+        const int ent = e < Ld ? s_ndir[myleaf][e] : 0;
+        const int first = ent & 0x7ffffff;
+        cnt = act ? (ent >> 27) & 0xf : 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { v[k].x = 1e30; v[k].y = 1e30; v[k].z = 1e30; v[k].w = 0.0; if (k < cnt) v[k] = d.posm[first + k]; }
+        for (int k = 0; k < 6; k++) { v[k].x = 1e30; v[k].y = 1e30; v[k].z = 1e30; v[k].w = 0.0; if (k < cnt) v[k] = d.posm[first + k]; }
+      };
+      auto dcomp = [&](const double4 (&v)[6], int cnt) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        if (k < occ) point_mass<ND>(ti, A, v[k].x, v[k].y, v[k].z, v[k].w);
+        for (int k = 0; k < 6; k++) {
+          if (k < occ) point_mass<ND>(ti, A, v[k].x, v[k].y, v[k].z, v[k].w);
+        }
+        if (COUNT) n_direct += cnt;
+      };
+      double4 va[6], vb[6];
+      int ca = 0, cb = 0;
+      if (maxd > 0) dload(0, va, ca);
+      for (int e = 0; e < maxd; e += 2) {
+        dload(e + 1, vb, cb);
+        dcomp(va, ca);
+        dload(e + 2, va, ca);
+        if (e + 1 < maxd) dcomp(vb, cb);
       }
-      if (COUNT) n_direct += cnt;
     }
     STAMP_ADD(2, tn0);
     STAMP(th0);
-    // leaves with hydro candidates: per pair SPH neighbour or direct  (NeighbourManager.h:521-533)
-    for (int e = 0; e < maxh; e++) {
-      const int ent = e < Lh ? s_nhyd[myleaf][e] : 0;
-      const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
-      for (int k = 0; k < occ; k++) {
-        const bool valid = k < cnt;
-        Neib nb;
-        {
-          double4 q0, q1, q2, q3;
-          q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
-          q1.x = 0.0; q1.y = 0.0; q1.z = 0.0; q1.w = 0.0;
-          q2.x = 1.0; q2.y = 0.0; q2.z = 0.0; q2.w = 1.0;
-          q3.x = 0.0; q3.y = 0.0; q3.z = 0.0; q3.w = 0.0;
-          if (valid) { const double4 *r = d.hrec + 4*(size_t) (first + k); q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
-          nb.x = q0.x; nb.y = q0.y; nb.z = q0.z; nb.m = q0.w; nb.vx = q1.x; nb.vy = q1.y; nb.vz = q1.z; nb.hr2 = q1.w;
-          nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
-        }
+    // leaves with hydro candidates: per pair SPH neighbour or direct  (NeighbourManager.h:521-533).
+    // Pass 1 streams every candidate of the lane's leaf (position, mass, hrangesqd only), evaluates the
+    // direct ones at once and records the SPH neighbours in a bit set; pass 2 walks the lane's own bits
+    // and evaluates the (long) SPH pair term only for those - no lane waits on another lane's branch.
+    {
+      const int nt = maxh*occ;                       // flattened (entry, slot) index, same for all lanes
+      auto hload = [&](int t, double4 &q0, double &hr2, bool &valid) {
+        const int e = t/occ, k = t - e*occ;
+        const int ent = e < Lh ? s_nhyd[myleaf][e] : 0;
+        const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
+        valid = k < cnt;
+        q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0;
+        if (valid) { const double4 *r = d.hrec + 4*(size_t) (first + k); q0 = r[0]; hr2 = r[1].w; }
+      };
+      unsigned int cur = 0;
+      auto hcomp = [&](int t, const double4 &q0, double hr2, bool valid) {
         double dr[3] = {0.0, 0.0, 0.0};
-        dr[0] = nb.x - ti.r[0];
-        if (ND > 1) dr[1] = nb.y - ti.r[1];
-        if (ND > 2) dr[2] = nb.z - ti.r[2];
+        dr[0] = q0.x - ti.r[0];
+        if (ND > 1) dr[1] = q0.y - ti.r[1];
+        if (ND > 2) dr[2] = q0.z - ti.r[2];
         double r2 = dr[0]*dr[0];
         if (ND > 1) r2 += dr[1]*dr[1];
         if (ND > 2) r2 += dr[2]*dr[2];
-        const bool sph = valid && !(r2 >= ti.hr2 && r2 >= nb.hr2);
-        if (sph) { sph_pair<ND, true>(P, ti, A, nb, dr, r2); if (COUNT) n_pairs++; }
-        else {
+        const bool sph = valid && !(r2 >= ti.hr2 && r2 >= hr2);
+        cur |= (sph ? 1u : 0u) << (t & 31);
+        {
 #pragma clang fp contract(fast)
+          const double mj = sph ? 0.0 : q0.w;                           // 0 for empty slots and SPH neighbours
           const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
-          const double minvdr3 = nb.m*(invdrmag*invdrmag*invdrmag);     // nb.m = 0 for an empty slot
+          const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
           for (int kk = 0; kk < ND; kk++) A.at[kk] += dr[kk]*minvdr3;
-          A.gpot += nb.m*invdrmag;
-          if (COUNT) n_direct += valid ? 1 : 0;
+          A.gpot += mj*invdrmag;
+        }
+        if (COUNT) n_direct += (valid && !sph) ? 1 : 0;
+        if ((t & 31) == 31) { s_sphbits[t >> 5][lane] = cur; cur = 0; }
+      };
+      double4 qa, qb; double ha = 0.0, hb = 0.0; bool vala = false, valb = false;
+      if (nt > 0) hload(0, qa, ha, vala);
+      for (int t = 0; t < nt; t += 2) {
+        hload(t + 1, qb, hb, valb);
+        hcomp(t, qa, ha, vala);
+        hload(t + 2, qa, ha, vala);
+        if (t + 1 < nt) hcomp(t + 1, qb, hb, valb);
+      }
+      const int nw = (nt + 31) >> 5;
+      if (nt & 31) s_sphbits[nt >> 5][lane] = cur;
+      // pass 2 (each lane reads back only what it wrote: no barrier needed)
+      int w = 0;
+      unsigned int bits = nw > 0 ? s_sphbits[0][lane] : 0u;
+      for (;;) {
+        while (bits == 0u && w + 1 < nw) bits = s_sphbits[++w][lane];
+        if (!__any(bits != 0u)) break;
+        if (bits != 0u) {
+          const int t = w*32 + __ffs((int) bits) - 1;
+          bits &= bits - 1u;
+          const int e = t/occ, k = t - e*occ;
+          const int first = s_nhyd[myleaf][e] & 0x7ffffff;
+          const double4 *r = d.hrec + 4*(size_t) (first + k);
+          const double4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+          Neib nb;
+          nb.x = q0.x; nb.y = q0.y; nb.z = q0.z; nb.m = q0.w; nb.vx = q1.x; nb.vy = q1.y; nb.vz = q1.z; nb.hr2 = q1.w;
+          nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = nb.x - ti.r[0];
+          if (ND > 1) dr[1] = nb.y - ti.r[1];
+          if (ND > 2) dr[2] = nb.z - ti.r[2];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          sph_pair<ND, true>(P, ti, A, nb, dr, r2);
+          if (COUNT) n_pairs++;
         }
       }
     }
     __syncthreads();
-    if (lane < GH_MAXLEAF) { s_nlen[0][lane] = 0; s_nlen[1][lane] = 0; }
-    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < GH_MAXLEAF; l++) { len_d[l] = 0; len_h[l] = 0; }
+    maxlen_d = 0; maxlen_h = 0;
     STAMP_ADD(3, th0);
   };
 
@@ -465,11 +525,10 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
   __syncthreads();
   int top = 1;
-  int maxlen_d = 0, maxlen_h = 0;                     // wave-uniform upper bounds of the near-list lengths
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
     if (ncell > 64) flush_cells();
-    if (maxlen_d > GH_NDCAP - 64 || maxlen_h > GH_NHCAP - 64) { flush_near(); maxlen_d = 0; maxlen_h = 0; }
+    if (maxlen_d > GH_NDCAP - 64 || maxlen_h > GH_NHCAP - 64) flush_near();
     STAMP(tw0);
     const int p = pop_width(top);
     const int newtop = top - p;
@@ -536,28 +595,26 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     }
     ncell += __popcll(cm);
     if (anynear) {
-      // append this step's near leaves to the lists of the target leaves they belong to
+      // append this step's near leaves to the lists of the target leaves they belong to; the list
+      // lengths are wave-uniform and live in scalar registers (len_d / len_h), the loop is fully unrolled
       const int ent = near_entry(g.first, g.N);
-      int md = 0, mh = 0;
-      for (int l = 0; l < nl; l++) {
-        const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
-        const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
-        if (mh_) {
-          const int base = s_nlen[1][l];
-          if (bh) { const int pos = base + __popcll(mh_ & lt); if (pos < GH_NHCAP) s_nhyd[l][pos] = ent; }
-          const int nn = base + __popcll(mh_);
-          mh = max(mh, nn);
-          if (lane == 0) s_nlen[1][l] = nn;
-        }
-        if (md_) {
-          const int base = s_nlen[0][l];
-          if (bd) { const int pos = base + __popcll(md_ & lt); if (pos < GH_NDCAP) s_ndir[l][pos] = ent; }
-          const int nn = base + __popcll(md_);
-          md = max(md, nn);
-          if (lane == 0) s_nlen[0][l] = nn;
+#pragma unroll
+      for (int l = 0; l < GH_MAXLEAF; l++) {
+        if (l < nl) {
+          const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
+          const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
+          if (mh_) {
+            if (bh) { const int pos = len_h[l] + __popcll(mh_ & lt); if (pos < GH_NHCAP) s_nhyd[l][pos] = ent; }
+            len_h[l] += __popcll(mh_);
+            maxlen_h = max(maxlen_h, len_h[l]);
+          }
+          if (md_) {
+            if (bd) { const int pos = len_d[l] + __popcll(md_ & lt); if (pos < GH_NDCAP) s_ndir[l][pos] = ent; }
+            len_d[l] += __popcll(md_);
+            maxlen_d = max(maxlen_d, len_d[l]);
+          }
         }
       }
-      maxlen_d = max(maxlen_d, md); maxlen_h = max(maxlen_h, mh);
     }
     __syncthreads();
     STAMP_ADD(0, tw0);
