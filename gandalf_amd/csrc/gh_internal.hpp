@@ -100,6 +100,10 @@ struct gh_ctx {
   double *redbuf = nullptr;        // reduction scratch
   bool tree_valid = false;
 
+  // gravity interaction lists in HBM (gravity.hip)
+  int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr;
+  size_t glist_leaves = 0;
+
   // statistics / timers
   unsigned long long *d_stats = nullptr;   // device counters
   int *d_flags = nullptr;                  // device error flags
@@ -153,6 +157,7 @@ int gh_update_hmax_impl(gh_ctx *ctx);
 int gh_density_impl(gh_ctx *ctx, bool count);
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count);
 int gh_all_forces_impl(gh_ctx *ctx, bool count);
+int gh_grav_lists_impl(gh_ctx *ctx, bool count);   // two-kernel gravity with interaction lists in HBM
 int gh_zero_acc_impl(gh_ctx *ctx);
 int gh_kdk_advance_impl(gh_ctx *ctx, int n, double t, double timestep);
 int gh_kdk_end_impl(gh_ctx *ctx, int n, double t, double timestep);

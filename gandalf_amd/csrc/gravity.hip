@@ -1,0 +1,419 @@
+// gravity.hip -- hydro + self-gravity forces as two kernels with the interaction lists in HBM.
+//
+// Replaces the same reference code as k_grav_forces in forces.hip (GradhSphTree::UpdateAllSphForces and
+// everything it calls per leaf cell, reference src/GradhSph/GradhSphTree.cpp:444-657, src/Tree/Tree.cpp:628-735,
+// src/Headers/NeighbourManager.h:368-543, src/GradhSph/GradhSph.cpp:474-690, NeighbourSearch.h:350-377).
+//
+// The reference builds one interaction list per LEAF CELL and then loops particle x list entry.  A
+// leaf's list (~1300 cells + ~100 near leaves at theta = 0.5) is far longer than a leaf is wide (4-6
+// particles), so the parallel axis of the evaluation is the LIST, not the particles:
+//
+//   k_grav_walk : one wavefront per group of <= 16 leaves walks the tree once with a 16-bit leaf mask
+//                 per stack entry (every (node, leaf) decision is the reference's, taken with the leaf's
+//                 own rcell/rmax/hmax) and appends node / leaf ids to the per-leaf lists in HBM
+//                 (three lists per leaf: accepted cells, direct-only leaves, leaves with hydro candidates).
+//                 With 288 GB of HBM the lists of a 1M-particle run (1.8 GB) are no concern.
+//   k_grav_eval : one wavefront per leaf; lane = list entry.  Every lane evaluates its entry against the
+//                 leaf's 4-6 particles (target data broadcast from LDS) and the wave reduces the partial
+//                 sums at the end: all 64 lanes are busy whatever the masks were.  Hydro candidates are
+//                 classified per (particle, candidate); the real SPH neighbours of each particle are
+//                 compacted (ballot) into an LDS list and evaluated 64 pairs at a time.
+#include "force_common.hpp"
+
+#define GH_MAXLEAF 16
+#define GH_MAXOCC 8          /* max particles per leaf handled by the evaluation kernel */
+#define GH_SPHCAP 640        /* SPH neighbours of one particle held in LDS (SURVEY: max 393 at 4k Plummer) */
+
+struct GravLists {
+  int *cells, *dirl, *hydl;  // [gtot][cap_*]
+  int *len;                  // [gtot][3]
+  int cap_c, cap_d, cap_h;
+};
+
+// ================================================================================================
+// walk                                                           (Tree.cpp:628-735, Tree.h:413-432)
+// ================================================================================================
+template <int ND>
+__global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, GravLists G, int *flags)
+{
+  typedef M4<ND> K;
+  __shared__ int s_stack[GH_SCAP];
+  __shared__ unsigned short s_smask[GH_SCAP];
+  __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
+
+  const int lane = threadIdx.x;
+  const unsigned long long lt = lanemask_lt();
+  const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  if (d.cN[gnode] == 0) return;
+  const int nl = 1 << (d.ltot - d.lgroup);
+  const int leaf0 = d.gtot - 1;
+  const int leafnode0 = leaf0 + q*nl;
+
+  unsigned int allmask = 0;
+  const CellGeo gg = d.cgeo[gnode];
+  double Rg = 0.0, Lm = 0.0, Lr = 0.0;
+  {
+    double rg = 0.0, lm = 0.0, lr = 0.0;
+    if (lane < nl) {
+      const CellGeo g = d.cgeo[leafnode0 + lane];
+      for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
+      s_lrmax[lane] = g.rmax;
+      s_lhr[lane] = K::kernrange*g.hmax;
+      if (g.N > 0) {
+        double dd = 0.0;
+        for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; dd += dx*dx; }
+        rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
+      }
+    }
+    Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
+  }
+  for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
+  // list lengths: wave-uniform, in scalar registers (loops over leaves are fully unrolled)
+  int len_c[GH_MAXLEAF], len_d[GH_MAXLEAF], len_h[GH_MAXLEAF];
+#pragma unroll
+  for (int l = 0; l < GH_MAXLEAF; l++) { len_c[l] = 0; len_d[l] = 0; len_h[l] = 0; }
+  if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
+  __syncthreads();
+  int top = 1;
+  bool overflow = false;
+  while (top > 0) {
+    const int p = pop_width(top);
+    const int newtop = top - p;
+    unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
+    int n = 0; bool isleaf = false;
+    CellGeo g;
+    g.first = 0; g.N = 0;
+    if (lane < p) {
+      n = s_stack[top - 1 - lane];
+      const unsigned int fm = s_smask[top - 1 - lane];
+      g = d.cgeo[n];
+      isleaf = n >= leaf0;
+      const double khr = K::kernrange*g.hmax;
+      // quick classification against the whole group (see k_grav_forces): lower bound D - Rg on every
+      // leaf's distance; if it clears the overlap and opening distances, every leaf says "cell"
+      double D2 = 0.0;
+      for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; D2 += dx*dx; }
+      const double Dm = (sqrt(D2) - Rg)*(1.0 - 1e-12);
+      const double Tn = g.rmax + fmax(Lm, Lr + khr);
+      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd) {
+        if (isleaf && g.N == 1) dirm = fm; else cellm = fm;
+      }
+      else {
+        for (int l = 0; l < nl; l++) {
+          if (!((fm >> l) & 1)) continue;
+          double drsqd = 0.0;
+          for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - s_lrc[l][k]; drsqd += dx*dx; }
+          const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
+          const double d2 = s_lrmax[l] + g.rmax + khr;
+          if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
+            if (!isleaf) openm |= 1u << l;
+            else if (g.N > 0) hydm |= 1u << l;
+          }
+          else if (g.N == 0) { }
+          else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
+            if (isleaf && g.N == 1) dirm |= 1u << l;
+            else cellm |= 1u << l;
+          }
+          else {
+            if (!isleaf) openm |= 1u << l;
+            else dirm |= 1u << l;
+          }
+        }
+      }
+    }
+    const unsigned long long om = __ballot(openm != 0);
+    const bool anycell = __any(cellm != 0), anynear = __any((hydm | dirm) != 0);
+    __syncthreads();
+    if (openm) {
+      const int pos = newtop + 2*__popcll(om & lt);
+      if (pos + 1 < GH_SCAP) {
+        s_stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
+        s_stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
+      }
+    }
+    top = newtop + 2*__popcll(om);
+    if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
+    if (anycell | anynear) {
+      const int nent = g.first | (g.N << 27);
+#pragma unroll
+      for (int l = 0; l < GH_MAXLEAF; l++) {
+        if (l < nl) {
+          const size_t leaf = (size_t) (q*nl + l);
+          if (anycell) {
+            const bool bc = (cellm >> l) & 1;
+            const unsigned long long m_ = __ballot(bc);
+            if (m_) {
+              const int pos = len_c[l] + __popcll(m_ & lt);
+              if (bc) { if (pos < G.cap_c) G.cells[leaf*G.cap_c + pos] = n; else overflow = true; }
+              len_c[l] += __popcll(m_);
+            }
+          }
+          if (anynear) {
+            const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
+            const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
+            if (mh_) {
+              const int pos = len_h[l] + __popcll(mh_ & lt);
+              if (bh) { if (pos < G.cap_h) G.hydl[leaf*G.cap_h + pos] = nent; else overflow = true; }
+              len_h[l] += __popcll(mh_);
+            }
+            if (md_) {
+              const int pos = len_d[l] + __popcll(md_ & lt);
+              if (bd) { if (pos < G.cap_d) G.dirl[leaf*G.cap_d + pos] = nent; else overflow = true; }
+              len_d[l] += __popcll(md_);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < GH_MAXLEAF; l++) {
+      if (l < nl) {
+        const size_t leaf = (size_t) (q*nl + l);
+        G.len[leaf*3 + 0] = min(len_c[l], G.cap_c);
+        G.len[leaf*3 + 1] = min(len_d[l], G.cap_d);
+        G.len[leaf*3 + 2] = min(len_h[l], G.cap_h);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// evaluation                                                      (GradhSphTree.cpp:505-619)
+// ================================================================================================
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int ND, bool COUNT>
+__global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
+                                                   unsigned long long *stats, int *flags)
+{
+  typedef M4<ND> K;
+  __shared__ TargetI s_tg[GH_MAXOCC];
+  __shared__ int s_sph[GH_MAXOCC][GH_SPHCAP];
+  __shared__ double s_out[GH_MAXOCC][10];             // a[3], at[3], dudt, div_v, gpot, spare
+
+  const int lane = threadIdx.x;
+  const unsigned long long lt = lanemask_lt();
+  const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
+  const int node = (d.gtot - 1) + gl;
+  const int first = d.cfirst[node], Nt = d.cN[node];
+  if (Nt == 0) return;
+  if (Nt > GH_MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
+  const int occ = d.leafocc;
+
+  if (lane < Nt) {
+    TargetI t;
+    load_target(d, first + lane, ND, t);
+    s_tg[lane] = t;
+    for (int k = 0; k < 10; k++) s_out[lane][k] = 0.0;
+    s_out[lane][8] = (d.f[D_M][first + lane]/d.f[D_H][first + lane])*K::wpot(0.0);    // self term, GradhSphTree.cpp:512
+  }
+  __syncthreads();
+  const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = G.len[(size_t) gl*3 + 2];
+  const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d, *hydl = G.hydl + (size_t) gl*G.cap_h;
+
+  // per-lane partial sums of the point-mass terms, one set per target particle
+  Accum acc[GH_MAXOCC];
+#pragma unroll
+  for (int i = 0; i < GH_MAXOCC; i++) { for (int k = 0; k < 3; k++) { acc[i].a[k] = 0.0; acc[i].at[k] = 0.0; } acc[i].dudt = 0.0; acc[i].div_v = 0.0; acc[i].gpot = 0.0; }
+  unsigned long long n_cells = 0, n_direct = 0, n_pairs = 0;
+
+  // ---- accepted cells: monopole terms                            (NeighbourSearch.h:350-377)
+  {
+    auto cload = [&](int c0, double4 &v) {
+      const int e = c0 + lane;
+      v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
+      if (e < lenc) { const CellCom c = d.ccom[cells[e]]; v.x = c.com[0]; v.y = c.com[1]; v.z = c.com[2]; v.w = c.m; }
+    };
+    auto ccomp = [&](const double4 &v) {
+#pragma unroll
+      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+    };
+    double4 va, vb;
+    if (lenc > 0) cload(0, va);
+    for (int c0 = 0; c0 < lenc; c0 += 128) {
+      cload(c0 + 64, vb);
+      ccomp(va);
+      cload(c0 + 128, va);
+      if (c0 + 64 < lenc) ccomp(vb);
+    }
+    if (COUNT) n_cells += (unsigned long long) lenc*Nt;       // counted once per wave below
+  }
+  // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
+  for (int c0 = 0; c0 < lend; c0 += 64) {
+    const int e = c0 + lane;
+    const int ent = e < lend ? dirl[e] : 0;
+    const int pf = ent & 0x7ffffff, pn = (ent >> 27) & 0xf;
+    for (int k = 0; k < occ; k++) {
+      double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
+      if (k < pn) v = d.posm[pf + k];
+#pragma unroll
+      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+      if (COUNT) n_direct += (k < pn) ? Nt : 0;
+    }
+  }
+  // ---- leaves with hydro candidates: classify every (particle, candidate); direct ones at once, SPH
+  //      neighbours compacted per particle into LDS              (NeighbourManager.h:521-533)
+  int nsph[GH_MAXOCC];
+#pragma unroll
+  for (int i = 0; i < GH_MAXOCC; i++) nsph[i] = 0;
+  bool overflow = false;
+  for (int c0 = 0; c0 < lenh; c0 += 64) {
+    const int e = c0 + lane;
+    const int ent = e < lenh ? hydl[e] : 0;
+    const int pf = ent & 0x7ffffff, pn = (ent >> 27) & 0xf;
+    for (int k = 0; k < occ; k++) {
+      const bool valid = k < pn;
+      double4 q0; q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
+      double hr2 = 0.0;
+      if (valid) { const double4 *r = d.hrec + 4*(size_t) (pf + k); q0 = r[0]; hr2 = r[1].w; }
+#pragma unroll
+      for (int i = 0; i < GH_MAXOCC; i++) {
+        if (i < Nt) {
+          const TargetI &ti = s_tg[i];
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = q0.x - ti.r[0];
+          if (ND > 1) dr[1] = q0.y - ti.r[1];
+          if (ND > 2) dr[2] = q0.z - ti.r[2];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          const bool sph = valid && !(r2 >= ti.hr2 && r2 >= hr2);
+          const unsigned long long sm = __ballot(sph);
+          if (sm) {
+            const int pos = nsph[i] + __popcll(sm & lt);
+            if (sph) { if (pos < GH_SPHCAP) s_sph[i][pos] = pf + k; else overflow = true; }
+            nsph[i] += __popcll(sm);
+          }
+          {
+#pragma clang fp contract(fast)
+            const double mj = sph ? 0.0 : q0.w;
+            const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
+            const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
+            for (int kk = 0; kk < ND; kk++) acc[i].at[kk] += dr[kk]*minvdr3;
+            acc[i].gpot += mj*invdrmag;
+          }
+          if (COUNT) n_direct += (valid && !sph) ? 1 : 0;
+        }
+      }
+    }
+  }
+  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);
+  __syncthreads();
+  // ---- SPH pairs, 64 at a time per target particle               (GradhSph.cpp:474-585)
+#pragma unroll
+  for (int i = 0; i < GH_MAXOCC; i++) {
+    if (i < Nt) {
+      const TargetI ti = s_tg[i];
+      const int ns = min(nsph[i], GH_SPHCAP);
+      Accum A;
+      for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
+      A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
+      for (int c0 = 0; c0 < ns; c0 += 64) {
+        if (c0 + lane < ns) {
+          const int j = s_sph[i][c0 + lane];
+          const double4 *r = d.hrec + 4*(size_t) j;
+          const double4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+          Neib nb;
+          nb.x = q0.x; nb.y = q0.y; nb.z = q0.z; nb.m = q0.w; nb.vx = q1.x; nb.vy = q1.y; nb.vz = q1.z; nb.hr2 = q1.w;
+          nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = nb.x - ti.r[0];
+          if (ND > 1) dr[1] = nb.y - ti.r[1];
+          if (ND > 2) dr[2] = nb.z - ti.r[2];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          sph_pair<ND, true>(P, ti, A, nb, dr, r2);
+        }
+      }
+      if (COUNT) n_pairs += (unsigned long long) ns;
+      // reduce this particle's sums over the wave
+      double red[9];
+      for (int k = 0; k < 3; k++) { red[k] = wave_sum_d(A.a[k]); red[3 + k] = wave_sum_d(A.at[k] + acc[i].at[k]); }
+      red[6] = wave_sum_d(A.dudt); red[7] = wave_sum_d(A.div_v); red[8] = wave_sum_d(A.gpot + acc[i].gpot);
+      if (lane == 0) for (int k = 0; k < 9; k++) s_out[i][k] += red[k];
+    }
+  }
+  __syncthreads();
+  if (lane < Nt) {
+    // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619
+    const int i = first + lane;
+    const TargetI &ti = s_tg[lane];
+    double div_v = s_out[lane][7], dudt = s_out[lane][6];
+    div_v *= ti.invrho;
+    dudt -= ti.press*div_v*ti.invrho*d.f[D_INVOMEGA][i];
+    for (int k = 0; k < ND; k++) {
+      double a = d.f[D_AX + k][i];
+      a += s_out[lane][k];
+      a += s_out[lane][3 + k];
+      d.f[D_AX + k][i] = a;
+      d.f[D_ATX + k][i] += s_out[lane][3 + k];
+    }
+    d.f[D_GPOT][i] += s_out[lane][8];
+    d.f[D_GPOT_HYDRO][i] += s_out[lane][8];
+    d.f[D_DUDT][i] += dudt;
+    d.f[D_DIV_V][i] += div_v;
+  }
+  if (COUNT && lane == 0) {
+    atomicAdd(&stats[ST_CELLS], n_cells);
+    atomicAdd(&stats[ST_PAIRS], n_pairs);
+  }
+  if (COUNT) { const unsigned long long b = wave_sum_u64(n_direct); if (lane == 0) atomicAdd(&stats[ST_DIRECT], b); }
+}
+
+// ================================================================================================
+// host
+// ================================================================================================
+int gh_grav_lists_impl(gh_ctx *ctx, bool count)
+{
+  // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
+  const int cap_c = 4096, cap_d = 256, cap_h = 768;
+  const size_t nleaf = (size_t) ctx->gtot;
+  if (ctx->glist_leaves != nleaf) {
+    for (void *p : {(void*) ctx->gl_cells, (void*) ctx->gl_dirl, (void*) ctx->gl_hydl, (void*) ctx->gl_len}) if (p) (void) hipFree(p);
+    ctx->gl_cells = ctx->gl_dirl = ctx->gl_hydl = ctx->gl_len = nullptr;
+    ctx->glist_leaves = 0;
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_cells, sizeof(int)*nleaf*cap_c));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_dirl, sizeof(int)*nleaf*cap_d));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_hydl, sizeof(int)*nleaf*cap_h));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_len, sizeof(int)*nleaf*3));
+    ctx->glist_leaves = nleaf;
+  }
+  GravLists G;
+  G.cells = ctx->gl_cells; G.dirl = ctx->gl_dirl; G.hydl = ctx->gl_hydl; G.len = ctx->gl_len;
+  G.cap_c = cap_c; G.cap_d = cap_d; G.cap_h = cap_h;
+  DevicePtrs d = gh_dev(ctx);
+  ForceParams P;
+  gh_fill_domain(ctx, P.dom);
+  gh_fill_eos(ctx, P.eos);
+  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
+  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond;
+  int g0, g1;
+  gh_shard_groups(ctx, ctx->rank, g0, g1);
+  P.group0 = g0;
+  const int ngroups = g1 - g0;
+  const int nl = 1 << (ctx->ltot - ctx->lgroup);
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
+  gh_phase_begin(ctx, GH_T_SPH_FORCES);
+  if (ngroups > 0) {
+#define LAUNCH(ND_)                                                                                            \
+    hipLaunchKernelGGL((k_grav_walk<ND_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);                \
+    if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_grav_eval<ND_, false>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags);
+    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#undef LAUNCH
+  }
+  gh_phase_end(ctx, GH_T_SPH_FORCES);
+  GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
+}
