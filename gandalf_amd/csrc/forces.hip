@@ -148,9 +148,10 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 __device__ __forceinline__ int near_entry(int first, int n) { return first | (n << 27); }
 
 template <int ND, bool COUNT>
-__global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
+__global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags, const int *only_if)
 {
   typedef M4<ND> K;
+  if (only_if && !*only_if) return;                   // fallback launch that is not needed
 #ifdef GH_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long st_t0 = clock64();
@@ -518,6 +519,26 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   return GH_OK;
 }
 
+// launch of the fused gravity kernel; with only_if != NULL the kernel returns at once unless *only_if is set
+int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
+{
+  DevicePtrs d = gh_dev(ctx);
+  ForceParams P;
+  fill_force_params(ctx, P);
+  int g0, g1;
+  gh_shard_groups(ctx, ctx->rank, g0, g1);
+  const int nblocks = g1 - g0;
+  hipStream_t s = ctx->stream;
+  if (nblocks > 0) {
+#define LAUNCH(ND_)                                                                                              \
+    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
+    else hipLaunchKernelGGL((k_grav_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if);
+    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#undef LAUNCH
+  }
+  return GH_OK;
+}
+
 int gh_all_forces_impl(gh_ctx *ctx, bool count)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_all_forces: no tree");
@@ -529,27 +550,15 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
-    // GH_GRAV_FUSED=1 selects the single fused kernel below (same results to rounding)
+    // GH_GRAV_FUSED=1 (or leaves wider than the evaluation kernel handles) selects the single fused kernel
     const char *fused = getenv("GH_GRAV_FUSED");
-    if (!(fused && fused[0] == '1')) return gh_grav_lists_impl(ctx, count);
+    if (!(fused && fused[0] == '1') && ctx->leafocc <= 8) return gh_grav_lists_impl(ctx, count);
   }
-  DevicePtrs d = gh_dev(ctx);
-  ForceParams P;
-  fill_force_params(ctx, P);
-  int g0, g1;
-  gh_shard_groups(ctx, ctx->rank, g0, g1);
-  const int nblocks = g1 - g0;
-  hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
-  if (nblocks > 0) {
-#define LAUNCH(ND_)                                                                                              \
-    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_grav_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
-#undef LAUNCH
-  }
+  int rc = gh_grav_fused_launch(ctx, count, nullptr);
   gh_phase_end(ctx, GH_T_SPH_FORCES);
+  if (rc) return rc;
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }

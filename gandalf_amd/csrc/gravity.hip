@@ -20,13 +20,17 @@
 //                 compacted (ballot) into an LDS list and evaluated 64 pairs at a time.
 #include "force_common.hpp"
 
+int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if);
+
 #define GH_MAXLEAF 16
 #define GH_MAXOCC 8          /* max particles per leaf handled by the evaluation kernel */
 #define GH_SPHCAP 640        /* SPH neighbours of one particle held in LDS (SURVEY: max 393 at 4k Plummer) */
 
 struct GravLists {
-  int *cells, *dirl, *hydl;  // [gtot][cap_*]
+  int *cells, *dirl;         // [gtot][cap_*]: node ids / (first | N << 27) leaf entries
+  int2 *hydl;                // [gtot][cap_h]: (first, count) particle ranges - a leaf, or a whole subtree
   int *len;                  // [gtot][3]
+  int *fallback;             // set when a list overflowed: the fused kernel redoes the call
   int cap_c, cap_d, cap_h;
 };
 
@@ -107,8 +111,16 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
           const double d1 = g.rmax + s_lrmax[l] + s_lhr[l];
           const double d2 = s_lrmax[l] + g.rmax + khr;
           if (drsqd <= d1*d1 || drsqd <= d2*d2) {                  // overlap -> hydro candidates / open
-            if (!isleaf) openm |= 1u << l;
-            else if (g.N > 0) hydm |= 1u << l;
+            if (isleaf) { if (g.N > 0) hydm |= 1u << l; }
+            else {
+              // the node's bounding sphere lies inside the leaf's overlap range: every descendant leaf
+              // (its centre is within g.rmax of this centre) passes the first overlap test, so the walk
+              // would list ALL its particles as hydro candidates - emit the whole range, do not open
+              const double rr = s_lrmax[l] + s_lhr[l];
+              const double dd_ = sqrt(drsqd) + g.rmax;
+              if (g.N > 0 && dd_ <= rr*(1.0 - 1e-12)) hydm |= 1u << l;
+              else openm |= 1u << l;
+            }
           }
           else if (g.N == 0) { }
           else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
             const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
             if (mh_) {
               const int pos = len_h[l] + __popcll(mh_ & lt);
-              if (bh) { if (pos < G.cap_h) G.hydl[leaf*G.cap_h + pos] = nent; else overflow = true; }
+              if (bh) { if (pos < G.cap_h) G.hydl[leaf*G.cap_h + pos] = make_int2(g.first, g.N); else overflow = true; }
               len_h[l] += __popcll(mh_);
             }
             if (md_) {
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
     }
     __syncthreads();
   }
-  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);
+  if (__any(overflow) && lane == 0) atomicOr(G.fallback, 1);
   if (lane == 0) {
 #pragma unroll
     for (int l = 0; l < GH_MAXLEAF; l++) {
@@ -198,10 +210,13 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
   typedef M4<ND> K;
   __shared__ TargetI s_tg[GH_MAXOCC];
   __shared__ int s_sph[GH_MAXOCC][GH_SPHCAP];
+  __shared__ RangeRing s_ring;
+  __shared__ int s_pre[64];
   __shared__ double s_out[GH_MAXOCC][10];             // a[3], at[3], dudt, div_v, gpot, spare
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
+  if (*G.fallback) return;                              // a list overflowed: the fused kernel does this call
   const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
   const int node = (d.gtot - 1) + gl;
   const int first = d.cfirst[node], Nt = d.cN[node];
@@ -218,7 +233,8 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
   }
   __syncthreads();
   const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = G.len[(size_t) gl*3 + 2];
-  const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d, *hydl = G.hydl + (size_t) gl*G.cap_h;
+  const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d;
+  const int2 *hydl = G.hydl + (size_t) gl*G.cap_h;
 
   // per-lane partial sums of the point-mass terms, one set per target particle
   Accum acc[GH_MAXOCC];
@@ -266,47 +282,55 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
 #pragma unroll
   for (int i = 0; i < GH_MAXOCC; i++) nsph[i] = 0;
   bool overflow = false;
-  for (int c0 = 0; c0 < lenh; c0 += 64) {
-    const int e = c0 + lane;
-    const int ent = e < lenh ? hydl[e] : 0;
-    const int pf = ent & 0x7ffffff, pn = (ent >> 27) & 0xf;
-    for (int k = 0; k < occ; k++) {
-      const bool valid = k < pn;
-      double4 q0; q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
-      double hr2 = 0.0;
-      if (valid) { const double4 *r = d.hrec + 4*(size_t) (pf + k); q0 = r[0]; hr2 = r[1].w; }
+  auto hyd_tile = [&](bool valid, int j, int) {
+    double4 q0; q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
+    double hr2 = 0.0;
+    if (valid) { const double4 *r = d.hrec + 4*(size_t) j; q0 = r[0]; hr2 = r[1].w; }
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) {
-        if (i < Nt) {
-          const TargetI &ti = s_tg[i];
-          double dr[3] = {0.0, 0.0, 0.0};
-          dr[0] = q0.x - ti.r[0];
-          if (ND > 1) dr[1] = q0.y - ti.r[1];
-          if (ND > 2) dr[2] = q0.z - ti.r[2];
-          double r2 = dr[0]*dr[0];
-          if (ND > 1) r2 += dr[1]*dr[1];
-          if (ND > 2) r2 += dr[2]*dr[2];
-          const bool sph = valid && !(r2 >= ti.hr2 && r2 >= hr2);
-          const unsigned long long sm = __ballot(sph);
-          if (sm) {
-            const int pos = nsph[i] + __popcll(sm & lt);
-            if (sph) { if (pos < GH_SPHCAP) s_sph[i][pos] = pf + k; else overflow = true; }
-            nsph[i] += __popcll(sm);
-          }
-          {
-#pragma clang fp contract(fast)
-            const double mj = sph ? 0.0 : q0.w;
-            const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
-            const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
-            for (int kk = 0; kk < ND; kk++) acc[i].at[kk] += dr[kk]*minvdr3;
-            acc[i].gpot += mj*invdrmag;
-          }
-          if (COUNT) n_direct += (valid && !sph) ? 1 : 0;
+    for (int i = 0; i < GH_MAXOCC; i++) {
+      if (i < Nt) {
+        const TargetI &ti = s_tg[i];
+        double dr[3] = {0.0, 0.0, 0.0};
+        dr[0] = q0.x - ti.r[0];
+        if (ND > 1) dr[1] = q0.y - ti.r[1];
+        if (ND > 2) dr[2] = q0.z - ti.r[2];
+        double r2 = dr[0]*dr[0];
+        if (ND > 1) r2 += dr[1]*dr[1];
+        if (ND > 2) r2 += dr[2]*dr[2];
+        const bool sph = valid && !(r2 >= ti.hr2 && r2 >= hr2);
+        const unsigned long long sm = __ballot(sph);
+        if (sm) {
+          const int pos = nsph[i] + __popcll(sm & lt);
+          if (sph) { if (pos < GH_SPHCAP) s_sph[i][pos] = j; else overflow = true; }
+          nsph[i] += __popcll(sm);
         }
+        {
+#pragma clang fp contract(fast)
+          const double mj = sph ? 0.0 : q0.w;
+          const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
+          const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
+          for (int kk = 0; kk < ND; kk++) acc[i].at[kk] += dr[kk]*minvdr3;
+          acc[i].gpot += mj*invdrmag;
+        }
+        if (COUNT) n_direct += (valid && !sph) ? 1 : 0;
       }
     }
+  };
+  {
+    RangeState R; R.nrb = 0; R.nslots = 0;
+    for (int c0 = 0; c0 < lenh; c0 += 64) {
+      const int e = c0 + lane;
+      int2 ent = make_int2(0, 0);
+      if (e < lenh) ent = hydl[e];
+      const unsigned long long vm = __ballot(ent.y > 0);
+      if (ent.y > 0) { const int pos = R.nrb + __popcll(vm & lt); s_ring.first[pos] = ent.x; s_ring.cnt[pos] = ent.y; s_ring.tag[pos] = 0; }
+      R.nrb += __popcll(vm);
+      R.nslots += wave_sum_i(ent.y);
+      range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, hyd_tile);
+    }
+    range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, hyd_tile);
   }
-  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);
+  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);      // > GH_SPHCAP neighbours of one particle
   __syncthreads();
   // ---- SPH pairs, 64 at a time per target particle               (GradhSph.cpp:474-585)
 #pragma unroll
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
 int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
-  const int cap_c = 4096, cap_d = 256, cap_h = 768;
+  const int cap_c = 4096, cap_d = 256, cap_h = 1024;
   const size_t nleaf = (size_t) ctx->gtot;
   if (ctx->glist_leaves != nleaf) {
     for (void *p : {(void*) ctx->gl_cells, (void*) ctx->gl_dirl, (void*) ctx->gl_hydl, (void*) ctx->gl_len}) if (p) (void) hipFree(p);
@@ -384,12 +408,14 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
     ctx->glist_leaves = 0;
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_cells, sizeof(int)*nleaf*cap_c));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_dirl, sizeof(int)*nleaf*cap_d));
-    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_hydl, sizeof(int)*nleaf*cap_h));
-    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_len, sizeof(int)*nleaf*3));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_hydl, sizeof(int2)*nleaf*cap_h));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_len, sizeof(int)*(nleaf*3 + 4)));
     ctx->glist_leaves = nleaf;
   }
   GravLists G;
-  G.cells = ctx->gl_cells; G.dirl = ctx->gl_dirl; G.hydl = ctx->gl_hydl; G.len = ctx->gl_len;
+  G.cells = ctx->gl_cells; G.dirl = ctx->gl_dirl; G.hydl = (int2*) ctx->gl_hydl; G.len = ctx->gl_len;
+  G.fallback = ctx->gl_len + nleaf*3;
+  GH_CHECK(ctx, hipMemsetAsync(G.fallback, 0, sizeof(int), ctx->stream));
   G.cap_c = cap_c; G.cap_d = cap_d; G.cap_h = cap_h;
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
@@ -413,7 +439,11 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
     if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
 #undef LAUNCH
   }
+  // if a list overflowed the evaluation kernel did nothing; the fused kernel (forces.hip) then does the
+  // whole call.  It checks the same word and returns at once otherwise - no host round trip.
+  int rc = gh_grav_fused_launch(ctx, count, G.fallback);
   gh_phase_end(ctx, GH_T_SPH_FORCES);
+  if (rc) return rc;
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
