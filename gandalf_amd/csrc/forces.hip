@@ -552,7 +552,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
     // GH_GRAV_FUSED=1 (or leaves wider than the evaluation kernel handles) selects the single fused kernel
     const char *fused = getenv("GH_GRAV_FUSED");
-    if (!(fused && fused[0] == '1') && ctx->leafocc <= 8) return gh_grav_lists_impl(ctx, count);
+    if (!(fused && fused[0] == '1') && ctx->leafocc <= 6) return gh_grav_lists_impl(ctx, count);
   }
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
   gh_phase_begin(ctx, GH_T_SPH_FORCES);

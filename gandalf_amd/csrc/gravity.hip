@@ -23,8 +23,8 @@
 int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if);
 
 #define GH_MAXLEAF 16
-#define GH_MAXOCC 8          /* max particles per leaf handled by the evaluation kernel */
-#define GH_SPHCAP 640        /* SPH neighbours of one particle held in LDS (SURVEY: max 393 at 4k Plummer) */
+#define GH_MAXOCC 6          /* max particles per leaf handled by the evaluation kernel (Nleafmax default 6) */
+#define GH_SPHCAP 448        /* SPH neighbours of one particle held in LDS (SURVEY: max 393 at 4k Plummer) */
 
 struct GravLists {
   int *cells, *dirl;         // [gtot][cap_*]: node ids / (first | N << 27) leaf entries
@@ -203,8 +203,28 @@ __device__ __forceinline__ double wave_sum_d(double v)
   return v;
 }
 
+struct PMAcc { double at[3], gpot; };              // point-mass partial sums of one target particle
+
+template <int ND>
+__device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, double x, double y, double z, double m)
+{
+#pragma clang fp contract(fast)
+  double dr[3] = {0.0, 0.0, 0.0};
+  dr[0] = x - ti.r[0];
+  if (ND > 1) dr[1] = y - ti.r[1];
+  if (ND > 2) dr[2] = z - ti.r[2];
+  double drsqd = dr[0]*dr[0];
+  if (ND > 1) drsqd += dr[1]*dr[1];
+  if (ND > 2) drsqd += dr[2]*dr[2];
+  drsqd += GH_SMALL;
+  const double invdrmag = fast_rsqrt(drsqd);
+  const double minvdr3 = m*(invdrmag*invdrmag*invdrmag);
+  A.gpot += m*invdrmag;
+  for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
+}
+
 template <int ND, bool COUNT>
-__global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
                                                    unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
@@ -237,29 +257,32 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
   const int2 *hydl = G.hydl + (size_t) gl*G.cap_h;
 
   // per-lane partial sums of the point-mass terms, one set per target particle
-  Accum acc[GH_MAXOCC];
+  PMAcc acc[GH_MAXOCC];
 #pragma unroll
-  for (int i = 0; i < GH_MAXOCC; i++) { for (int k = 0; k < 3; k++) { acc[i].a[k] = 0.0; acc[i].at[k] = 0.0; } acc[i].dudt = 0.0; acc[i].div_v = 0.0; acc[i].gpot = 0.0; }
+  for (int i = 0; i < GH_MAXOCC; i++) { for (int k = 0; k < 3; k++) acc[i].at[k] = 0.0; acc[i].gpot = 0.0; }
   unsigned long long n_cells = 0, n_direct = 0, n_pairs = 0;
 
   // ---- accepted cells: monopole terms                            (NeighbourSearch.h:350-377)
+  // two-level gather (node id from the list, then the 32-byte COM record from the L2-resident table):
+  // ids run two chunks ahead, records one chunk ahead of the arithmetic
   {
-    auto cload = [&](int c0, double4 &v) {
-      const int e = c0 + lane;
+    auto idload = [&](int c0) -> int { const int e = c0 + lane; return e < lenc ? cells[e] : -1; };
+    auto recload = [&](int id, double4 &v) {
       v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
-      if (e < lenc) { const CellCom c = d.ccom[cells[e]]; v.x = c.com[0]; v.y = c.com[1]; v.z = c.com[2]; v.w = c.m; }
+      if (id >= 0) { const double4 *c = (const double4*) &d.ccom[id]; v = *c; }
     };
     auto ccomp = [&](const double4 &v) {
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
     };
-    double4 va, vb;
-    if (lenc > 0) cload(0, va);
-    for (int c0 = 0; c0 < lenc; c0 += 128) {
-      cload(c0 + 64, vb);
-      ccomp(va);
-      cload(c0 + 128, va);
-      if (c0 + 64 < lenc) ccomp(vb);
+    int id1 = idload(0), id2 = idload(64);
+    double4 vcur, vnext;
+    recload(id1, vcur);
+    for (int c0 = 0; c0 < lenc; c0 += 64) {
+      const int id3 = idload(c0 + 128);
+      recload(id2, vnext);
+      ccomp(vcur);
+      vcur = vnext; id2 = id3;
     }
     if (COUNT) n_cells += (unsigned long long) lenc*Nt;       // counted once per wave below
   }
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(64) void k_grav_eval(DevicePtrs d, ForceParams P, G
       double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
       if (k < pn) v = d.posm[pf + k];
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
       if (COUNT) n_direct += (k < pn) ? Nt : 0;
     }
   }
