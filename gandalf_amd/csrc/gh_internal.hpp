@@ -103,6 +103,7 @@ struct gh_ctx {
   // gravity interaction lists in HBM (gravity.hip)
   int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr;
   size_t glist_leaves = 0;
+  int glist_caps = 0;
 
   // statistics / timers
   unsigned long long *d_stats = nullptr;   // device counters

@@ -19,6 +19,7 @@
 //                 classified per (particle, candidate); the real SPH neighbours of each particle are
 //                 compacted (ballot) into an LDS list and evaluated 64 pairs at a time.
 #include "force_common.hpp"
+#include <cstdlib>
 
 int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if);
 
@@ -423,9 +424,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
-  const int cap_c = 4096, cap_d = 256, cap_h = 1024;
+  int cap_c = 4096, cap_d = 256, cap_h = 1024;
+  if (const char *e = getenv("GH_GRAV_CAPS")) {       // test hook: tiny capacities force the overflow fallback
+    int a = 0, b = 0, c = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { cap_c = a; cap_d = b; cap_h = c; }
+  }
   const size_t nleaf = (size_t) ctx->gtot;
-  if (ctx->glist_leaves != nleaf) {
+  if (ctx->glist_leaves != nleaf || ctx->glist_caps != cap_c + 7*cap_d + 31*cap_h) {
     for (void *p : {(void*) ctx->gl_cells, (void*) ctx->gl_dirl, (void*) ctx->gl_hydl, (void*) ctx->gl_len}) if (p) (void) hipFree(p);
     ctx->gl_cells = ctx->gl_dirl = ctx->gl_hydl = ctx->gl_len = nullptr;
     ctx->glist_leaves = 0;
@@ -434,6 +439,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_hydl, sizeof(int2)*nleaf*cap_h));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_len, sizeof(int)*(nleaf*3 + 4)));
     ctx->glist_leaves = nleaf;
+    ctx->glist_caps = cap_c + 7*cap_d + 31*cap_h;
   }
   GravLists G;
   G.cells = ctx->gl_cells; G.dirl = ctx->gl_dirl; G.hydl = (int2*) ctx->gl_hydl; G.len = ctx->gl_len;

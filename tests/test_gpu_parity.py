@@ -137,3 +137,19 @@ def test_steps_match_reference(case):
     assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
     assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
     assert relerr(sim.download("u"), g["final_u"]) < 1e-10
+
+
+def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):
+    """with absurdly small interaction-list capacities the walk flags an overflow on the device, the
+    evaluation kernel steps aside and the fused kernel redoes the call: same forces"""
+    monkeypatch.setenv("GH_GRAV_CAPS", "16,4,8")
+    g = load_golden("plummer_4k_passes")
+    sim, _ = make("plummer_4k")
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.build_tree()
+    sim.update_density()
+    sim.zero_accelerations()
+    st = sim.update_all_forces(stats=True)
+    assert st["n_cells"] > 0
+    assert vec_err(sim.download("a"), g["force_a"]) < 1e-11
+    assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
