@@ -134,7 +134,13 @@ def main():
                 "avg_launch_ms": ms}
 
     r_d = roof("k_density", dens_bytes, dens_ms)
-    r_f = roof("k_grav_forces" if int(sim.get_param("self_gravity")) else "k_hydro_forces", f_bytes, forc_ms)
+    grav = int(sim.get_param("self_gravity"))
+    r_f = roof("k_grav_eval (interaction lists from k_grav_walk)" if grav else "k_hydro_forces", f_bytes, forc_ms)
+    if grav:
+        r_f["walk_ms"] = timers.get("GRAV_WALK", 0.0)/args.steps
+        r_f["note"] = ("algorithmic bytes are counted per (particle, list entry) interaction (SURVEY 8d); the kernel "
+                       "evaluates every loaded entry against the 4-6 particles of a leaf, so the model rate may exceed "
+                       "the HBM peak - real HBM traffic is in profiles/")
     dominant = r_f if forc_ms >= dens_ms else r_d
 
     if rank == 0:

@@ -6,7 +6,7 @@ import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgandalf_hip.so")
 
-GH_T_NAMES = ["BUILD_TREE", "SPH_PROPERTIES", "SPH_FORCES", "KDK"]
+GH_T_NAMES = ["BUILD_TREE", "SPH_PROPERTIES", "SPH_FORCES", "KDK", "GRAV_WALK"]
 
 FIELDS = {name: i for i, name in enumerate(
     ["r", "v", "a", "atree", "r0", "v0", "a0",
@@ -317,7 +317,7 @@ class GandalfHip:
         return offs, ids[:offs[n]]
 
     def timers(self):
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * len(GH_T_NAMES))()
         d, f = Stats(), Stats()
         self._chk(self.lib.gh_get_timers(self.ctx, ms, C.byref(d), C.byref(f)))
         return dict(zip(GH_T_NAMES, list(ms))), d.as_dict(), f.as_dict()

@@ -151,7 +151,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -585,17 +585,21 @@ extern "C" int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *co
 // ------------------------------------------------------------------------------------------------
 // multi-GPU: slices, exchange sets, step sections
 // ------------------------------------------------------------------------------------------------
+void gh_derive_after_unpack(gh_ctx *ctx, int set, int64_t first, int64_t count);
+
 static int exchange_list(gh_ctx *ctx, int set, int *out)
 {
   int n = 0;
   if (set == GH_X_DENSITY) {
-    const int l[] = {D_H, D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD, D_U, D_SOUND, D_PRESSURE, D_DIV_V};
+    // hfactor, hrangesqd, u, sound, pressure, div_v are functions of these four (and of u, which the
+    // density pass only rewrites for a non-adiabatic EOS): the receiver recomputes them (k_derive_density)
+    const int l[] = {D_H, D_RHO, D_INVOMEGA, D_ZETA};
     for (int v : l) out[n++] = v;
   }
   else if (set == GH_X_FORCES) {
     for (int k = 0; k < ctx->ndim; k++) out[n++] = D_AX + k;
     for (int k = 0; k < ctx->ndim; k++) out[n++] = D_ATX + k;
-    const int l[] = {D_GPOT, D_GPOT_HYDRO, D_DUDT, D_DIV_V};
+    const int l[] = {D_GPOT, D_DUDT, D_DIV_V};            // gpot_hydro = gpot without stars: copied locally
     for (int v : l) out[n++] = v;
   }
   return n;
@@ -624,6 +628,7 @@ static int shard_copy(gh_ctx *ctx, int set, int rank, void *buf, int64_t stride,
     if (pack) GH_CHECK(ctx, hipMemcpyAsync(b + (size_t) a*stride, fld, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
     else GH_CHECK(ctx, hipMemcpyAsync(fld, b + (size_t) a*stride, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
   }
+  if (!pack) gh_derive_after_unpack(ctx, set, first, count);
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
 }

@@ -308,3 +308,48 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: the fields of a received slice that are pure functions of (h, rho, u) - same expressions
+// as the end of k_density, so the values are bit-identical to the owner's
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ void k_derive_density(DevicePtrs d, EosParams eos, int first, int count)
+{
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const int i = first + t;
+  typedef M4<ND> K;
+  const double h = d.f[D_H][i], rho = d.f[D_RHO][i];
+  double u = d.f[D_U][i];
+  const double invh1 = 1.0/h;
+  double sound, press;
+  eos_eval(eos, rho, u, sound, press);
+  d.f[D_HFACTOR][i] = powN<ND>(invh1)*invh1;
+  d.f[D_HRANGESQD][i] = K::kernrangesqd*h*h;
+  d.f[D_DIV_V][i] = 0.0;
+  d.f[D_U][i] = u;
+  d.f[D_SOUND][i] = sound;
+  d.f[D_PRESSURE][i] = press;
+}
+
+__global__ void k_copy_gpot_hydro(DevicePtrs d, int first, int count)
+{
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  if (t < count) d.f[D_GPOT_HYDRO][first + t] = d.f[D_GPOT][first + t];
+}
+
+void gh_derive_after_unpack(gh_ctx *ctx, int set, int64_t first, int64_t count)
+{
+  if (count <= 0) return;
+  DevicePtrs d = gh_dev(ctx);
+  const int nb = cdiv(count, 256);
+  if (set == GH_X_DENSITY) {
+    EosParams e;
+    gh_fill_eos(ctx, e);
+    if (ctx->ndim == 1) hipLaunchKernelGGL(k_derive_density<1>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
+    else if (ctx->ndim == 2) hipLaunchKernelGGL(k_derive_density<2>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
+    else hipLaunchKernelGGL(k_derive_density<3>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
+  }
+  else hipLaunchKernelGGL(k_copy_gpot_hydro, dim3(nb), dim3(256), 0, ctx->stream, d, (int) first, (int) count);
+}

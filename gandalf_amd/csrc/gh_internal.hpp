@@ -101,7 +101,7 @@ struct gh_ctx {
   bool tree_valid = false;
 
   // gravity interaction lists in HBM (gravity.hip)
-  int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr;
+  int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr, *gl_gcells = nullptr, *gl_glen = nullptr;
   size_t glist_leaves = 0;
   int glist_caps = 0;
 

@@ -29,10 +29,12 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if);
 
 struct GravLists {
   int *cells, *dirl;         // [gtot][cap_*]: node ids / (first | N << 27) leaf entries
+  int *gcells;               // [ngroups][cap_g]: cells accepted by EVERY leaf of a group (stored once)
+  int *glen;                 // [ngroups]
   int2 *hydl;                // [gtot][cap_h]: (first, count) particle ranges - a leaf, or a whole subtree
   int *len;                  // [gtot][3]
   int *fallback;             // set when a list overflowed: the fused kernel redoes the call
-  int cap_c, cap_d, cap_h;
+  int cap_c, cap_d, cap_h, cap_g;
 };
 
 // ================================================================================================
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
   for (int l = 0; l < GH_MAXLEAF; l++) { len_c[l] = 0; len_d[l] = 0; len_h[l] = 0; }
   if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
   __syncthreads();
-  int top = 1;
+  int top = 1, len_g = 0;
   bool overflow = false;
   while (top > 0) {
     const int p = pop_width(top);
@@ -135,6 +137,15 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
         }
       }
     }
+    // cells that every (non-empty) leaf of the group accepts go once into the group's shared list
+    const bool gfull = cellm != 0 && cellm == allmask;
+    const unsigned long long gm = __ballot(gfull);
+    if (gm) {
+      const int pos = len_g + __popcll(gm & lt);
+      if (gfull) { if (pos < G.cap_g) G.gcells[(size_t) q*G.cap_g + pos] = n; else overflow = true; }
+      len_g += __popcll(gm);
+    }
+    if (gfull) cellm = 0;
     const unsigned long long om = __ballot(openm != 0);
     const bool anycell = __any(cellm != 0), anynear = __any((hydm | dirm) != 0);
     __syncthreads();
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
     __syncthreads();
   }
   if (__any(overflow) && lane == 0) atomicOr(G.fallback, 1);
+  if (lane == 0) G.glen[q] = min(len_g, G.cap_g);
   if (lane == 0) {
 #pragma unroll
     for (int l = 0; l < GH_MAXLEAF; l++) {
@@ -255,6 +267,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   __syncthreads();
   const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = G.len[(size_t) gl*3 + 2];
   const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d;
+  const int nlg = 1 << (d.ltot - d.lgroup);
+  const int grp = gl/nlg;
+  const int leng = G.glen[grp];
+  const int *gcells = G.gcells + (size_t) grp*G.cap_g;
   const int2 *hydl = G.hydl + (size_t) gl*G.cap_h;
 
   // per-lane partial sums of the point-mass terms, one set per target particle
@@ -267,7 +283,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   // two-level gather (node id from the list, then the 32-byte COM record from the L2-resident table):
   // ids run two chunks ahead, records one chunk ahead of the arithmetic
   {
-    auto idload = [&](int c0) -> int { const int e = c0 + lane; return e < lenc ? cells[e] : -1; };
+    // entries [0, leng) come from the group's shared list, [leng, leng + lenc) from the leaf's own
+    const int ltot_ = leng + lenc;
+    auto idload = [&](int c0) -> int { const int e = c0 + lane; return e < leng ? gcells[e] : (e < ltot_ ? cells[e - leng] : -1); };
     auto recload = [&](int id, double4 &v) {
       v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
       if (id >= 0) { const double4 *c = (const double4*) &d.ccom[id]; v = *c; }
@@ -279,13 +297,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     int id1 = idload(0), id2 = idload(64);
     double4 vcur, vnext;
     recload(id1, vcur);
-    for (int c0 = 0; c0 < lenc; c0 += 64) {
+    for (int c0 = 0; c0 < ltot_; c0 += 64) {
       const int id3 = idload(c0 + 128);
       recload(id2, vnext);
       ccomp(vcur);
       vcur = vnext; id2 = id3;
     }
-    if (COUNT) n_cells += (unsigned long long) lenc*Nt;       // counted once per wave below
+    if (COUNT) n_cells += (unsigned long long) ltot_*Nt;      // counted once per wave below
   }
   // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
   for (int c0 = 0; c0 < lend; c0 += 64) {
@@ -425,6 +443,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
   int cap_c = 4096, cap_d = 256, cap_h = 1024;
+  const int cap_g = 4096;
   if (const char *e = getenv("GH_GRAV_CAPS")) {       // test hook: tiny capacities force the overflow fallback
     int a = 0, b = 0, c = 0;
     if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { cap_c = a; cap_d = b; cap_h = c; }
@@ -438,6 +457,10 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_dirl, sizeof(int)*nleaf*cap_d));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_hydl, sizeof(int2)*nleaf*cap_h));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_len, sizeof(int)*(nleaf*3 + 4)));
+    if (ctx->gl_gcells) (void) hipFree(ctx->gl_gcells);
+    if (ctx->gl_glen) (void) hipFree(ctx->gl_glen);
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_gcells, sizeof(int)*(size_t) ctx->ngroups*cap_g));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->gl_glen, sizeof(int)*(size_t) ctx->ngroups));
     ctx->glist_leaves = nleaf;
     ctx->glist_caps = cap_c + 7*cap_d + 31*cap_h;
   }
@@ -445,7 +468,8 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   G.cells = ctx->gl_cells; G.dirl = ctx->gl_dirl; G.hydl = (int2*) ctx->gl_hydl; G.len = ctx->gl_len;
   G.fallback = ctx->gl_len + nleaf*3;
   GH_CHECK(ctx, hipMemsetAsync(G.fallback, 0, sizeof(int), ctx->stream));
-  G.cap_c = cap_c; G.cap_d = cap_d; G.cap_h = cap_h;
+  G.cap_c = cap_c; G.cap_d = cap_d; G.cap_h = cap_h; G.cap_g = cap_g;
+  G.gcells = ctx->gl_gcells; G.glen = ctx->gl_glen;
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
   gh_fill_domain(ctx, P.dom);
@@ -459,10 +483,16 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   const int nl = 1 << (ctx->ltot - ctx->lgroup);
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
+  gh_phase_begin(ctx, GH_T_GRAV_WALK);
+  if (ngroups > 0) {
+#define LAUNCH(ND_) hipLaunchKernelGGL((k_grav_walk<ND_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
+    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#undef LAUNCH
+  }
+  gh_phase_end(ctx, GH_T_GRAV_WALK);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (ngroups > 0) {
 #define LAUNCH(ND_)                                                                                            \
-    hipLaunchKernelGGL((k_grav_walk<ND_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);                \
     if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     else hipLaunchKernelGGL((k_grav_eval<ND_, false>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags);
     if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }

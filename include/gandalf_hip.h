@@ -180,7 +180,9 @@ int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep);
 int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, int32_t *ids);
 /* device time (ms) spent in each phase since the last call to gh_reset_timers, reference block
  * names (CodeTiming: BUILD_TREE, SPH_PROPERTIES, SPH_HYDRO_FORCES / SPH_ALL_FORCES, KDK) */
-enum { GH_T_BUILD_TREE = 0, GH_T_SPH_PROPERTIES, GH_T_SPH_FORCES, GH_T_KDK, GH_T_COUNT };
+enum { GH_T_BUILD_TREE = 0, GH_T_SPH_PROPERTIES, GH_T_SPH_FORCES, GH_T_KDK,
+       GH_T_GRAV_WALK /* interaction-list walk of the self-gravity pass; GH_T_SPH_FORCES is then the evaluation */,
+       GH_T_COUNT };
 int gh_get_timers(gh_ctx *ctx, double *ms /* [GH_T_COUNT] */, gh_stats *density, gh_stats *forces);
 int gh_reset_timers(gh_ctx *ctx);
 
@@ -192,8 +194,9 @@ int gh_set_shard(gh_ctx *ctx, int rank, int nranks);
 /* particle range [first, first+count) (tree order) owned by a rank after the last gh_build_tree */
 int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count);
 /* exchange sets: the per-particle outputs a rank produces for its own slice in one phase.
- * GH_X_DENSITY: h rho invomega zeta hfactor hrangesqd u sound pressure div_v   (10 arrays)
- * GH_X_FORCES : a[ndim] atree[ndim] gpot gpot_hydro dudt div_v                 (4 + 2 ndim arrays) */
+ * GH_X_DENSITY: h rho invomega zeta (4 arrays; hfactor, hrangesqd, u, sound, pressure, div_v are
+ *               recomputed by the receiver from these)
+ * GH_X_FORCES : a[ndim] atree[ndim] gpot dudt div_v   (3 + 2 ndim arrays; gpot_hydro = gpot) */
 enum { GH_X_DENSITY = 0, GH_X_FORCES = 1 };
 int gh_exchange_narrays(gh_ctx *ctx, int set);
 /* copy this rank's slice of every array of `set` into dst_dev[a*stride .. ) (device memory, doubles),
