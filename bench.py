@@ -127,11 +127,21 @@ def main():
     dens_ms = dst["kernel_ms"]
     forc_ms = fst["kernel_ms"]
 
+    # HBM bytes per launch measured with PMC counters in a separate rocprofv3 pass (profiles/pmc_traffic.json);
+    # only valid for the single-GPU workload it was collected on
+    pmc = {}
+    try:
+        if world == 1:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get(args.workload, {})
+    except OSError:
+        pass
+
     def roof(name, nbytes, ms):
         gbs = nbytes/(ms*1e-3)/1e9 if ms > 0 else 0.0
         return {"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs/HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": nbytes,
-                "avg_launch_ms": ms}
+                "frac": gbs/HBM_PEAK_GBS, "traffic": pmc.get(name.split(" ")[0]),
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
 
     r_d = roof("k_density", dens_bytes, dens_ms)
     grav = int(sim.get_param("self_gravity"))

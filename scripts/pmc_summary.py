@@ -17,4 +17,6 @@ for name in sorted(acc):
     print(name)
     for c in sorted(acc[name]):
         v = acc[name][c]
-        print("   %-28s n=%d mean=%.6g" % (c, len(v), sum(v)/len(v)))
+        vs = sorted(v)
+        print("   %-28s n=%d mean=%.6g median=%.6g min=%.6g max=%.6g" %
+              (c, len(v), sum(v)/len(v), vs[len(vs)//2], vs[0], vs[-1]))
