@@ -119,6 +119,11 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");
   GH_CHECK(ctx, hipSetDevice(cfg->device));
   GH_CHECK(ctx, hipStreamCreate(&ctx->stream));
+  for (int i = 0; i < 2; i++) {
+    GH_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+    GH_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+  }
+  GH_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->redbuf, sizeof(double)*(256*6 + 8)));
   GH_CHECK(ctx, hipMemset(ctx->redbuf, 0, sizeof(double)*(256*6 + 8)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_stats, sizeof(unsigned long long)*ST_TOTAL));
@@ -144,6 +149,7 @@ static void free_particles(gh_ctx *ctx)
   void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
+  ctx->iota_N = -1;
 }
 
 extern "C" void gh_destroy(gh_ctx *ctx)
@@ -156,6 +162,8 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
   for (auto &p : ctx->ev_free) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+  for (int i = 0; i < 2; i++) { if (ctx->aux[i]) (void) hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void) hipEventDestroy(ctx->ev_join[i]); }
+  if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
   if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -185,7 +193,7 @@ int gh_alloc_particles(gh_ctx *ctx, int64_t N)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->posm, sizeof(double4)*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->hrec, sizeof(double4)*4*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->side, n));
-  GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*n));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*3*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortvals, sizeof(int)*n));
   {
     // permute tables: [0] = gather buffer 0 -> 1, [1] = gather buffer 1 -> 0 (src pointers then dst pointers)

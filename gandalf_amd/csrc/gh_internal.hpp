@@ -96,7 +96,10 @@ struct gh_ctx {
   unsigned int *Wpre[3] = {};      // exclusive prefix of popcounts
   double *sortkeys = nullptr, *sortkeys_out = nullptr;
   int *sortvals = nullptr;
-  void *sorttemp = nullptr; size_t sorttemp_bytes = 0;
+  void *sorttemp = nullptr; size_t sorttemp_bytes = 0;   // 3 slabs (one per axis: the argsorts run on 3 streams)
+  hipStream_t aux[2] = {}; hipEvent_t ev_fork = nullptr, ev_join[2] = {};
+  int iota_N = -1;
+  int lsub = 0;                    // first level built by the LDS-resident subtree kernel
   double *redbuf = nullptr;        // reduction scratch
   bool tree_valid = false;
 

@@ -29,13 +29,14 @@ static const double BIG = 9.9e20;   // reference Constants.h:72 big_number
 // ------------------------------------------------------------------------------------------------
 // root box: min/max over particles of r -/+ kernrange*h           (KDTree.cpp:269-280)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */)
+__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */, int *cellnode0)
 {
   __shared__ double s[6][256];
   double mn[3] = {BIG, BIG, BIG}, mx[3] = {-BIG, -BIG, -BIG};
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
+    cellnode0[i] = 0;                  // every particle starts in the root cell
     const double hr = kernrange*d.f[D_H][i];
-    for (int k = 0; k < d.ndim; k++) {
+    _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
       const double x = d.f[D_RX + k][i];
       mx[k] = fmax(mx[k], x + hr);
       mn[k] = fmin(mn[k], x - hr);
@@ -56,12 +57,14 @@ __global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /*
 
 __global__ void k_rootbox_final(const double *part, int nblk, double *dbbmin, double *dbbmax)
 {
-  const int k = threadIdx.x;
-  if (k >= 3) return;
-  double mn = BIG, mx = -BIG;
-  for (int b = 0; b < nblk; b++) { mn = fmin(mn, part[b*6 + k]); mx = fmax(mx, part[b*6 + 3 + k]); }
-  dbbmin[k] = mn;
-  dbbmax[k] = mx;
+  // one wave: lanes stride over the block partials, then a shuffle reduction per component
+  const int lane = threadIdx.x;
+  for (int k = 0; k < 3; k++) {
+    double mn = BIG, mx = -BIG;
+    for (int b = lane; b < nblk; b += 64) { mn = fmin(mn, part[b*6 + k]); mx = fmax(mx, part[b*6 + 3 + k]); }
+    for (int off = 32; off > 0; off >>= 1) { mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64)); }
+    if (lane == 0) { dbbmin[k] = mn; dbbmax[k] = mx; }
+  }
 }
 
 __global__ void k_iota(int *v, int n)
@@ -91,41 +94,36 @@ struct LevelArgs {
   int level, nwords;
 };
 
-__global__ void k_divide_cells(DevicePtrs d, LevelArgs a)
-{
-  const int j = blockIdx.x*blockDim.x + threadIdx.x;
-  if (j >= (1 << a.level)) return;
-  const int n = (1 << a.level) - 1 + j;
-  const int first = d.cfirst[n], cnt = d.cN[n];
-  double rkmax = 0.0;
-  int kd = 0;
-  for (int k = 0; k < d.ndim; k++) {
-    const double ext = a.dbbmax[n*3 + k] - a.dbbmin[n*3 + k];
-    if (ext > rkmax) { rkmax = ext; kd = k; }
-  }
-  double rdiv = a.dbbmin[n*3 + kd];
-  if (cnt > 0) rdiv = d.f[D_RX + kd][a.P[kd][first + cnt/2]];
-  const int c1 = 2*n + 1, c2 = 2*n + 2;
-  for (int k = 0; k < 3; k++) {
-    a.dbbmin[c1*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c1*3 + k] = a.dbbmax[n*3 + k];
-    a.dbbmin[c2*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c2*3 + k] = a.dbbmax[n*3 + k];
-  }
-  a.dbbmax[c1*3 + kd] = rdiv;
-  a.dbbmin[c2*3 + kd] = rdiv;
-  a.kdiv[n] = kd;
-}
-
-// level step 2: mark every particle left (0) / right (1) from its cell's split-axis list
+// level steps 1+2: split axis + median + children's inherited boxes (KDTree.cpp:490-533) and the left (0) /
+// right (1) mark of every particle, taken from its cell's split-axis list
 __global__ void k_mark_side(DevicePtrs d, LevelArgs a)
 {
   const int p = blockIdx.x*blockDim.x + threadIdx.x;
   if (p >= d.N) return;
   const int n = a.cellnode[p];
-  const int first = d.cfirst[n], half = d.cN[n]/2;
-  const int kd = a.kdiv[n];
+  const int first = d.cfirst[n], cnt = d.cN[n], half = cnt/2;
+  // split axis = longest side of the inherited box (every particle of the cell recomputes it: 6 cached loads)
+  double bmin[3], bmax[3];
+  double rkmax = 0.0;
+  int kd = 0;
+  for (int k = 0; k < 3; k++) { bmin[k] = a.dbbmin[n*3 + k]; bmax[k] = a.dbbmax[n*3 + k]; }
+  _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
+    const double ext = bmax[k] - bmin[k];
+    if (ext > rkmax) { rkmax = ext; kd = k; }
+  }
   const int right = (p - first >= half) ? 1 : 0;
   a.side[a.P[kd][p]] = (unsigned char) right;
   a.cellnode_next[p] = 2*n + 1 + right;
+  if (p == first) {
+    // the cell's first particle also writes the children's inherited boxes (median = first of the right half)
+    const double rdiv = d.f[D_RX + kd][a.P[kd][first + half]];
+    const int c1 = 2*n + 1, c2 = 2*n + 2;
+    for (int k = 0; k < 3; k++) {
+      a.dbbmin[c1*3 + k] = bmin[k]; a.dbbmax[c1*3 + k] = (k == kd) ? rdiv : bmax[k];
+      a.dbbmin[c2*3 + k] = (k == kd) ? rdiv : bmin[k]; a.dbbmax[c2*3 + k] = bmax[k];
+    }
+    a.kdiv[n] = kd;
+  }
 }
 
 // level step 3: one 64-bit word of "is left" flags per wave per axis, plus the count of left flags of
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(256) void k_ballot_words(DevicePtrs d, LevelArgs a)
 {
   __shared__ unsigned int s_cnt[3][4];
   const int p = blockIdx.x*blockDim.x + threadIdx.x;
-  for (int k = 0; k < d.ndim; k++) {
+  _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     const int flag = (p < d.N) ? (a.side[a.P[k][p]] == 0) : 0;
     const unsigned long long w = __ballot(flag);
     if ((threadIdx.x & 63) == 0) {
@@ -193,13 +191,120 @@ __global__ void k_partition(DevicePtrs d, LevelArgs a)
   if (p >= d.N) return;
   const int n = a.cellnode[p];
   const int first = d.cfirst[n], half = d.cN[n]/2;
-  for (int k = 0; k < d.ndim; k++) {
+  _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     const int id = a.P[k][p];
     const int right = a.side[id];
     const int nleft_before = (int) (rank_left(a.W[k], a.Wpre[k], p) - rank_left(a.W[k], a.Wpre[k], first));
     const int np = right ? first + half + ((p - first) - nleft_before) : first + nleft_before;
     a.Pn[k][np] = id;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Levels >= L0 (cells of <= GH_SEG particles): the whole subtree below one level-L0 cell is built by ONE
+// workgroup with the three presorted lists held in LDS as 16-bit local indices - the same
+// divide / mark / ballot / prefix / stable-partition sequence as the level kernels above, with barriers in
+// place of launches.  Cuts ~5 launches per level off the (launch-bound) lower half of the build.
+// ------------------------------------------------------------------------------------------------
+#define GH_SEG 2048
+__global__ __launch_bounds__(1024) void k_build_subtree(DevicePtrs d, LevelArgs a, int L0, int ltot, int *perm_out, int *inv)
+{
+  __shared__ unsigned short s_L[2][3][GH_SEG];
+  __shared__ int s_gid[GH_SEG];
+  __shared__ unsigned short s_cnode[2][GH_SEG];
+  __shared__ unsigned char s_side[GH_SEG];
+  __shared__ unsigned long long s_W[3][GH_SEG/64];
+  __shared__ unsigned int s_pre[3][GH_SEG/64 + 1];
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x;
+  const int n0 = (1 << L0) - 1 + j0;
+  const int first0 = d.cfirst[n0], cnt = d.cN[n0];
+  const int ndim = d.ndim;
+  for (int i = tid; i < cnt; i += 1024) {
+    const int g = a.P[0][first0 + i];
+    s_gid[i] = g;
+    inv[g] = i;
+    s_L[0][0][i] = (unsigned short) i;
+    s_cnode[0][i] = 0;
+  }
+  __syncthreads();
+  for (int k = 1; k < ndim; k++)
+    for (int i = tid; i < cnt; i += 1024) s_L[0][k][i] = (unsigned short) inv[a.P[k][first0 + i]];
+  __syncthreads();
+  int cur = 0;
+  const int nw = (cnt + 63) >> 6;
+  for (int l = L0; l < ltot; l++) {
+    const int sh = l - L0;
+    const int nbase = (1 << l) - 1 + (j0 << sh);
+    // divide the cells of this level (KDTree.cpp:490-533)
+    for (int t = tid; t < (1 << sh); t += 1024) {
+      const int n = nbase + t;
+      const int first = d.cfirst[n], c = d.cN[n];
+      double rkmax = 0.0;
+      int kd = 0;
+      for (int k = 0; k < ndim; k++) {
+        const double ext = a.dbbmax[n*3 + k] - a.dbbmin[n*3 + k];
+        if (ext > rkmax) { rkmax = ext; kd = k; }
+      }
+      double rdiv = a.dbbmin[n*3 + kd];
+      if (c > 0) rdiv = d.f[D_RX + kd][s_gid[s_L[cur][kd][first - first0 + c/2]]];
+      const int c1 = 2*n + 1, c2 = 2*n + 2;
+      for (int k = 0; k < 3; k++) {
+        a.dbbmin[c1*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c1*3 + k] = a.dbbmax[n*3 + k];
+        a.dbbmin[c2*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c2*3 + k] = a.dbbmax[n*3 + k];
+      }
+      a.dbbmax[c1*3 + kd] = rdiv;
+      a.dbbmin[c2*3 + kd] = rdiv;
+      a.kdiv[n] = kd;
+    }
+    __syncthreads();
+    // mark left / right from the split-axis list
+    for (int p = tid; p < cnt; p += 1024) {
+      const int jl = s_cnode[cur][p];
+      const int n = nbase + jl;
+      const int lf = d.cfirst[n] - first0, half = d.cN[n]/2;
+      const int right = (p - lf >= half) ? 1 : 0;
+      s_side[s_L[cur][a.kdiv[n]][p]] = (unsigned char) right;
+      s_cnode[cur ^ 1][p] = (unsigned short) (2*jl + right);
+    }
+    __syncthreads();
+    for (int k = 0; k < ndim; k++)
+      for (int pb = 0; pb < nw*64; pb += 1024) {
+        const int p = pb + tid;
+        if (p < nw*64) {        // whole waves take this branch together (nw*64 is a multiple of 64)
+          const int flag = (p < cnt) ? (s_side[s_L[cur][k][p]] == 0) : 0;
+          const unsigned long long w = __ballot(flag);
+          if ((tid & 63) == 0) s_W[k][p >> 6] = w;
+        }
+      }
+    __syncthreads();
+    if (tid < 64*ndim) {
+      const int k = tid >> 6, lane = tid & 63;
+      const unsigned int c = lane < nw ? (unsigned int) __popcll(s_W[k][lane]) : 0u;
+      unsigned int inc = c;
+      for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+      if (lane < nw) s_pre[k][lane] = inc - c;
+    }
+    __syncthreads();
+    for (int p = tid; p < cnt; p += 1024) {
+      const int n = nbase + s_cnode[cur][p];
+      const int lf = d.cfirst[n] - first0, half = d.cN[n]/2;
+      for (int k = 0; k < ndim; k++) {
+        const unsigned short id = s_L[cur][k][p];
+        const int right = s_side[id];
+        const int bp = p & 63, bf = lf & 63;
+        const unsigned int rp = s_pre[k][p >> 6] + (bp ? __popcll(s_W[k][p >> 6] & ((1ull << bp) - 1ull)) : 0);
+        const unsigned int rf = s_pre[k][lf >> 6] + (bf ? __popcll(s_W[k][lf >> 6] & ((1ull << bf) - 1ull)) : 0);
+        const int nleft = (int) (rp - rf);
+        const int np = right ? lf + half + ((p - lf) - nleft) : lf + nleft;
+        s_L[cur ^ 1][k][np] = id;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int i = tid; i < cnt; i += 1024) perm_out[first0 + i] = s_gid[s_L[cur][0][i]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -237,7 +342,7 @@ __global__ void k_pack_posm(DevicePtrs d)
 __device__ __forceinline__ void finish_cell(const DevicePtrs &d, const CellBox &b, CellGeo &g, double hmax, double thetamaxsqd)
 {
   double dr2 = 0.0;
-  for (int k = 0; k < d.ndim; k++) {
+  _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     g.rcell[k] = 0.5*(b.bbmin[k] + b.bbmax[k]);
     const double dr = 0.5*(b.bbmax[k] - b.bbmin[k]);
     dr2 += dr*dr;
@@ -246,12 +351,31 @@ __device__ __forceinline__ void finish_cell(const DevicePtrs &d, const CellBox &
   g.rmax = sqrt(dr2);
 }
 
-// hmax_only = 1 restates KDTree::UpdateHmaxValues: only hmax and hbox are refreshed
-__global__ void k_stock_leaves(DevicePtrs d, double kernrange, double thetamaxsqd, int hmax_only)
+// what a parent needs of a child (held in LDS between the levels of one fused launch)
+struct SRec {
+  double hbmin[3], hbmax[3], hmax;
+  double bbmin[3], bbmax[3];
+  double com[3], m;
+  int N, pad;
+};
+
+__device__ __forceinline__ void srec_load(const DevicePtrs &d, int c, int hmax_only, SRec &r)
 {
-  const int g = blockIdx.x*blockDim.x + threadIdx.x;
-  if (g >= d.gtot) return;
-  const int n = d.gtot - 1 + g;
+  const CellH h = d.ch[c];
+  for (int k = 0; k < 3; k++) { r.hbmin[k] = h.hbmin[k]; r.hbmax[k] = h.hbmax[k]; }
+  r.hmax = h.hmax;
+  r.N = d.cN[c];
+  if (hmax_only) return;
+  const CellBox b = d.cbox[c];
+  const CellCom m = d.ccom[c];
+  for (int k = 0; k < 3; k++) { r.bbmin[k] = b.bbmin[k]; r.bbmax[k] = b.bbmax[k]; r.com[k] = m.com[k]; }
+  r.m = m.m;
+}
+
+// leaf cell from its particles (StockCellProperties KDTree.cpp:808-930); hmax_only = 1 restates
+// KDTree::UpdateHmaxValues: only hmax and hbox are refreshed
+__device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double kernrange, double thetamaxsqd, int hmax_only, SRec &o)
+{
   const int first = d.cfirst[n], cnt = d.cN[n];
   CellH hh;
   hh.hmax = 0.0; hh.pad = 0.0;
@@ -267,7 +391,7 @@ __global__ void k_stock_leaves(DevicePtrs d, double kernrange, double thetamaxsq
     hh.hmax = fmax(hh.hmax, h);
     const double m = d.f[D_M][i];
     if (!hmax_only) cm.m += m;
-    for (int k = 0; k < d.ndim; k++) {
+    _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
       const double x = d.f[D_RX + k][i];
       if (!hmax_only) {
         cm.com[k] += m*x;
@@ -280,60 +404,120 @@ __global__ void k_stock_leaves(DevicePtrs d, double kernrange, double thetamaxsq
   }
   d.ch[n] = hh;
   if (!hmax_only) {
-    if (cm.m > 0) for (int k = 0; k < d.ndim; k++) cm.com[k] /= cm.m;
+    if (cm.m > 0) _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) cm.com[k] /= cm.m;
     if (cnt > 0) finish_cell(d, b, c, hh.hmax, thetamaxsqd);
     c.hmax = hh.hmax;
     d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
   }
   else d.cgeo[n].hmax = hh.hmax;
+  for (int k = 0; k < 3; k++) { o.hbmin[k] = hh.hbmin[k]; o.hbmax[k] = hh.hbmax[k]; }
+  o.hmax = hh.hmax; o.N = cnt;
+  if (!hmax_only) {
+    for (int k = 0; k < 3; k++) { o.bbmin[k] = b.bbmin[k]; o.bbmax[k] = b.bbmax[k]; o.com[k] = cm.com[k]; }
+    o.m = cm.m;
+  }
 }
 
-__device__ __forceinline__ void stock_internal(const DevicePtrs &d, int n, double thetamaxsqd, int hmax_only)
+// parent n from its two children (StockCellProperties, KDTree.cpp:931-1083; UpdateHmaxValues :1170-1200);
+// writes the parent's global records and returns what the next level up needs
+__device__ __forceinline__ void stock_combine(const DevicePtrs &d, int n, const SRec &r1, const SRec &r2, SRec &o,
+                                              double thetamaxsqd, int hmax_only)
 {
-  const int c1 = 2*n + 1, c2 = 2*n + 2;
-  const int N1 = d.cN[c1], N2 = d.cN[c2];
   CellH hh;
   hh.hmax = 0.0; hh.pad = 0.0;
   for (int k = 0; k < 3; k++) { hh.hbmin[k] = BIG; hh.hbmax[k] = -BIG; }
-  const CellH h1 = d.ch[c1], h2 = d.ch[c2];
-  if (N1 > 0) {
-    for (int k = 0; k < d.ndim; k++) { hh.hbmin[k] = fmin(h1.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(h1.hbmax[k], hh.hbmax[k]); }
-    hh.hmax = fmax(hh.hmax, h1.hmax);
+  if (r1.N > 0) {
+    _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) { hh.hbmin[k] = fmin(r1.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(r1.hbmax[k], hh.hbmax[k]); }
+    hh.hmax = fmax(hh.hmax, r1.hmax);
   }
-  if (N2 > 0) {
-    for (int k = 0; k < d.ndim; k++) { hh.hbmin[k] = fmin(h2.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(h2.hbmax[k], hh.hbmax[k]); }
-    hh.hmax = fmax(hh.hmax, h2.hmax);
+  if (r2.N > 0) {
+    _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) { hh.hbmin[k] = fmin(r2.hbmin[k], hh.hbmin[k]); hh.hbmax[k] = fmax(r2.hbmax[k], hh.hbmax[k]); }
+    hh.hmax = fmax(hh.hmax, r2.hmax);
   }
   d.ch[n] = hh;
+  for (int k = 0; k < 3; k++) { o.hbmin[k] = hh.hbmin[k]; o.hbmax[k] = hh.hbmax[k]; }
+  o.hmax = hh.hmax;
+  o.N = d.cN[n];
   if (hmax_only) { d.cgeo[n].hmax = hh.hmax; return; }
   CellBox b; CellGeo c; CellCom cm;
   cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.pad = 0.0; b.pad = 0.0;
   for (int k = 0; k < 3; k++) { cm.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
-  c.first = d.cfirst[n]; c.N = d.cN[n]; b.first = c.first; b.N = c.N;
-  const CellBox b1 = d.cbox[c1], b2 = d.cbox[c2];
-  const CellCom m1 = d.ccom[c1], m2 = d.ccom[c2];
-  if (N1 > 0) for (int k = 0; k < d.ndim; k++) { b.bbmin[k] = fmin(b1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b1.bbmax[k], b.bbmax[k]); }
-  if (N2 > 0) for (int k = 0; k < d.ndim; k++) { b.bbmin[k] = fmin(b2.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(b2.bbmax[k], b.bbmax[k]); }
-  cm.m = m1.m + m2.m;
-  if (cm.m > 0) for (int k = 0; k < d.ndim; k++) cm.com[k] = (m1.m*m1.com[k] + m2.m*m2.com[k])/cm.m;
+  c.first = d.cfirst[n]; c.N = o.N; b.first = c.first; b.N = c.N;
+  if (r1.N > 0) _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) { b.bbmin[k] = fmin(r1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(r1.bbmax[k], b.bbmax[k]); }
+  if (r2.N > 0) _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) { b.bbmin[k] = fmin(r2.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(r2.bbmax[k], b.bbmax[k]); }
+  cm.m = r1.m + r2.m;
+  if (cm.m > 0) _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) cm.com[k] = (r1.m*r1.com[k] + r2.m*r2.com[k])/cm.m;
   if (c.N > 0) finish_cell(d, b, c, hh.hmax, thetamaxsqd);
   c.hmax = hh.hmax;
   d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
+  for (int k = 0; k < 3; k++) { o.bbmin[k] = b.bbmin[k]; o.bbmax[k] = b.bbmax[k]; o.com[k] = cm.com[k]; }
+  o.m = cm.m;
 }
 
 __global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only)
 {
   const int j = blockIdx.x*blockDim.x + threadIdx.x;
   if (j >= (1 << level)) return;
-  stock_internal(d, (1 << level) - 1 + j, thetamaxsqd, hmax_only);
+  const int n = (1 << level) - 1 + j;
+  SRec r1, r2, o;
+  srec_load(d, 2*n + 1, hmax_only, r1);
+  srec_load(d, 2*n + 2, hmax_only, r2);
+  stock_combine(d, n, r1, r2, o, thetamaxsqd, hmax_only);
 }
 
-// levels ltop .. 0 in one launch of one workgroup (<= 1023 cells): the top of the tree is launch-latency,
-// not bandwidth
-__global__ void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only)
+// Leaves plus the nlev levels above them in one launch: a workgroup owns the 2^nlev leaves below one cell of
+// level ltot-nlev and passes child records between levels through LDS (a barrier per level instead of a launch).
+#define GH_STOCK_NLEV 8
+__global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs d, double kernrange, double thetamaxsqd,
+                                                                      int hmax_only, int nlev)
 {
+  __shared__ SRec s_a[1 << GH_STOCK_NLEV];
+  __shared__ SRec s_b[1 << (GH_STOCK_NLEV - 1)];
+  const int t = threadIdx.x;
+  if (t < (1 << nlev)) {
+    const int g = (blockIdx.x << nlev) + t;
+    const int n = d.gtot - 1 + g;
+    SRec r;
+    stock_leaf(d, n, kernrange, thetamaxsqd, hmax_only, r);
+    s_a[t] = r;
+  }
+  SRec *src = s_a, *dst = s_b;
+  for (int s = 1; s <= nlev; s++) {
+    __syncthreads();
+    const int level = d.ltot - s;
+    if (t < (1 << (nlev - s))) {
+      const int n = (1 << level) - 1 + (blockIdx.x << (nlev - s)) + t;
+      SRec o;
+      stock_combine(d, n, src[2*t], src[2*t + 1], o, thetamaxsqd, hmax_only);
+      dst[t] = o;
+    }
+    SRec *tmp = src; src = dst; dst = tmp;
+  }
+}
+
+// levels ltop .. 0 in one launch of one workgroup: the top of the tree is latency, not bandwidth.  Levels
+// wider than 256 cells hand their results on through global memory, the rest through LDS.
+__global__ __launch_bounds__(1024) void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only)
+{
+  __shared__ SRec s_a[256];
+  __shared__ SRec s_b[128];
+  SRec *src = s_a, *dst = s_b;
+  bool in_lds = false;
   for (int level = ltop; level >= 0; level--) {
-    for (int j = threadIdx.x; j < (1 << level); j += blockDim.x) stock_internal(d, (1 << level) - 1 + j, thetamaxsqd, hmax_only);
+    const int nc = 1 << level;
+    const bool out_lds = nc <= 256;
+    SRec *o_buf = in_lds ? dst : s_a;
+    for (int j = threadIdx.x; j < nc; j += blockDim.x) {
+      const int n = nc - 1 + j;
+      SRec r1, r2, o;
+      if (in_lds) { r1 = src[2*j]; r2 = src[2*j + 1]; }
+      else { srec_load(d, 2*n + 1, hmax_only, r1); srec_load(d, 2*n + 2, hmax_only, r2); }
+      stock_combine(d, n, r1, r2, o, thetamaxsqd, hmax_only);
+      if (out_lds) o_buf[j] = o;
+    }
+    if (in_lds) { SRec *tmp = src; src = dst; dst = tmp; }
+    else if (out_lds) { src = s_a; dst = s_b; }
+    in_lds = out_lds;
     __threadfence_block();
     __syncthreads();
   }
@@ -379,6 +563,14 @@ int gh_alloc_tree(gh_ctx *ctx)
   while (G < ltot && occ*(2 << G) <= GH_WAVE) G++;
   ctx->lgroup = ltot - G;
   ctx->ngroups = 1 << ctx->lgroup;
+  // first level whose cells all fit the LDS-resident subtree kernel
+  int lsub = 0;
+  for (; lsub < ltot; lsub++) {
+    int mx = 0;
+    for (int j = 0; j < (1 << lsub); j++) mx = std::max(mx, ctx->h_cN[(1 << lsub) - 1 + j]);
+    if (mx <= GH_SEG) break;
+  }
+  ctx->lsub = lsub;
 
   auto re = [&](void **p, size_t bytes) -> hipError_t { if (*p) (void) hipFree(*p); *p = nullptr; return hipMalloc(p, bytes); };
   GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
@@ -412,14 +604,16 @@ static int stock_tree(gh_ctx *ctx, int hmax_only)
 {
   DevicePtrs d = gh_dev(ctx);
   const double kr = KERNRANGE_OF(ctx->cfg);
-  hipLaunchKernelGGL(k_stock_leaves, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, d, kr,
-                     ctx->cfg.thetamaxsqd, hmax_only);
-  const int ltop = std::min(ctx->ltot - 1, 9);
-  for (int l = ctx->ltot - 1; l > ltop; l--)
+  const int nlev = std::min(ctx->ltot, GH_STOCK_NLEV);
+  hipLaunchKernelGGL(k_stock_bottom, dim3(ctx->gtot >> nlev), dim3(1 << GH_STOCK_NLEV), 0, ctx->stream, d, kr,
+                     ctx->cfg.thetamaxsqd, hmax_only, nlev);
+  const int lnext = ctx->ltot - nlev - 1;        // highest level not stocked yet
+  const int ltop = std::min(lnext, 9);
+  for (int l = lnext; l > ltop; l--)
     hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << l, 256)), dim3(256), 0, ctx->stream, d, l,
                        ctx->cfg.thetamaxsqd, hmax_only);
   if (ltop >= 0)
-    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(512), 0, ctx->stream, d, ltop, ctx->cfg.thetamaxsqd, hmax_only);
+    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, d, ltop, ctx->cfg.thetamaxsqd, hmax_only);
   return GH_OK;
 }
 
@@ -437,39 +631,60 @@ int gh_tree_build_impl(gh_ctx *ctx)
 
   // root box
   const int nblk = 256;
-  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, s, d, kr, ctx->redbuf);
+  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, s, d, kr, ctx->redbuf, ctx->cellnode[0]);
   hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, s, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
 
-  // one argsort per axis
-  for (int k = 0; k < ctx->ndim; k++) {
+  // one argsort per axis, on three streams (each sort is ~30 small launches: they overlap)
+  if (ctx->iota_N != N) {             // identity values for the argsorts: never modified
     hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, s, ctx->sortvals, N);
+    ctx->iota_N = N;
+  }
+  {
     size_t need = 0;
-    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX + k], ctx->sortkeys_out, ctx->sortvals,
-                                            ctx->P[0][k], (size_t) N, 0, 64, s));
-    if (need > ctx->sorttemp_bytes) {
+    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX], ctx->sortkeys_out, ctx->sortvals,
+                                            ctx->P[0][0], (size_t) N, 0, 64, s));
+    need = (need + 255) & ~(size_t) 255;
+    if (3*need > ctx->sorttemp_bytes) {
       GH_CHECK(ctx, hipStreamSynchronize(s));
       if (ctx->sorttemp) (void) hipFree(ctx->sorttemp);
-      GH_CHECK(ctx, hipMalloc(&ctx->sorttemp, need));
-      ctx->sorttemp_bytes = need;
+      GH_CHECK(ctx, hipMalloc(&ctx->sorttemp, 3*need));
+      ctx->sorttemp_bytes = 3*need;
     }
-    GH_CHECK(ctx, rocprim::radix_sort_pairs(ctx->sorttemp, ctx->sorttemp_bytes, d.f[D_RX + k], ctx->sortkeys_out,
-                                            ctx->sortvals, ctx->P[0][k], (size_t) N, 0, 64, s));
+    GH_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
+    for (int k = 0; k < ctx->ndim; k++) {
+      hipStream_t sk = k == 0 ? s : ctx->aux[k - 1];
+      if (k > 0) GH_CHECK(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
+      GH_CHECK(ctx, rocprim::radix_sort_pairs((char*) ctx->sorttemp + k*need, need, d.f[D_RX + k],
+                                              ctx->sortkeys_out + (size_t) k*N, ctx->sortvals, ctx->P[0][k], (size_t) N, 0, 64, sk));
+      if (k > 0) GH_CHECK(ctx, hipEventRecord(ctx->ev_join[k - 1], sk));
+    }
+    for (int k = 1; k < ctx->ndim; k++) GH_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
   }
-  hipLaunchKernelGGL(k_fill_int, dim3(nb), dim3(256), 0, s, ctx->cellnode[0], N, 0);
 
   int pb = 0;
   const int nwords = (N + 63)/64;
-  for (int l = 0; l < ctx->ltot; l++) {
+  auto level_args = [&](int l) {
     LevelArgs a;
     for (int k = 0; k < 3; k++) { a.P[k] = ctx->P[pb][k]; a.Pn[k] = ctx->P[pb ^ 1][k]; a.W[k] = ctx->W[k]; a.Wpre[k] = ctx->Wpre[k]; }
     a.cellnode = ctx->cellnode[pb]; a.cellnode_next = ctx->cellnode[pb ^ 1];
     a.side = ctx->side; a.dbbmin = ctx->dbbmin; a.dbbmax = ctx->dbbmax; a.kdiv = ctx->kdiv;
     a.level = l; a.nwords = nwords;
-    hipLaunchKernelGGL(k_divide_cells, dim3(cdiv(1 << l, 256)), dim3(256), 0, s, d, a);
+    return a;
+  };
+  const int lsub = ctx->lsub;
+  for (int l = 0; l < lsub; l++) {
+    LevelArgs a = level_args(l);
     hipLaunchKernelGGL(k_mark_side, dim3(nb), dim3(256), 0, s, d, a);
     hipLaunchKernelGGL(k_ballot_words, dim3(nb), dim3(256), 0, s, d, a);
     hipLaunchKernelGGL(k_scan_words, dim3(ctx->ndim), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_partition, dim3(nb), dim3(256), 0, s, d, a);
+    pb ^= 1;
+  }
+  {
+    // remaining levels: one workgroup per level-lsub cell (cellnode[pb^1] is free: used as id -> local index map)
+    LevelArgs a = level_args(lsub);
+    hipLaunchKernelGGL(k_build_subtree, dim3(1 << lsub), dim3(1024), 0, s, d, a, lsub, ctx->ltot, ctx->P[pb ^ 1][0],
+                       ctx->cellnode[pb ^ 1]);
     pb ^= 1;
   }
 
