@@ -151,6 +151,15 @@ __device__ __forceinline__ double fast_rsqrt(double x)
   return y;
 }
 
+// one Newton step: v_rsq_f64 is good to ~2^-26, one step gives ~2^-51 - far inside the 1e-11 force tolerance
+__device__ __forceinline__ double fast_rsqrt1(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y*(1.5 - (0.5*x)*y*y);
+  return y;
+}
+
 // far-field entry evaluation: a += m dr/(dr^2+eps)^(3/2), gpot += m/(dr^2+eps)^(1/2).  The reference
 // writes this once with 1/x and sqrt (cells, NeighbourSearch.h:364-372) and once with 1/sqrt(x) (direct
 // particles, GradhSph.cpp:675-681); both are evaluated here with one rsqrt (<= 2 ulp from either).

@@ -218,6 +218,37 @@ __device__ __forceinline__ double wave_sum_d(double v)
 
 struct PMAcc { double at[3], gpot; };              // point-mass partial sums of one target particle
 
+// ---- wave reduction of FOUR values at once with the gfx950 lane-swap instructions ----------------
+// v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of the second, so
+// "swap, then add the two results" halves the lanes of two values in 3 instructions with no select and no
+// LDS traffic; v_permlane16_swap does the same on 16-lane rows.  Four values end up one per row, then four
+// DPP row rotations finish the sum inside each row: 21 VALU instructions instead of 4 x 18 shuffles+adds.
+__device__ __forceinline__ double swap32_add(double a, double b)
+{
+  const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+  return __hiloint2double((int) r1[0], (int) r0[0]) + __hiloint2double((int) r1[1], (int) r0[1]);
+}
+__device__ __forceinline__ double swap16_add(double a, double b)
+{
+  const auto r0 = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+  return __hiloint2double((int) r1[0], (int) r0[0]) + __hiloint2double((int) r1[1], (int) r0[1]);
+}
+template <int N> __device__ __forceinline__ double row_ror_add(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+// returns, in every lane of row q (= lane >> 4), the wave sum of (v0, v2, v1, v3)[q]
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3)
+{
+  double e = swap16_add(swap32_add(v0, v1), swap32_add(v2, v3));
+  e = row_ror_add<8>(e); e = row_ror_add<4>(e); e = row_ror_add<2>(e); e = row_ror_add<1>(e);
+  return e;
+}
+
 template <int ND>
 __device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, double x, double y, double z, double m)
 {
@@ -230,7 +261,7 @@ __device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, doubl
   if (ND > 1) drsqd += dr[1]*dr[1];
   if (ND > 2) drsqd += dr[2]*dr[2];
   drsqd += GH_SMALL;
-  const double invdrmag = fast_rsqrt(drsqd);
+  const double invdrmag = fast_rsqrt1(drsqd);
   const double minvdr3 = m*(invdrmag*invdrmag*invdrmag);
   A.gpot += m*invdrmag;
   for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
@@ -285,37 +316,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   {
     // entries [0, leng) come from the group's shared list, [leng, leng + lenc) from the leaf's own
     const int ltot_ = leng + lenc;
-    auto idload = [&](int c0) -> int { const int e = c0 + lane; return e < leng ? gcells[e] : (e < ltot_ ? cells[e - leng] : -1); };
+    // all loads are unconditional (clamped index, mass zeroed afterwards): loads inside divergent branches
+    // make the compiler wait for vmcnt(0), which would also wait for the prefetches
+    auto idload = [&](int c0) -> int {
+      const int e = c0 + lane;
+      const bool ok = e < ltot_;
+      const int ec = ok ? e : ltot_ - 1;
+      const int *p = ec < leng ? gcells + ec : cells + (ec - leng);
+      const int id = *p;
+      return ok ? id : -1;
+    };
     auto recload = [&](int id, double4 &v) {
-      v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
-      if (id >= 0) { const double4 *c = (const double4*) &d.ccom[id]; v = *c; }
+      const double4 *c = (const double4*) &d.ccom[id < 0 ? 0 : id];
+      v = *c;
+      v.w = id < 0 ? 0.0 : v.w;
     };
     auto ccomp = [&](const double4 &v) {
 #pragma unroll
       for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
     };
-    int id1 = idload(0), id2 = idload(64);
-    double4 vcur, vnext;
-    recload(id1, vcur);
-    for (int c0 = 0; c0 < ltot_; c0 += 64) {
-      const int id3 = idload(c0 + 128);
-      recload(id2, vnext);
-      ccomp(vcur);
-      vcur = vnext; id2 = id3;
+    if (ltot_ > 0) {
+      int id1 = idload(0), id2 = idload(64);
+      double4 vcur, vnext;
+      recload(id1, vcur);
+      for (int c0 = 0; c0 < ltot_; c0 += 64) {
+        const int id3 = idload(c0 + 128);
+        recload(id2, vnext);
+        ccomp(vcur);
+        vcur = vnext; id2 = id3;
+      }
     }
     if (COUNT) n_cells += (unsigned long long) ltot_*Nt;      // counted once per wave below
   }
   // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
   for (int c0 = 0; c0 < lend; c0 += 64) {
     const int e = c0 + lane;
-    const int ent = e < lend ? dirl[e] : 0;
-    const int pf = ent & 0x7ffffff, pn = (ent >> 27) & 0xf;
-    for (int k = 0; k < occ; k++) {
-      double4 v; v.x = 1e30; v.y = 1e30; v.z = 1e30; v.w = 0.0;
-      if (k < pn) v = d.posm[pf + k];
+    const int ent = dirl[e < lend ? e : lend - 1];
+    const int pf = ent & 0x7ffffff, pn = e < lend ? ((ent >> 27) & 0xf) : 0;
+    // particle k of the entry's leaf; clamped unconditional loads, one ahead of the arithmetic
+    double4 v = d.posm[pf];
+    int kmax = pn;
+    for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
+    for (int k = 0; k < kmax; k++) {
+      const double4 vn = d.posm[pf + (k + 1 < pn ? k + 1 : 0)];
+      const double mk = k < pn ? v.w : 0.0;
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, mk);
       if (COUNT) n_direct += (k < pn) ? Nt : 0;
+      v = vn;
     }
   }
   // ---- leaves with hydro candidates: classify every (particle, candidate); direct ones at once, SPH
@@ -402,11 +450,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
       }
       if (COUNT) n_pairs += (unsigned long long) ns;
-      // reduce this particle's sums over the wave
-      double red[9];
-      for (int k = 0; k < 3; k++) { red[k] = wave_sum_d(A.a[k]); red[3 + k] = wave_sum_d(A.at[k] + acc[i].at[k]); }
-      red[6] = wave_sum_d(A.dudt); red[7] = wave_sum_d(A.div_v); red[8] = wave_sum_d(A.gpot + acc[i].gpot);
-      if (lane == 0) for (int k = 0; k < 9; k++) s_out[i][k] += red[k];
+      // reduce this particle's sums over the wave, four values per pass (rows hold values 0,2,1,3);
+      // the potential is reduced for all particles together after the loop
+      acc[i].gpot += A.gpot;
+      const double e0 = wave_sum4(A.a[0], A.a[1], A.a[2], A.dudt);
+      const double e1 = wave_sum4(A.at[0] + acc[i].at[0], A.at[1] + acc[i].at[1], A.at[2] + acc[i].at[2], A.div_v);
+      if ((lane & 15) == 0) {
+        const int q = lane >> 4;                       // row -> value: a0, a2, a1, dudt | at0, at2, at1, div_v
+        const int k0 = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 6));
+        const int k1 = q == 0 ? 3 : (q == 1 ? 5 : (q == 2 ? 4 : 7));
+        s_out[i][k0] += e0;
+        s_out[i][k1] += e1;
+      }
+    }
+  }
+  {
+    const double g0 = wave_sum4(acc[0].gpot, acc[1].gpot, acc[2].gpot, acc[3].gpot);
+    if ((lane & 15) == 0) { const int q = lane >> 4; const int t = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3)); if (t < Nt) s_out[t][8] += g0; }
+    if (GH_MAXOCC > 4 && Nt > 4) {
+      const double g1 = wave_sum4(acc[4].gpot, acc[GH_MAXOCC > 5 ? 5 : 4].gpot, 0.0, 0.0);
+      if (lane == 0) s_out[4][8] += g1;
+      if (lane == 32 && Nt > 5) s_out[5][8] += g1;
     }
   }
   __syncthreads();
