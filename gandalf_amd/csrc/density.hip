@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           if (ND > 2) r2 += dr[2]*dr[2];
           {
 #pragma clang fp contract(fast)
-            const double s = sqrt(invhsqd*r2);
+            const double s = gh_fast_sqrt(invhsqd*r2);
             rho += mj*K::w0(s);
             omg += mj*invh*K::womega(s);
             zet += mj*K::wzeta(s);

@@ -46,14 +46,17 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
   typedef M4<ND> K;
   double dr[3] = {dr_in[0], dr_in[1], dr_in[2]};
   double drmag;
+  // |dr| and 1/|dr| from one rsqrt (the reference: sqrt then a division, GradhSph.cpp:399-400, 517-518)
   if (GRAV) {
-    drmag = sqrt(r2 + GH_SMALL);
-    const double inv = 1.0/drmag;
+    const double x = r2 + GH_SMALL;
+    const double inv = fast_rsqrt(x);
+    drmag = x*inv;
     for (int k = 0; k < ND; k++) dr[k] *= inv;
   }
   else {
-    drmag = sqrt(r2);
-    if (drmag > 0.0) { const double inv = 1.0/drmag; for (int k = 0; k < ND; k++) dr[k] *= inv; }
+    const double inv = r2 > 0.0 ? fast_rsqrt(r2) : 0.0;
+    drmag = r2*inv;
+    for (int k = 0; k < ND; k++) dr[k] *= inv;
   }
   const double mj = nb.m;
   const double invh_j = nb.invh;
@@ -82,10 +85,12 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
   }
   for (int k = 0; k < ND; k++) A.a[k] += mj*dr[k]*paux;
   if (GRAV) {
-    const double pg = 0.5*(ti.invhsqd*K::wgrav(drmag*ti.invh) + ti.zeta*wkerni +
-                           invh_j*invh_j*K::wgrav(drmag*invh_j) + nb.zeta*wkernj);
+    const double si = drmag*ti.invh, sj = drmag*invh_j;
+    const double invsi = gh_fast_rcp(si), invsj = gh_fast_rcp(sj);
+    const double pg = 0.5*(ti.invhsqd*K::wgrav_i(si, invsi) + ti.zeta*wkerni +
+                           invh_j*invh_j*K::wgrav_i(sj, invsj) + nb.zeta*wkernj);
     for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*pg;
-    A.gpot += 0.5*mj*(ti.invh*K::wpot(drmag*ti.invh) + invh_j*K::wpot(drmag*invh_j));
+    A.gpot += 0.5*mj*(ti.invh*K::wpot_i(si, invsi) + invh_j*K::wpot_i(sj, invsj));
   }
 }
 
@@ -141,25 +146,6 @@ __device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (
 
 // 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps in FMA form; ends within
 // 1-2 ulp.  (ocml's rsqrt also handles denormals/inf/nan, which cannot occur here: x >= 1e-20.)
-__device__ __forceinline__ double fast_rsqrt(double x)
-{
-#pragma clang fp contract(fast)
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5*x;
-  y = y*(1.5 - hx*y*y);
-  y = y*(1.5 - hx*y*y);
-  return y;
-}
-
-// one Newton step: v_rsq_f64 is good to ~2^-26, one step gives ~2^-51 - far inside the 1e-11 force tolerance
-__device__ __forceinline__ double fast_rsqrt1(double x)
-{
-#pragma clang fp contract(fast)
-  double y = __builtin_amdgcn_rsq(x);
-  y = y*(1.5 - (0.5*x)*y*y);
-  return y;
-}
-
 // far-field entry evaluation: a += m dr/(dr^2+eps)^(3/2), gpot += m/(dr^2+eps)^(1/2).  The reference
 // writes this once with 1/x and sqrt (cells, NeighbourSearch.h:364-372) and once with 1/sqrt(x) (direct
 // particles, GradhSph.cpp:675-681); both are evaluated here with one rsqrt (<= 2 ulp from either).

@@ -267,16 +267,17 @@ __device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, doubl
   for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
 }
 
-template <int ND, bool COUNT>
+template <int ND, bool COUNT, int MAXOCC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
                                                    unsigned long long *stats, int *flags)
 {
   typedef M4<ND> K;
-  __shared__ TargetI s_tg[GH_MAXOCC];
-  __shared__ int s_sph[GH_MAXOCC][GH_SPHCAP];
+  constexpr int SPHCAP = MAXOCC <= 4 ? 416 : GH_SPHCAP;   // keeps 16 workgroups per CU inside 160 KB of LDS
+  __shared__ TargetI s_tg[MAXOCC];
+  __shared__ int s_sph[MAXOCC][SPHCAP];
   __shared__ RangeRing s_ring;
   __shared__ int s_pre[64];
-  __shared__ double s_out[GH_MAXOCC][10];             // a[3], at[3], dudt, div_v, gpot, spare
+  __shared__ double s_out[MAXOCC][10];             // a[3], at[3], dudt, div_v, gpot, spare
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
@@ -285,29 +286,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const int node = (d.gtot - 1) + gl;
   const int first = d.cfirst[node], Nt = d.cN[node];
   if (Nt == 0) return;
-  if (Nt > GH_MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
+  if (Nt > MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
   const int occ = d.leafocc;
 
-  if (lane < Nt) {
+  // slots >= Nt of a partly filled leaf hold a copy of particle 0: the point-mass loops then run unguarded
+  // over all MAXOCC slots (independent chains the scheduler can interleave); their sums are never stored
+  if (lane < MAXOCC) {
     TargetI t;
-    load_target(d, first + lane, ND, t);
+    load_target(d, first + (lane < Nt ? lane : 0), ND, t);
     s_tg[lane] = t;
+  }
+  if (lane < Nt) {
     for (int k = 0; k < 10; k++) s_out[lane][k] = 0.0;
     s_out[lane][8] = (d.f[D_M][first + lane]/d.f[D_H][first + lane])*K::wpot(0.0);    // self term, GradhSphTree.cpp:512
   }
   __syncthreads();
+#if defined(GH_DEBUG_SKIP_ALL)       /* timing experiments only: drop the point-mass and / or the SPH part */
+  const int lenc = 0, lend = 0, lenh = 0;
+#elif defined(GH_DEBUG_SKIP_PM)
+  const int lenc = 0, lend = 0, lenh = G.len[(size_t) gl*3 + 2];
+#elif defined(GH_DEBUG_SKIP_SPH)
+  const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = 0;
+#else
   const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = G.len[(size_t) gl*3 + 2];
+#endif
   const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d;
   const int nlg = 1 << (d.ltot - d.lgroup);
   const int grp = gl/nlg;
+#if defined(GH_DEBUG_SKIP_PM)
+  const int leng = 0;
+#else
   const int leng = G.glen[grp];
+#endif
   const int *gcells = G.gcells + (size_t) grp*G.cap_g;
   const int2 *hydl = G.hydl + (size_t) gl*G.cap_h;
 
   // per-lane partial sums of the point-mass terms, one set per target particle
-  PMAcc acc[GH_MAXOCC];
+  PMAcc acc[MAXOCC];
 #pragma unroll
-  for (int i = 0; i < GH_MAXOCC; i++) { for (int k = 0; k < 3; k++) acc[i].at[k] = 0.0; acc[i].gpot = 0.0; }
+  for (int i = 0; i < MAXOCC; i++) { for (int k = 0; k < 3; k++) acc[i].at[k] = 0.0; acc[i].gpot = 0.0; }
   unsigned long long n_cells = 0, n_direct = 0, n_pairs = 0;
 
   // ---- accepted cells: monopole terms                            (NeighbourSearch.h:350-377)
@@ -318,32 +335,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int ltot_ = leng + lenc;
     // all loads are unconditional (clamped index, mass zeroed afterwards): loads inside divergent branches
     // make the compiler wait for vmcnt(0), which would also wait for the prefetches
-    auto idload = [&](int c0) -> int {
+    auto idraw = [&](int c0) -> int {               // raw id of entry c0 + lane (clamped index)
       const int e = c0 + lane;
-      const bool ok = e < ltot_;
-      const int ec = ok ? e : ltot_ - 1;
+      const int ec = e < ltot_ ? e : ltot_ - 1;
       const int *p = ec < leng ? gcells + ec : cells + (ec - leng);
-      const int id = *p;
-      return ok ? id : -1;
+      return *p;
     };
-    auto recload = [&](int id, double4 &v) {
+    auto idfix = [&](int raw, int c0) -> int { return c0 + lane < ltot_ ? raw : -1; };
+    auto recload = [&](int id, double4 &v) {         // raw load; the caller zeroes the mass of id < 0 entries
       const double4 *c = (const double4*) &d.ccom[id < 0 ? 0 : id];
       v = *c;
-      v.w = id < 0 ? 0.0 : v.w;
     };
     auto ccomp = [&](const double4 &v) {
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
+      for (int i = 0; i < MAXOCC; i++) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
     };
     if (ltot_ > 0) {
-      int id1 = idload(0), id2 = idload(64);
+      int id1 = idfix(idraw(0), 0), id2 = idfix(idraw(64), 64);
       double4 vcur, vnext;
       recload(id1, vcur);
+      vcur.w = id1 < 0 ? 0.0 : vcur.w;
       for (int c0 = 0; c0 < ltot_; c0 += 64) {
-        const int id3 = idload(c0 + 128);
+        int id3 = idraw(c0 + 128);
         recload(id2, vnext);
+        __builtin_amdgcn_sched_barrier(0);        // keep the loads above the arithmetic they overlap with
         ccomp(vcur);
-        vcur = vnext; id2 = id3;
+        __builtin_amdgcn_sched_barrier(0);
+        // pin the prefetched record to this iteration: without it the optimiser moves the x/y/z load to the
+        // top of the next iteration (fewer live registers) and the L2 latency is back on the critical path
+        asm volatile("" : "+v"(vnext.x), "+v"(vnext.y), "+v"(vnext.z), "+v"(vnext.w), "+v"(id3));
+        vnext.w = id2 < 0 ? 0.0 : vnext.w;
+        vcur = vnext; id2 = idfix(id3, c0 + 128);
       }
     }
     if (COUNT) n_cells += (unsigned long long) ltot_*Nt;      // counted once per wave below
@@ -358,26 +380,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     int kmax = pn;
     for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off, 64));
     for (int k = 0; k < kmax; k++) {
-      const double4 vn = d.posm[pf + (k + 1 < pn ? k + 1 : 0)];
+      double4 vn = d.posm[pf + (k + 1 < pn ? k + 1 : 0)];
+      __builtin_amdgcn_sched_barrier(0);
       const double mk = k < pn ? v.w : 0.0;
 #pragma unroll
-      for (int i = 0; i < GH_MAXOCC; i++) if (i < Nt) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, mk);
+      for (int i = 0; i < MAXOCC; i++) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, mk);
       if (COUNT) n_direct += (k < pn) ? Nt : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(vn.x), "+v"(vn.y), "+v"(vn.z), "+v"(vn.w));
       v = vn;
     }
   }
   // ---- leaves with hydro candidates: classify every (particle, candidate); direct ones at once, SPH
   //      neighbours compacted per particle into LDS              (NeighbourManager.h:521-533)
-  int nsph[GH_MAXOCC];
+  int nsph[MAXOCC];
 #pragma unroll
-  for (int i = 0; i < GH_MAXOCC; i++) nsph[i] = 0;
+  for (int i = 0; i < MAXOCC; i++) nsph[i] = 0;
   bool overflow = false;
-  auto hyd_tile = [&](bool valid, int j, int) {
-    double4 q0; q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
-    double hr2 = 0.0;
-    if (valid) { const double4 *r = d.hrec + 4*(size_t) j; q0 = r[0]; hr2 = r[1].w; }
+  auto hyd_process = [&](bool valid, int j, const double4 &q0, double hr2) {
 #pragma unroll
-    for (int i = 0; i < GH_MAXOCC; i++) {
+    for (int i = 0; i < MAXOCC; i++) {
       if (i < Nt) {
         const TargetI &ti = s_tg[i];
         double dr[3] = {0.0, 0.0, 0.0};
@@ -391,13 +413,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         const unsigned long long sm = __ballot(sph);
         if (sm) {
           const int pos = nsph[i] + __popcll(sm & lt);
-          if (sph) { if (pos < GH_SPHCAP) s_sph[i][pos] = j; else overflow = true; }
+          if (sph) { if (pos < SPHCAP) s_sph[i][pos] = j; else overflow = true; }
           nsph[i] += __popcll(sm);
         }
         {
 #pragma clang fp contract(fast)
           const double mj = sph ? 0.0 : q0.w;
-          const double invdrmag = fast_rsqrt(r2 + GH_SMALL);
+          const double invdrmag = fast_rsqrt1(r2 + GH_SMALL);
           const double minvdr3 = mj*(invdrmag*invdrmag*invdrmag);
           for (int kk = 0; kk < ND; kk++) acc[i].at[kk] += dr[kk]*minvdr3;
           acc[i].gpot += mj*invdrmag;
@@ -405,6 +427,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (COUNT) n_direct += (valid && !sph) ? 1 : 0;
       }
     }
+  };
+  // one-chunk delay line: the records of chunk c+1 are requested before chunk c is evaluated, so the gather
+  // latency (one 128-byte line per candidate, L2/HBM) overlaps with arithmetic instead of stalling the wave
+  bool pend = false, p_valid = false;
+  int p_j = 0;
+  double4 p_q0; p_q0.x = 1e30; p_q0.y = 1e30; p_q0.z = 1e30; p_q0.w = 0.0;
+  double p_hr2 = 0.0;
+  auto hyd_tile = [&](bool valid, int j, int) {
+    const double4 *r = d.hrec + 4*(size_t) (valid ? j : 0);
+    double4 q0 = r[0];
+    double hr2 = r[1].w;
+    __builtin_amdgcn_sched_barrier(0);
+    if (pend) hyd_process(p_valid, p_j, p_q0, p_hr2);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(hr2));
+    if (!valid) { q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0; }
+    p_valid = valid; p_j = j; p_q0 = q0; p_hr2 = hr2; pend = true;
   };
   {
     RangeState R; R.nrb = 0; R.nslots = 0;
@@ -419,15 +458,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, hyd_tile);
     }
     range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, hyd_tile);
+    if (pend) hyd_process(p_valid, p_j, p_q0, p_hr2);
   }
-  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);      // > GH_SPHCAP neighbours of one particle
+  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);      // > SPHCAP neighbours of one particle
   __syncthreads();
   // ---- SPH pairs, 64 at a time per target particle               (GradhSph.cpp:474-585)
 #pragma unroll
-  for (int i = 0; i < GH_MAXOCC; i++) {
+  for (int i = 0; i < MAXOCC; i++) {
     if (i < Nt) {
       const TargetI ti = s_tg[i];
-      const int ns = min(nsph[i], GH_SPHCAP);
+#if defined(GH_DEBUG_SKIP_PAIRS)
+      const int ns = 0;
+#else
+      const int ns = min(nsph[i], SPHCAP);
+#endif
       Accum A;
       for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
       A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
@@ -465,10 +509,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
   }
   {
-    const double g0 = wave_sum4(acc[0].gpot, acc[1].gpot, acc[2].gpot, acc[3].gpot);
+    const double g0 = wave_sum4(acc[0].gpot, acc[MAXOCC > 1 ? 1 : 0].gpot, acc[MAXOCC > 2 ? 2 : 0].gpot, acc[MAXOCC > 3 ? 3 : 0].gpot);
     if ((lane & 15) == 0) { const int q = lane >> 4; const int t = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3)); if (t < Nt) s_out[t][8] += g0; }
-    if (GH_MAXOCC > 4 && Nt > 4) {
-      const double g1 = wave_sum4(acc[4].gpot, acc[GH_MAXOCC > 5 ? 5 : 4].gpot, 0.0, 0.0);
+    if (MAXOCC > 4 && Nt > 4) {
+      const double g1 = wave_sum4(acc[MAXOCC > 4 ? 4 : 0].gpot, acc[MAXOCC > 5 ? 5 : 0].gpot, 0.0, 0.0);
       if (lane == 0) s_out[4][8] += g1;
       if (lane == 32 && Nt > 5) s_out[5][8] += g1;
     }
@@ -557,8 +601,13 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (ngroups > 0) {
 #define LAUNCH(ND_)                                                                                            \
-    if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_grav_eval<ND_, false>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags);
+    if (ctx->leafocc <= 4) { \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+    } else { \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+    }
     if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
 #undef LAUNCH
   }

@@ -12,6 +12,48 @@
 #define GH_SMALL 1.0e-20               /* Constants.h:73 small_number */
 #define GH_SMALL_DP 1.0e-50            /* Constants.h:90 small_number_dp */
 
+// 1/x from v_rcp_f64 and two Newton steps (<= 1 ulp): used where the reference divides inside a pair loop
+__device__ __forceinline__ double gh_fast_rcp(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rcp(x);
+  y = y + y*(1.0 - x*y);
+  y = y + y*(1.0 - x*y);
+  return y;
+}
+
+// 1/sqrt(x): v_rsq_f64 (~2^-26) + Newton steps
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5*x;
+  y = y*(1.5 - hx*y*y);
+  y = y*(1.5 - hx*y*y);
+  return y;
+}
+
+// one Newton step: v_rsq_f64 is good to ~2^-26, one step gives ~2^-51 - far inside the 1e-11 force tolerance
+__device__ __forceinline__ double fast_rsqrt1(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y*(1.5 - (0.5*x)*y*y);
+  return y;
+}
+
+
+// sqrt(x) as x*rsqrt(x) with two Newton steps on the rsqrt (<= 2 ulp; IEEE sqrt costs ~4x as many instructions)
+__device__ __forceinline__ double gh_fast_sqrt(double x)
+{
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5*x;
+  y = y*(1.5 - hx*y*y);
+  y = y*(1.5 - hx*y*y);
+  return x > 0.0 ? x*y : 0.0;
+}
+
 template <int ND> struct M4 {
   static constexpr double kernrange = 2.0;
   static constexpr double kernrangesqd = 4.0;
@@ -59,6 +101,27 @@ template <int ND> struct M4 {
       return 2.6666666666666666667*s - 3.0*s2 + 1.2*(s2*s) - 0.166666666666666666667*(s2*s2) -
              0.06666666666666666667/s2;
     return 1.0/s2;
+  }
+  // wgrav / wpot with 1/s supplied by the caller (one reciprocal shared by both, no division in any branch)
+  __device__ static __forceinline__ double wgrav_i(double s, double invs)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, invs2 = invs*invs;
+    if (s < 1.0) return 1.333333333333333333333*s - 1.2*(s2*s) + 0.5*(s2*s2);
+    else if (s < 2.0)
+      return 2.6666666666666666667*s - 3.0*s2 + 1.2*(s2*s) - 0.166666666666666666667*(s2*s2) -
+             0.06666666666666666667*invs2;
+    return invs2;
+  }
+  __device__ static __forceinline__ double wpot_i(double s, double invs)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s;
+    if (s < 1.0) return 1.4 - 0.666666666666666666666666*s2 + 0.3*(s2*s2) - 0.1*(s2*s2*s);
+    else if (s < 2.0)
+      return -(1.0/15.0)*invs + 1.6 - 1.33333333333333333333333333*s2 + (s2*s) - 0.3*(s2*s2) +
+             (1.0/30.0)*(s2*s2*s);
+    return invs;
   }
   __device__ static __forceinline__ double wpot(double s)
   {
