@@ -85,6 +85,14 @@ SYMBOLS = {
     "gh_step_begin": (C.c_int, [_CTX]),
     "gh_step_forces": (C.c_int, [_CTX]),
     "gh_step_end": (C.c_int, [_CTX, _PD, _PD]),
+    "gh_nbody_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(_CTX)]),
+    "gh_nbody_destroy": (None, [_CTX]),
+    "gh_nbody_last_error": (C.c_char_p, [_CTX]),
+    "gh_nbody_upload": (C.c_int, [_CTX, C.c_int64, _PD, _PD, _PD, _PD]),
+    "gh_nbody_download": (C.c_int, [_CTX, C.c_int, _PD]),
+    "gh_nbody_forces": (C.c_int, [_CTX]),
+    "gh_nbody_setup": (C.c_int, [_CTX, _PD]),
+    "gh_nbody_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
 }
 
 _lib = None
@@ -360,3 +368,57 @@ class GandalfHip:
 
     def field_dev(self, name, k=0):
         return self.lib.gh_field_dev(self.ctx, FIELDS[name], k)
+
+
+class NbodyHip:
+    """Stars: direct-sum forces + leapfrog KDK on the GPU (gh_nbody_* of include/gandalf_hip.h)."""
+    FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4}
+
+    def __init__(self, ndim=3, softening=0, nbody_mult=0.1, device=0):
+        self.lib = load_library()
+        self.ndim = ndim
+        self.N = 0
+        ctx = _CTX()
+        rc = self.lib.gh_nbody_create(ndim, int(softening), float(nbody_mult), device, C.byref(ctx))
+        self.ctx = ctx
+        self._chk(rc)
+
+    def _chk(self, rc):
+        if rc < 0:
+            msg = self.lib.gh_nbody_last_error(self.ctx) if self.ctx else b"gh_nbody_create failed"
+            raise GhError(rc, (msg or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gh_nbody_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, r, v, m, h):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (r, v, m, h)]
+        self.N = len(a[2])
+        self._chk(self.lib.gh_nbody_upload(self.ctx, self.N, *[_dp(x) for x in a]))
+
+    def download(self, name):
+        out = np.empty(self.N if name == "gpot" else (self.N, self.ndim))
+        self._chk(self.lib.gh_nbody_download(self.ctx, self.FIELDS[name], _dp(out)))
+        return out
+
+    def forces(self):
+        self._chk(self.lib.gh_nbody_forces(self.ctx))
+
+    def setup(self):
+        dt = C.c_double()
+        self._chk(self.lib.gh_nbody_setup(self.ctx, C.byref(dt)))
+        return dt.value
+
+    def step(self, nsteps=1):
+        t, dt = C.c_double(), C.c_double()
+        self._chk(self.lib.gh_nbody_step(self.ctx, int(nsteps), C.byref(t), C.byref(dt)))
+        return t.value, dt.value

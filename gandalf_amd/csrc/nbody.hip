@@ -1,0 +1,347 @@
+// nbody.hip -- star-star direct summation and the stars' leapfrog KDK on the GPU.
+//
+// Replaces Nbody<ndim>::CalculateDirectGravForces (reference src/Nbody/Nbody.cpp:233-287),
+// NbodyLeapfrogKDK::CalculateDirectSmoothedGravForces (src/Nbody/NbodyLeapfrogKDK.cpp:78-142) and the
+// elementwise integrator members (:253-400).  All pairs, no tree: N is a few thousand at most in GANDALF
+// runs (sinks / stars), so the kernel is organised for latency, not bandwidth: a workgroup owns 64 target
+// stars and splits the source loop over its 4 wavefronts (lane = target, wave = source slice); source
+// tiles of 64 stars go through LDS (8 doubles per star) and are read as broadcasts.  Each lane sums its
+// slice in source order, the four slices are added through LDS.  Jerk (adot) is summed with the forces.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/gandalf_hip.h"
+#include "sph_kernels.hpp"
+
+#define NB_SMALL 1.0e-20
+#define NB_SMALL_DP 1.0e-50
+#define NB_BIG 9.9e20
+#define NB_TWOPI 6.28318530717959       /* reference Constants.h:62 */
+
+struct gh_nbody {
+  int ndim = 3, softening = 0, device = 0;
+  double nbody_mult = 0.1;
+  int64_t N = 0, Ncap = 0;
+  hipStream_t stream = nullptr;
+  // SoA, component-major: r[k*N + i]
+  double *r = nullptr, *v = nullptr, *a = nullptr, *adot = nullptr, *r0 = nullptr, *v0 = nullptr, *a0 = nullptr;
+  double *m = nullptr, *h = nullptr, *gpot = nullptr, *tlast = nullptr;
+  double *tdt = nullptr;            // device {t, timestep, scratch min}
+  double *red = nullptr;            // block minima
+  double *stage = nullptr;          // host<->device transposition buffer
+  std::string err;
+};
+
+#define NB_CHECK(nb, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (nb)->err = std::string(#call) + ": " + hipGetErrorString(e__); return GH_ERR_HIP; } } while (0)
+
+struct NbPtrs { double *r, *v, *a, *adot, *r0, *v0, *a0, *m, *h, *gpot, *tlast, *tdt; int N, ndim; };
+
+static NbPtrs nb_ptrs(gh_nbody *nb)
+{
+  NbPtrs p = {nb->r, nb->v, nb->a, nb->adot, nb->r0, nb->v0, nb->a0, nb->m, nb->h, nb->gpot, nb->tlast, nb->tdt, (int) nb->N, nb->ndim};
+  return p;
+}
+
+// powf(invhmean, ndim) as the reference evaluates it (NbodyLeapfrogKDK.cpp:118): single precision
+__device__ __forceinline__ double powf_ref(double x, int nd)
+{
+  const float xf = (float) x;
+  const double xd = (double) xf;
+  const float p = nd == 1 ? xf : (nd == 2 ? (float) (xd*xd) : (float) (xd*xd*xd));
+  return (double) p;
+}
+
+template <int ND, bool SOFT>
+__global__ __launch_bounds__(256) void k_nbody_forces(NbPtrs p)
+{
+  typedef M4<ND> K;
+  __shared__ double s_src[4][8][64];          // per wave: x,y,z,vx,vy,vz,m,h of a 64-star tile
+  __shared__ double s_acc[4][7][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x*64 + lane;
+  const bool live = i < p.N;
+  double ri[3] = {0, 0, 0}, vi[3] = {0, 0, 0}, hi = 1.0;
+  if (live) { for (int k = 0; k < ND; k++) { ri[k] = p.r[(size_t) k*p.N + i]; vi[k] = p.v[(size_t) k*p.N + i]; } hi = p.h[i]; }
+  double a[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, gp = 0.0;
+  const int ntile = (p.N + 63)/64;
+  // wave w takes a contiguous quarter of the tiles, so that every partial sum runs in source order
+  const int per = (ntile + 3)/4;
+  const int t0 = wave*per, t1 = min(ntile, t0 + per);
+  for (int t = t0; t < t1; t++) {
+    const int j = t*64 + lane;
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 1.0};
+    if (j < p.N) {
+      for (int k = 0; k < ND; k++) { q[k] = p.r[(size_t) k*p.N + j]; q[3 + k] = p.v[(size_t) k*p.N + j]; }
+      q[6] = p.m[j]; q[7] = p.h[j];
+    }
+    for (int c = 0; c < 8; c++) s_src[wave][c][lane] = q[c];
+    // a wave only reads its own tile: no workgroup barrier needed (LDS operations of one wave are in order)
+    const int cnt = min(64, p.N - t*64);
+    for (int jj = 0; jj < cnt; jj++) {
+      if (t*64 + jj == i) continue;                                            // i == j
+      double dr[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+      for (int k = 0; k < ND; k++) { dr[k] = s_src[wave][k][jj] - ri[k]; dv[k] = s_src[wave][3 + k][jj] - vi[k]; }
+      const double mj = s_src[wave][6][jj];
+      double drsqd = dr[0]*dr[0];
+      if (ND > 1) drsqd += dr[1]*dr[1];
+      if (ND > 2) drsqd += dr[2]*dr[2];
+      double dvdr = dv[0]*dr[0];
+      if (ND > 1) dvdr += dv[1]*dr[1];
+      if (ND > 2) dvdr += dv[2]*dr[2];
+      if (!SOFT) {                                                             // Nbody.cpp:264-272
+        const double invdrmag = 1.0/sqrt(drsqd);
+        const double drdt = dvdr*invdrmag;
+        const double inv3 = invdrmag*invdrmag*invdrmag;
+        gp += mj*invdrmag;
+        for (int k = 0; k < ND; k++) a[k] += mj*dr[k]*inv3;
+        for (int k = 0; k < ND; k++) ad[k] += mj*inv3*(dv[k] - 3.0*drdt*invdrmag*dr[k]);
+      }
+      else {                                                                   // NbodyLeapfrogKDK.cpp:111-126
+        const double hj = s_src[wave][7][jj];
+        const double drmag = sqrt(drsqd) + NB_SMALL;
+        const double invdrmag = 1.0/drmag;
+        const double invhmean = 2.0/(hi + hj);
+        const double drdt = dvdr*invdrmag;
+        const double paux = mj*invhmean*invhmean*K::wgrav(drmag*invhmean)*invdrmag;
+        const double wmean = K::w0(drmag*invhmean)*powf_ref(invhmean, ND);
+        gp += mj*invhmean*K::wpot(drmag*invhmean);
+        for (int k = 0; k < ND; k++) a[k] += paux*dr[k];
+        for (int k = 0; k < ND; k++)
+          ad[k] += paux*dv[k] - 3.0*paux*drdt*invdrmag*dr[k] + 2.0*NB_TWOPI*mj*drdt*wmean*invdrmag*dr[k];
+      }
+    }
+  }
+  for (int k = 0; k < 3; k++) { s_acc[wave][k][lane] = a[k]; s_acc[wave][3 + k][lane] = ad[k]; }
+  s_acc[wave][6][lane] = gp;
+  __syncthreads();
+  if (wave == 0 && live) {
+    for (int k = 0; k < ND; k++) {
+      p.a[(size_t) k*p.N + i] = ((s_acc[0][k][lane] + s_acc[1][k][lane]) + s_acc[2][k][lane]) + s_acc[3][k][lane];
+      p.adot[(size_t) k*p.N + i] = ((s_acc[0][3 + k][lane] + s_acc[1][3 + k][lane]) + s_acc[2][3 + k][lane]) + s_acc[3][3 + k][lane];
+    }
+    p.gpot[i] = ((s_acc[0][6][lane] + s_acc[1][6][lane]) + s_acc[2][6][lane]) + s_acc[3][6][lane];
+  }
+}
+
+// t += timestep, then NbodyLeapfrogKDK::AdvanceParticles (:253-291)
+__global__ void k_nbody_advance(NbPtrs p, int first_thread_advances_clock)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  const double t = p.tdt[0] + p.tdt[1];
+  if (i < p.N) {
+    const double dt = t - p.tlast[i];
+    for (int k = 0; k < p.ndim; k++) {
+      const size_t o = (size_t) k*p.N + i;
+      p.r[o] = p.r0[o] + p.v0[o]*dt + 0.5*p.a0[o]*dt*dt;
+      p.v[o] = p.v0[o] + p.a0[o]*dt;
+    }
+  }
+}
+__global__ void k_nbody_clock(NbPtrs p) { p.tdt[0] = p.tdt[0] + p.tdt[1]; }
+
+// CorrectionTerms (:301-331) and the per-star timestep (:387-400) with a block min
+__global__ __launch_bounds__(256) void k_nbody_correct_dt(NbPtrs p, double nbody_mult, double *red, int correct)
+{
+  __shared__ double s_min[256];
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  double ts = 9.9e50;
+  if (i < p.N) {
+    double amag2 = 0.0;
+    for (int k = 0; k < p.ndim; k++) {
+      const size_t o = (size_t) k*p.N + i;
+      const double ak = p.a[o];
+      if (correct) p.v[o] += 0.5*(ak - p.a0[o])*(p.tdt[0] - p.tlast[i]);
+      amag2 += ak*ak;
+    }
+    const double amag = sqrt(amag2);
+    ts = nbody_mult*sqrt(p.h[i]/(amag + NB_SMALL_DP));
+    ts = fmin(ts, NB_BIG);                                  // dt_internal = big_number without sub-systems
+  }
+  s_min[threadIdx.x] = ts;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int) threadIdx.x < off) s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) red[blockIdx.x] = s_min[0];
+}
+
+// min over blocks -> timestep, then EndTimestep (:341-377)
+__global__ __launch_bounds__(256) void k_nbody_end(NbPtrs p, const double *red, int nblk)
+{
+  __shared__ double s_min[256];
+  double mn = 9.9e50;
+  for (int b = threadIdx.x; b < nblk; b += 256) mn = fmin(mn, red[b]);
+  s_min[threadIdx.x] = mn;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int) threadIdx.x < off) s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const double t = p.tdt[0];
+  for (int i = blockIdx.x*256 + threadIdx.x; i < p.N; i += gridDim.x*256) {
+    for (int k = 0; k < p.ndim; k++) {
+      const size_t o = (size_t) k*p.N + i;
+      p.r0[o] = p.r[o]; p.v0[o] = p.v[o]; p.a0[o] = p.a[o];
+    }
+    p.tlast[i] = t;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.tdt[2] = s_min[0];      // published as the timestep by k_nbody_publish
+}
+__global__ void k_nbody_publish(NbPtrs p) { p.tdt[1] = p.tdt[2]; }
+
+static void nb_free(gh_nbody *nb)
+{
+  double **ptrs[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->red, &nb->stage};
+  for (double **q : ptrs) { if (*q) (void) hipFree(*q); *q = nullptr; }
+  nb->Ncap = 0;
+}
+
+extern "C" int gh_nbody_create(int ndim, int softening, double nbody_mult, int device, gh_nbody **out)
+{
+  if (!out) return GH_ERR_INVALID;
+  *out = nullptr;
+  if (ndim < 1 || ndim > 3) return GH_ERR_INVALID;
+  gh_nbody *nb = new gh_nbody;
+  nb->ndim = ndim; nb->softening = softening ? 1 : 0; nb->nbody_mult = nbody_mult; nb->device = device;
+  *out = nb;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+    nb->err = "no HIP device: libgandalf_hip has no CPU path";
+    return GH_ERR_HIP;
+  }
+  NB_CHECK(nb, hipSetDevice(device));
+  NB_CHECK(nb, hipStreamCreate(&nb->stream));
+  NB_CHECK(nb, hipMalloc((void**) &nb->tdt, 4*sizeof(double)));
+  NB_CHECK(nb, hipMemset(nb->tdt, 0, 4*sizeof(double)));
+  return GH_OK;
+}
+
+extern "C" void gh_nbody_destroy(gh_nbody *nb)
+{
+  if (!nb) return;
+  if (nb->stream) (void) hipStreamSynchronize(nb->stream);
+  nb_free(nb);
+  if (nb->tdt) (void) hipFree(nb->tdt);
+  if (nb->stream) (void) hipStreamDestroy(nb->stream);
+  delete nb;
+}
+
+extern "C" const char *gh_nbody_last_error(const gh_nbody *nb) { return nb ? nb->err.c_str() : "null context"; }
+
+extern "C" int gh_nbody_upload(gh_nbody *nb, int64_t N, const double *r, const double *v, const double *m, const double *h)
+{
+  if (!nb || N <= 0 || !r || !v || !m || !h) return GH_ERR_INVALID;
+  const int nd = nb->ndim;
+  if (N > nb->Ncap) {
+    nb_free(nb);
+    double **vec[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->stage};
+    for (double **q : vec) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*3*N));
+    double **sca[] = {&nb->m, &nb->h, &nb->gpot, &nb->tlast};
+    for (double **q : sca) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*N));
+    NB_CHECK(nb, hipMalloc((void**) &nb->red, sizeof(double)*((N + 255)/256 + 1)));
+    nb->Ncap = N;
+  }
+  nb->N = N;
+  std::string tmp;
+  std::vector<double> t((size_t) 3*N, 0.0);
+  auto up = [&](double *dst, const double *src) -> hipError_t {
+    for (int64_t i = 0; i < N; i++) for (int k = 0; k < nd; k++) t[(size_t) k*N + i] = src[(size_t) i*nd + k];
+    return hipMemcpy(dst, t.data(), sizeof(double)*3*N, hipMemcpyHostToDevice);
+  };
+  NB_CHECK(nb, up(nb->r, r));
+  NB_CHECK(nb, up(nb->v, v));
+  NB_CHECK(nb, hipMemcpy(nb->r0, nb->r, sizeof(double)*3*N, hipMemcpyDeviceToDevice));
+  NB_CHECK(nb, hipMemcpy(nb->v0, nb->v, sizeof(double)*3*N, hipMemcpyDeviceToDevice));
+  NB_CHECK(nb, hipMemcpy(nb->m, m, sizeof(double)*N, hipMemcpyHostToDevice));
+  NB_CHECK(nb, hipMemcpy(nb->h, h, sizeof(double)*N, hipMemcpyHostToDevice));
+  double **zero3[] = {&nb->a, &nb->adot, &nb->a0};
+  for (double **q : zero3) NB_CHECK(nb, hipMemset(*q, 0, sizeof(double)*3*N));
+  NB_CHECK(nb, hipMemset(nb->gpot, 0, sizeof(double)*N));
+  NB_CHECK(nb, hipMemset(nb->tlast, 0, sizeof(double)*N));
+  NB_CHECK(nb, hipMemset(nb->tdt, 0, 4*sizeof(double)));
+  return GH_OK;
+}
+
+extern "C" int gh_nbody_download(gh_nbody *nb, int field, double *out)
+{
+  if (!nb || !out || nb->N <= 0 || field < 0 || field >= GH_NB_FIELDS) return GH_ERR_INVALID;
+  const int64_t N = nb->N;
+  const int nd = nb->ndim;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  if (field == GH_NB_GPOT) { NB_CHECK(nb, hipMemcpy(out, nb->gpot, sizeof(double)*N, hipMemcpyDeviceToHost)); return GH_OK; }
+  const double *src = field == GH_NB_R ? nb->r : field == GH_NB_V ? nb->v : field == GH_NB_A ? nb->a : nb->adot;
+  std::vector<double> t((size_t) 3*N);
+  NB_CHECK(nb, hipMemcpy(t.data(), src, sizeof(double)*3*N, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < N; i++) for (int k = 0; k < nd; k++) out[(size_t) i*nd + k] = t[(size_t) k*N + i];
+  return GH_OK;
+}
+
+static int nb_launch_forces(gh_nbody *nb)
+{
+  NbPtrs p = nb_ptrs(nb);
+  const dim3 grid((unsigned) ((nb->N + 63)/64)), block(256);
+#define NB_LAUNCH(ND_) \
+  if (nb->softening) hipLaunchKernelGGL((k_nbody_forces<ND_, true>), grid, block, 0, nb->stream, p); \
+  else hipLaunchKernelGGL((k_nbody_forces<ND_, false>), grid, block, 0, nb->stream, p);
+  if (nb->ndim == 1) { NB_LAUNCH(1) } else if (nb->ndim == 2) { NB_LAUNCH(2) } else { NB_LAUNCH(3) }
+#undef NB_LAUNCH
+  NB_CHECK(nb, hipGetLastError());
+  return GH_OK;
+}
+
+extern "C" int gh_nbody_forces(gh_nbody *nb)
+{
+  if (!nb || nb->N <= 0) return GH_ERR_INVALID;
+  int rc = nb_launch_forces(nb);
+  if (rc) return rc;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  return GH_OK;
+}
+
+static int nb_timestep_end(gh_nbody *nb, int correct)
+{
+  NbPtrs p = nb_ptrs(nb);
+  const int nblk = (int) ((nb->N + 255)/256);
+  hipLaunchKernelGGL(k_nbody_correct_dt, dim3(nblk), dim3(256), 0, nb->stream, p, nb->nbody_mult, nb->red, correct);
+  hipLaunchKernelGGL(k_nbody_end, dim3(std::min(nblk, 256)), dim3(256), 0, nb->stream, p, nb->red, nblk);
+  hipLaunchKernelGGL(k_nbody_publish, dim3(1), dim3(1), 0, nb->stream, p);
+  NB_CHECK(nb, hipGetLastError());
+  return GH_OK;
+}
+
+extern "C" int gh_nbody_setup(gh_nbody *nb, double *timestep)
+{
+  if (!nb || nb->N <= 0) return GH_ERR_INVALID;
+  int rc = nb_launch_forces(nb);
+  if (rc) return rc;
+  rc = nb_timestep_end(nb, 0);
+  if (rc) return rc;
+  double td[2];
+  NB_CHECK(nb, hipMemcpyAsync(td, nb->tdt, sizeof(td), hipMemcpyDeviceToHost, nb->stream));
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  if (timestep) *timestep = td[1];
+  return GH_OK;
+}
+
+extern "C" int gh_nbody_step(gh_nbody *nb, int nsteps, double *t, double *timestep)
+{
+  if (!nb || nb->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
+  NbPtrs p = nb_ptrs(nb);
+  const int nblk = (int) ((nb->N + 255)/256);
+  for (int s = 0; s < nsteps; s++) {
+    hipLaunchKernelGGL(k_nbody_advance, dim3(nblk), dim3(256), 0, nb->stream, p, 0);
+    hipLaunchKernelGGL(k_nbody_clock, dim3(1), dim3(1), 0, nb->stream, p);
+    int rc = nb_launch_forces(nb);
+    if (rc) return rc;
+    rc = nb_timestep_end(nb, 1);
+    if (rc) return rc;
+  }
+  double td[2];
+  NB_CHECK(nb, hipMemcpyAsync(td, nb->tdt, sizeof(td), hipMemcpyDeviceToHost, nb->stream));
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  if (t) *t = td[0];
+  if (timestep) *timestep = td[1];
+  return GH_OK;
+}

@@ -217,6 +217,30 @@ int gh_step_end(gh_ctx *ctx, double *t, double *timestep);
 /* device pointer of a field's tree-ordered storage: component k of a vector field, k=0 for scalars */
 void *gh_field_dev(gh_ctx *ctx, int field, int k);
 
+/* ---- N-body (stars): direct sum + leapfrog KDK ------------------------------------------------
+ * replaces: Nbody<ndim>::CalculateDirectGravForces (src/Nbody/Nbody.cpp:233-287),
+ * NbodyLeapfrogKDK::CalculateDirectSmoothedGravForces (src/Nbody/NbodyLeapfrogKDK.cpp:78-142),
+ * AdvanceParticles / CorrectionTerms / EndTimestep / Timestep (:253-400) and the star part of
+ * Simulation::ComputeGlobalTimestep (src/Common/Simulation.cpp:1720-1745), in the order of
+ * NbodySimulation::MainLoop (src/Nbody/NbodySimulation.cpp:311-404).  Global timestep (Nlevels = 1),
+ * open boundaries, no sub-systems / perturbers.  Stars stay in caller order (no tree). */
+typedef struct gh_nbody gh_nbody;
+enum { GH_NB_R = 0, GH_NB_V, GH_NB_A, GH_NB_ADOT, GH_NB_GPOT, GH_NB_FIELDS };
+/* softening: 0 = Newtonian point masses, 1 = M4-kernel softened with mean h (nbody_softening) */
+int gh_nbody_create(int ndim, int softening, double nbody_mult, int device, gh_nbody **out);
+void gh_nbody_destroy(gh_nbody *nb);
+const char *gh_nbody_last_error(const gh_nbody *nb);
+/* r, v: [N][ndim] row-major; m, h: [N] */
+int gh_nbody_upload(gh_nbody *nb, int64_t N, const double *r, const double *v, const double *m, const double *h);
+/* out: [N][ndim] for vector fields, [N] for GH_NB_GPOT */
+int gh_nbody_download(gh_nbody *nb, int field, double *out);
+/* zero a, adot, gpot of all stars and sum all pairs (every star active) */
+int gh_nbody_forces(gh_nbody *nb);
+/* PostInitialConditionsSetup for stars: forces, first global timestep, EndTimestep.  Returns dt. */
+int gh_nbody_setup(gh_nbody *nb, double *timestep);
+/* nsteps x MainLoop.  Returns t and the next timestep. */
+int gh_nbody_step(gh_nbody *nb, int nsteps, double *t, double *timestep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ static const FLOAT big_number = 9.9e20;         // Constants.h:72
 static const FLOAT small_number = 1.0e-20;      // Constants.h:73
 static const double small_number_dp = 1.0e-50;  // Constants.h:90
 static const double big_number_dp = 9.9e50;     // Constants.h:89
+static const FLOAT twopi = 6.28318530717959;    // Constants.h:61
 static const FLOAT invpi = 0.31830988618379;    // Constants.h:63
 static const FLOAT twothirds = 0.66666666666666666666666;
 static const FLOAT ghost_range = 2.5;           // Hydrodynamics.h:52
@@ -805,6 +806,125 @@ struct Oracle {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// N-body direct sum + leapfrog KDK for stars (global timestep, all stars active)
+// ---------------------------------------------------------------------------------------------
+struct Star {
+  FLOAT r[3], v[3], a[3], adot[3], r0[3], v0[3], a0[3], adot0[3];
+  FLOAT m, h, gpot, dt, dt_next, tlast, dt_internal;
+  int nstep, nlast; bool active, end_timestep;
+};
+
+struct NbodyOracle {
+  int N, softening;
+  FLOAT nbody_mult, t, timestep;
+  M4 kern;
+  std::vector<Star> s;
+  NbodyOracle(int N_, int soft, FLOAT mult) : N(N_), softening(soft), nbody_mult(mult), t(0.0), timestep(0.0), kern(3), s(N_) {}
+
+  // Nbody::CalculateDirectGravForces, Nbody.cpp:233-287 (open boundaries, no Ewald)
+  void DirectGrav() {
+    const int ndim = 3;
+    for (int i = 0; i < N; i++) {
+      if (!s[i].active) continue;
+      for (int j = 0; j < N; j++) {
+        if (i == j) continue;
+        FLOAT dr[3], dv[3];
+        for (int k = 0; k < ndim; k++) dr[k] = s[j].r[k] - s[i].r[k];
+        for (int k = 0; k < ndim; k++) dv[k] = s[j].v[k] - s[i].v[k];
+        const FLOAT drsqd = Dot(dr, dr, ndim);
+        const FLOAT invdrmag = (FLOAT) 1.0/sqrt(drsqd);
+        const FLOAT drdt = Dot(dv, dr, ndim)*invdrmag;
+        s[i].gpot += s[j].m*invdrmag;
+        for (int k = 0; k < ndim; k++) s[i].a[k] += s[j].m*dr[k]*pow(invdrmag, 3);
+        for (int k = 0; k < ndim; k++) s[i].adot[k] += s[j].m*pow(invdrmag, 3)*(dv[k] - 3.0*drdt*invdrmag*dr[k]);
+      }
+    }
+  }
+  // NbodyLeapfrogKDK::CalculateDirectSmoothedGravForces, NbodyLeapfrogKDK.cpp:78-142
+  void DirectSmoothedGrav() {
+    const int ndim = 3;
+    for (int i = 0; i < N; i++) {
+      if (!s[i].active) continue;
+      for (int j = 0; j < N; j++) {
+        if (i == j) continue;
+        FLOAT dr[3], dv[3];
+        for (int k = 0; k < ndim; k++) dr[k] = s[j].r[k] - s[i].r[k];
+        for (int k = 0; k < ndim; k++) dv[k] = s[j].v[k] - s[i].v[k];
+        const FLOAT drsqd = Dot(dr, dr, ndim);
+        const FLOAT drmag = sqrt(drsqd) + small_number;
+        const FLOAT invdrmag = (FLOAT) 1.0/drmag;
+        const FLOAT invhmean = (FLOAT) 2.0/(s[i].h + s[j].h);
+        const FLOAT drdt = Dot(dv, dr, ndim)*invdrmag;
+        const FLOAT paux = s[j].m*invhmean*invhmean*kern.wgrav(drmag*invhmean)*invdrmag;
+        const FLOAT wmean = kern.w0(drmag*invhmean)*powf(invhmean, ndim);       // float pow, :118
+        s[i].gpot += s[j].m*invhmean*kern.wpot(drmag*invhmean);
+        for (int k = 0; k < ndim; k++) s[i].a[k] += paux*dr[k];
+        for (int k = 0; k < ndim; k++) s[i].adot[k] += paux*dv[k] - (FLOAT) 3.0*paux*drdt*invdrmag*dr[k] +
+          (FLOAT) 2.0*twopi*s[j].m*drdt*wmean*invdrmag*dr[k];
+      }
+    }
+  }
+  void Zero() {                                  // NbodySimulation.cpp:332-340
+    for (int i = 0; i < N; i++) if (s[i].active) { for (int k = 0; k < 3; k++) { s[i].a[k] = 0.0; s[i].adot[k] = 0.0; } s[i].gpot = 0.0; }
+  }
+  void Forces() { if (softening) DirectSmoothedGrav(); else DirectGrav(); }
+  // NbodyLeapfrogKDK::AdvanceParticles, :253-291
+  void Advance(int n) {
+    for (int i = 0; i < N; i++) {
+      const int dn = n - s[i].nlast;
+      const FLOAT dt = t - s[i].tlast;
+      for (int k = 0; k < 3; k++) s[i].r[k] = s[i].r0[k] + s[i].v0[k]*dt + (FLOAT) 0.5*s[i].a0[k]*dt*dt;
+      for (int k = 0; k < 3; k++) s[i].v[k] = s[i].v0[k] + s[i].a0[k]*dt;
+      s[i].active = (dn == s[i].nstep);
+    }
+  }
+  // CorrectionTerms, :301-331
+  void Correct(int n) {
+    for (int i = 0; i < N; i++) {
+      const int dn = n - s[i].nlast;
+      if (dn == s[i].nstep) for (int k = 0; k < 3; k++) s[i].v[k] += (FLOAT) 0.5*(s[i].a[k] - s[i].a0[k])*(t - s[i].tlast);
+    }
+  }
+  // NbodyLeapfrogKDK::Timestep :387-400 inside Simulation::ComputeGlobalTimestep (Simulation.cpp:1720-1745)
+  void GlobalTimestep() {
+    double dt_min = big_number_dp;
+    for (int i = 0; i < N; i++) {
+      s[i].end_timestep = true;
+      s[i].nstep = 1;
+      const double amag = sqrt(Dot(s[i].a, s[i].a, 3));
+      double ts = nbody_mult*sqrt(s[i].h/(amag + small_number_dp));
+      ts = std::min(ts, (double) s[i].dt_internal);
+      s[i].dt_next = ts;
+      dt_min = std::min(dt_min, ts);
+    }
+    timestep = dt_min;
+    for (int i = 0; i < N; i++) s[i].dt_next = timestep;
+  }
+  // EndTimestep :341-377
+  void EndTimestep(int n) {
+    for (int i = 0; i < N; i++) if (s[i].end_timestep) {
+      for (int k = 0; k < 3; k++) { s[i].r0[k] = s[i].r[k]; s[i].v0[k] = s[i].v[k]; s[i].a0[k] = s[i].a[k]; s[i].adot0[k] = s[i].adot[k]; }
+      s[i].nlast = n; s[i].tlast = t; s[i].dt = s[i].dt_next; s[i].dt_next = 0;
+      s[i].active = false; s[i].end_timestep = false;
+    }
+  }
+  void Setup() {
+    for (int i = 0; i < N; i++) {
+      s[i].active = true;
+      for (int k = 0; k < 3; k++) { s[i].r0[k] = s[i].r[k]; s[i].v0[k] = s[i].v[k]; }
+      s[i].nlast = 0; s[i].tlast = 0.0; s[i].nstep = 1;
+    }
+    t = 0.0;
+    Zero(); Forces(); GlobalTimestep(); EndTimestep(0);
+  }
+  void Step() {                                   // NbodySimulation::MainLoop, NbodySimulation.cpp:311-404
+    t = t + timestep;
+    Advance(1); Zero(); Forces(); Correct(1); GlobalTimestep(); EndTimestep(0);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // C ABI for ctypes
 // ---------------------------------------------------------------------------------------------
@@ -924,6 +1044,36 @@ long orc_gather_neighbours(Oracle *o, long *offsets, int *ids)
     offsets[i + 1] = tot;
   }
   return tot;
+}
+
+NbodyOracle *orc_nbody_create(int N, int softening, double nbody_mult, const double *r, const double *v, const double *m, const double *h)
+{
+  NbodyOracle *o = new NbodyOracle(N, softening, nbody_mult);
+  for (int i = 0; i < N; i++) {
+    Star &q = o->s[i];
+    memset(&q, 0, sizeof(Star));
+    for (int k = 0; k < 3; k++) { q.r[k] = r[3*i + k]; q.v[k] = v[3*i + k]; }
+    q.m = m[i]; q.h = h[i]; q.dt_internal = big_number;
+    q.active = true;
+  }
+  return o;
+}
+void orc_nbody_destroy(NbodyOracle *o) { delete o; }
+void orc_nbody_forces(NbodyOracle *o) { for (int i = 0; i < o->N; i++) o->s[i].active = true; o->Zero(); o->Forces(); }
+void orc_nbody_setup(NbodyOracle *o) { o->Setup(); }
+void orc_nbody_step(NbodyOracle *o, int n) { for (int i = 0; i < n; i++) o->Step(); }
+double orc_nbody_time(NbodyOracle *o) { return o->t; }
+double orc_nbody_timestep(NbodyOracle *o) { return o->timestep; }
+// field: 0 r, 1 v, 2 a, 3 adot, 4 gpot, 5 r0, 6 v0, 7 a0
+void orc_nbody_get(NbodyOracle *o, int field, double *out)
+{
+  for (int i = 0; i < o->N; i++) {
+    const Star &q = o->s[i];
+    const FLOAT *src = field == 0 ? q.r : field == 1 ? q.v : field == 2 ? q.a : field == 3 ? q.adot : field == 5 ? q.r0 :
+                       field == 6 ? q.v0 : field == 7 ? q.a0 : NULL;
+    if (field == 4) out[i] = q.gpot;
+    else for (int k = 0; k < 3; k++) out[3*i + k] = src[k];
+  }
 }
 
 }

@@ -33,6 +33,15 @@ def lib():
                      "orc_set_all_active", "orc_build_tree", "orc_tree_size", "orc_export_tree", "orc_density",
                      "orc_zero_accelerations", "orc_forces", "orc_setup", "orc_step", "orc_num_ghosts", "orc_gather_neighbours"):
             getattr(L, name)
+        L.orc_nbody_create.restype = C.c_void_p
+        L.orc_nbody_create.argtypes = [C.c_int, C.c_int, C.c_double, _PD, _PD, _PD, _PD]
+        L.orc_nbody_time.restype = C.c_double
+        L.orc_nbody_timestep.restype = C.c_double
+        for name in ("orc_nbody_destroy", "orc_nbody_forces", "orc_nbody_setup", "orc_nbody_step"):
+            getattr(L, name).argtypes = [C.c_void_p] + ([C.c_int] if name == "orc_nbody_step" else [])
+        L.orc_nbody_time.argtypes = [C.c_void_p]
+        L.orc_nbody_timestep.argtypes = [C.c_void_p]
+        L.orc_nbody_get.argtypes = [C.c_void_p, C.c_int, _PD]
         _lib = L
     return _lib
 
@@ -166,3 +175,39 @@ def smoke_check(sim, g):
     e = np.max(np.abs(sim.download("rho") - o.get("rho"))/o.get("rho"))
     assert e < 1e-12, e
     return "(vs CPU restatement: rho %.1e)" % e
+
+
+class NbodyOracle:
+    """Stars: direct-sum forces + leapfrog KDK (reference Nbody.cpp:233-287, NbodyLeapfrogKDK.cpp:78-400)."""
+    FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4, "r0": 5, "v0": 6, "a0": 7}
+
+    def __init__(self, r, v, m, h, softening, nbody_mult=0.1):
+        self.L = lib()
+        self.N = len(m)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (r, v, m, h)]
+        self.o = self.L.orc_nbody_create(self.N, int(softening), float(nbody_mult), *[x.ctypes.data_as(_PD) for x in a])
+
+    def __del__(self):
+        if getattr(self, "o", None):
+            self.L.orc_nbody_destroy(self.o)
+            self.o = None
+
+    def forces(self):
+        self.L.orc_nbody_forces(self.o)
+
+    def setup(self):
+        self.L.orc_nbody_setup(self.o)
+
+    def step(self, n=1):
+        self.L.orc_nbody_step(self.o, int(n))
+
+    def t(self):
+        return self.L.orc_nbody_time(self.o)
+
+    def timestep(self):
+        return self.L.orc_nbody_timestep(self.o)
+
+    def get(self, name):
+        out = np.empty(self.N if name == "gpot" else (self.N, 3))
+        self.L.orc_nbody_get(self.o, self.FIELDS[name], out.ctypes.data_as(_PD))
+        return out

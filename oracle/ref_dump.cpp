@@ -17,6 +17,14 @@
 //   ref_dump time   <params.dat> <nsteps> [warmup]
 //       SetupSimulation(); warmup x MainLoop(); time nsteps x MainLoop(); prints one JSON line
 //       (the CPU baseline of bench.py, kind "reference").
+//   ref_dump nbody  <N> <softening 0|1> <nsteps> <out_prefix>
+//       star cluster through the reference's own NbodyLeapfrogKDK<3,M4Kernel>: direct-sum forces
+//       (Nbody::CalculateDirectGravForces / CalculateDirectSmoothedGravForces), then nsteps of
+//       AdvanceParticles -> forces -> CorrectionTerms -> Timestep -> EndTimestep in the order of
+//       NbodySimulation::MainLoop (NbodySimulation.cpp:258-405).  Star ICs come from a 64-bit LCG
+//       written out below (inputs are part of the dump).  The only glue restated here is the
+//       min-reduction of Simulation::ComputeGlobalTimestep (Simulation.cpp:1720-1745), which needs a
+//       full Simulation object in the reference.
 //
 // Dump format ("GDMP1"): records of
 //   u32 name_len, name bytes, u8 dtype ('d' f64, 'i' i32), u32 ndim, u64 dims[ndim], raw data.
@@ -205,8 +213,100 @@ static int run(const string &mode, Parameters *params, SimulationBase *simbase, 
   return 0;
 }
 
+// ---- N-body direct sum -------------------------------------------------------------------------
+#include "CodeTiming.h"
+#include "DomainBox.h"
+#include "SmoothingKernel.h"
+#include "StarParticle.h"
+
+static void dump_stars(Dump &out, int N, StarParticle<3> *p, double t, double dt)
+{
+  const int ndim = 3;
+  PVEC(r) PVEC(v) PVEC(a) PVEC(adot) PVEC(r0) PVEC(v0) PVEC(a0) PSCAL(m) PSCAL(h) PSCAL(gpot) PSCAL(dt)
+  vector<double> tt(2); tt[0] = t; tt[1] = dt; out.d("t_dt", tt);
+}
+
+static int run_nbody(int argc, char **argv)
+{
+  if (argc < 6) { fprintf(stderr, "usage: ref_dump nbody <N> <softening> <nsteps> <prefix>\n"); return 1; }
+  const int N = atoi(argv[2]), soft = atoi(argv[3]), nsteps = atoi(argv[4]);
+  const string prefix = argv[5];
+  const double nbody_mult = 0.1;
+  ExceptionHandler::makeExceptionHandler(cplusplus);
+  NbodyLeapfrogKDK<3, M4Kernel> nb(soft, 0, 0, nbody_mult, "m4");
+  CodeTiming timing;
+  nb.timing = &timing;
+  DomainBox<3> box;
+  for (int k = 0; k < 3; k++) {
+    box.boundary_lhs[k] = openBoundary; box.boundary_rhs[k] = openBoundary;
+    box.min[k] = -1e30; box.max[k] = 1e30; box.size[k] = 2e30; box.half[k] = 1e30;
+  }
+  box.PeriodicGravity = false;
+
+  // synthetic cluster: LCG x <- x*6364136223846793005 + 1442695040888963407, u = (x >> 11) * 2^-53
+  uint64_t x = 88172645463325252ull;
+  auto u01 = [&]() { x = x*6364136223846793005ull + 1442695040888963407ull; return (double) (x >> 11)*(1.0/9007199254740992.0); };
+  StarParticle<3> *star = new StarParticle<3>[N];
+  NbodyParticle<3> **ptr = new NbodyParticle<3>*[N];
+  for (int i = 0; i < N; i++) {
+    for (int k = 0; k < 3; k++) star[i].r[k] = u01();
+    for (int k = 0; k < 3; k++) star[i].v[k] = 0.2*(u01() - 0.5);
+    star[i].m = (0.5 + u01())/N;
+    star[i].h = 0.02*(1.0 + u01());
+    star[i].invh = 1.0/star[i].h;
+    star[i].dt_internal = big_number;
+    star[i].istar = i;
+    ptr[i] = &star[i];
+  }
+  auto zero = [&]() {
+    for (int i = 0; i < N; i++) if (ptr[i]->flags.check(active)) {
+      for (int k = 0; k < 3; k++) { ptr[i]->a[k] = 0.0; ptr[i]->adot[k] = 0.0; ptr[i]->a2dot[k] = 0.0; ptr[i]->a3dot[k] = 0.0; }
+      ptr[i]->gpot = 0.0;
+    }
+  };
+  auto forces = [&]() {
+    if (soft) nb.CalculateDirectSmoothedGravForces(N, ptr, box, NULL);
+    else nb.CalculateDirectGravForces(N, ptr, box, NULL);
+  };
+  double timestep = 0.0;
+  auto global_timestep = [&]() {          // Simulation.cpp:1720-1745, stars only, Nlevels = 1
+    double dt_min = big_number_dp;
+    for (int i = 0; i < N; i++) {
+      ptr[i]->flags.set(end_timestep);
+      ptr[i]->level = 0;
+      ptr[i]->nstep = 1;
+      ptr[i]->dt_next = nb.Timestep(ptr[i]);
+      dt_min = min(dt_min, ptr[i]->dt_next);
+    }
+    timestep = dt_min;
+    for (int i = 0; i < N; i++) ptr[i]->dt_next = timestep;
+  };
+  // setup (NbodySimulation::PostInitialConditionsSetup, NbodySimulation.cpp:150-248)
+  for (int i = 0; i < N; i++) {
+    ptr[i]->flags.set(active);
+    for (int k = 0; k < 3; k++) { ptr[i]->r0[k] = ptr[i]->r[k]; ptr[i]->v0[k] = ptr[i]->v[k]; }
+    ptr[i]->nlast = 0; ptr[i]->tlast = 0.0; ptr[i]->nstep = 1;
+  }
+  double t = 0.0;
+  zero(); forces();
+  global_timestep();
+  nb.EndTimestep(0, N, t, timestep, ptr);
+  { Dump out(prefix + "_setup.gdmp"); dump_stars(out, N, star, t, timestep); }
+  for (int s = 0; s < nsteps; s++) {
+    t = t + timestep;
+    nb.AdvanceParticles(1, N, t, timestep, ptr);
+    zero(); forces();
+    nb.CorrectionTerms(1, N, t, timestep, ptr);
+    global_timestep();
+    nb.EndTimestep(0, N, t, timestep, ptr);
+  }
+  { Dump out(prefix + "_final.gdmp"); dump_stars(out, N, star, t, timestep); }
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
+  if (argc >= 2 && string(argv[1]) == "nbody") return run_nbody(argc, argv);
   if (argc < 4) {
     fprintf(stderr, "usage: ref_dump passes|steps|time <params.dat> ...\n");
     return 1;

@@ -81,7 +81,31 @@ def passes(name, nsteps=None):
         print(name, "steps ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+NBODY_FIELDS = ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt", "t_dt"]
+
+
+def nbody(N, softening, nsteps=3):
+    """Star cluster through the reference's NbodyLeapfrogKDK (ref_dump nbody): direct-sum setup + nsteps."""
+    name = "nbody_%d_%s" % (N, "soft" if softening else "point")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["nbody", str(N), str(softening), str(nsteps), os.path.join(tmp, "n")], tmp)
+        setup = read_gdmp(os.path.join(tmp, "n_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "n_final.gdmp"))
+        out = {"N": np.array([N], dtype=np.int32), "softening": np.array([softening], dtype=np.int32),
+               "nsteps": np.array([nsteps], dtype=np.int32), "nbody_mult": np.array([0.1])}
+        for k in NBODY_FIELDS:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+        print(name, "->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    for cfg in (sys.argv[1:] or ["box3d_4k", "plummer_4k", "adsod_1d"]):
-        passes(cfg)
+    cases = sys.argv[1:] or ["box3d_4k", "plummer_4k", "adsod_1d", "nbody"]
+    for cfg in cases:
+        if cfg == "nbody":
+            nbody(256, 0)
+            nbody(256, 1)
+        else:
+            passes(cfg)
