@@ -112,7 +112,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   ctx->cfg = *cfg;
   ctx->ndim = cfg->ndim;
   *out = ctx;
-  if (cfg->kernel != GH_KERNEL_M4) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only kernel = m4 (tabulated_kernel = 0) is built");
+  if (cfg->kernel != GH_KERNEL_M4 && cfg->kernel != GH_KERNEL_QUINTIC)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only kernel = m4 / quintic (tabulated_kernel = 0) are built");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);

@@ -29,10 +29,10 @@ struct DensityParams {
 #define DB 4      /* candidate tiles per phase-2 batch */
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-template <int ND, bool COUNT>
+template <int ND, bool COUNT, int KT>
 __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
 {
-  typedef M4<ND> K;
+  typedef typename KSel<ND, KT>::type K;
   __shared__ WalkLDS<int> L;
   __shared__ double s_x[DB*64], s_y[DB*64], s_z[DB*64], s_m[DB*64];   // a batch of DB candidate tiles
   __shared__ unsigned long long s_mask[DB][64];                       // per tile, per lane: entries in support
@@ -52,27 +52,35 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   const double mi = d.f[D_M][i];
   double ui = d.f[D_U][i];
   const CellBox gb = d.cbox[gnode];
-  const double hfirst = 1.05*d.ch[gnode].hmax;      // the reference's first search radius (hmax*1.05)
   double gc[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < ND; k++) gc[k] = 0.5*(gb.bbmin[k] + gb.bbmax[k]);
   float tf[3] = {0.f, 0.f, 0.f};
   for (int k = 0; k < ND; k++) tf[k] = (float) (ri[k] - gc[k]);
 
+  // The reference runs ComputeH per LEAF cell with hmax = 1.05^k * cell.hmax: a particle whose iterate exceeds
+  // hmax makes ComputeH return 0 and the whole cell is redone from the stored h with the next k
+  // (GradhSphTree.cpp:141-226, GradhSph.cpp:255).  hmax is also the upper bound of the bisection fallback, so
+  // the try index matters for particles that need more than 30 iterations: keep it per leaf.
+  int leafn = gnode;
+  while (leafn < d.gtot - 1) { const int c2 = 2*leafn + 2; leafn = (i >= d.cfirst[c2]) ? c2 : 2*leafn + 1; }
+  unsigned long long leafmates = 0ull;                 // lanes of the same leaf cell
+  for (int l = 0; l < (1 << (d.ltot - d.lgroup)); l++) {
+    const int ln = (d.gtot - 1) + (gnode - ((1 << d.lgroup) - 1))*(1 << (d.ltot - d.lgroup)) + l;
+    const unsigned long long m = __ballot(act && leafn == ln);
+    if (leafn == ln) leafmates = m;
+  }
+  double hmaxl = 1.05*d.ch[leafn].hmax;
+
   // per-lane iteration state (GradhSph.cpp:148-158)
-  double h = d.f[D_H][i], hlo = 0.0, hup = hfirst;
+  const double h0 = d.f[D_H][i];
+  double h = h0, hlo = 0.0, hup = hmaxl;
   int iter = 0;
   bool done = !act;
   double rho = 0.0, omg = 0.0, zet = 0.0;
   double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
   unsigned long long n_iter = 0, n_cand = 0, n_retry = 0, n_tested = 0;
   // reference cull radius of the first try, for the candidate statistic: kernrange*1.05*hmax(leaf)
-  double cullsqd = 0.0;
-  if (COUNT) {
-    int n = gnode;
-    while (n < d.gtot - 1) { const int c2 = 2*n + 2; n = (i >= d.cfirst[c2]) ? c2 : 2*n + 1; }
-    const double hm = 1.05*d.ch[n].hmax;
-    cullsqd = K::kernrangesqd*hm*hm;
-  }
+  const double cullsqd = K::kernrangesqd*hmaxl*hmaxl;
 
   // ---- h iteration (GradhSph.cpp:184-257); every pass re-walks the tree with the radius it needs
   for (;;) {
@@ -80,8 +88,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
     if (!__any(running)) break;
     // the search volume covers kernrange*h of every lane still iterating (Tree.cpp:319-328 uses
     // bb +/- kernrange*hmax; where the reference's hmax is too small it retries with hmax*1.05)
-    const double hs = fmax(wave_max(running ? h : 0.0), iter == 0 ? hfirst : 0.0);
-    if (hs > hfirst && running && h > hfirst) n_retry++;
+    const double hs = wave_max(running ? h : 0.0);
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
       lo[k] = k < ND ? gb.bbmin[k] - K::kernrange*hs : -1e300;
@@ -93,7 +100,6 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       hfactor = powN<ND>(invh);
       invhsqd = invh*invh;
       rho = 0.0; omg = 0.0; zet = 0.0;
-      if (hup < hs) hup = hs;
     }
     const unsigned int codes = image_codes(P.dom, ND, lo, hi);
     const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
     walk_dfs_stream(d, L, codes, cls, tile, flags);
     process_batch();
 
+    bool failed = false;
     if (running) {
       rho *= hfactor; omg *= hfactor; zet *= invhsqd;
       const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
@@ -222,9 +229,17 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
         else { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
         if (!done) {
           if (!isfinite(h)) { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
-          else if (iter >= 30 && !(h > hlo && h < hup)) done = true;         // loop exit, :257
+          else if (h > hmaxl) failed = true;                                 // "return 0", :255
+          else if (!(h > hlo && h < hup)) done = true;                       // loop exit, :257
         }
       }
+    }
+    // a failed particle restarts its whole leaf cell with hmax*1.05, from the stored h (GradhSphTree.cpp:172-226)
+    const unsigned long long fm = __ballot(failed);
+    if (fm != 0ull && act && (leafmates & fm) != 0ull) {
+      hmaxl = 1.05*hmaxl;
+      h = h0; hlo = 0.0; hup = hmaxl; iter = 0; done = false;
+      if (failed) n_retry++;
     }
   }
 
@@ -298,10 +313,10 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   hipStream_t s = ctx->stream;
   gh_phase_begin(ctx, GH_T_SPH_PROPERTIES);
   if (nblocks > 0) {
-#define LAUNCH(ND_)                                                                                         \
-    if (count) hipLaunchKernelGGL((k_density<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_density<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#define LAUNCH(ND_, KT_)                                                                                      \
+    if (count) hipLaunchKernelGGL((k_density<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_density<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
+    GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
   gh_phase_end(ctx, GH_T_SPH_PROPERTIES);
@@ -313,13 +328,13 @@ int gh_density_impl(gh_ctx *ctx, bool count)
 // multi-GPU: the fields of a received slice that are pure functions of (h, rho, u) - same expressions
 // as the end of k_density, so the values are bit-identical to the owner's
 // ------------------------------------------------------------------------------------------------
-template <int ND>
+template <int ND, int KT>
 __global__ void k_derive_density(DevicePtrs d, EosParams eos, int first, int count)
 {
   const int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int i = first + t;
-  typedef M4<ND> K;
+  typedef typename KSel<ND, KT>::type K;
   const double h = d.f[D_H][i], rho = d.f[D_RHO][i];
   double u = d.f[D_U][i];
   const double invh1 = 1.0/h;
@@ -347,9 +362,9 @@ void gh_derive_after_unpack(gh_ctx *ctx, int set, int64_t first, int64_t count)
   if (set == GH_X_DENSITY) {
     EosParams e;
     gh_fill_eos(ctx, e);
-    if (ctx->ndim == 1) hipLaunchKernelGGL(k_derive_density<1>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
-    else if (ctx->ndim == 2) hipLaunchKernelGGL(k_derive_density<2>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
-    else hipLaunchKernelGGL(k_derive_density<3>, dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
+#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_derive_density<ND_, KT_>), dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
+    GH_DISPATCH(ctx, LAUNCH)
+#undef LAUNCH
   }
   else hipLaunchKernelGGL(k_copy_gpot_hydro, dim3(nb), dim3(256), 0, ctx->stream, d, (int) first, (int) count);
 }

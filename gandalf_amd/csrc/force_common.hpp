@@ -38,12 +38,12 @@ __device__ __forceinline__ void neib_from_tile(Neib &n, const double (*s_t)[64],
 }
 
 // one SPH pair, particle i <- neighbour j               (GradhSph.cpp:384-448 / 498-572)
-template <int ND, bool GRAV>
+template <int ND, bool GRAV, int KT>
 __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const Neib &nb,
                                          const double dr_in[3], double r2)
 {
 #pragma clang fp contract(fast)
-  typedef M4<ND> K;
+  typedef typename KSel<ND, KT>::type K;
   double dr[3] = {dr_in[0], dr_in[1], dr_in[2]};
   double drmag;
   // |dr| and 1/|dr| from one rsqrt (the reference: sqrt then a division, GradhSph.cpp:399-400, 517-518)

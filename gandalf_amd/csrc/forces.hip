@@ -26,7 +26,7 @@
 // ================================================================================================
 // hydro only                                                     (GradhSphTree.cpp:280-435)
 // ================================================================================================
-template <int ND, bool COUNT>
+template <int ND, bool COUNT, int KT>
 __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   __shared__ WalkLDS<int> L;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   // candidate cells: overlap(cell.bb, other.hbox) || overlap(cell.hbox, other.bb)   (Tree.cpp:579-580)
   const CellBox gb = d.cbox[gnode];
   const CellH gh = d.ch[gnode];
-  const double hr_root = M4<ND>::kernrange*d.ch[0].hmax;
+  const double hr_root = KSel<ND, KT>::type::kernrange*d.ch[0].hmax;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) {
     lo[k] = k < ND ? fmin(gh.hbmin[k], gb.bbmin[k] - hr_root) : -1e300;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         if (ND > 2) r2 += dr[2]*dr[2];
         Neib nbr;
         neib_from_tile(nbr, s_t, c);
-        sph_pair<ND, false>(P, ti, A, nbr, dr, r2);
+        sph_pair<ND, false, KT>(P, ti, A, nbr, dr, r2);
         if (COUNT) n_pairs++;
       }
     }
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // near-list entry: first particle (27 bits) | count << 27
 __device__ __forceinline__ int near_entry(int first, int n) { return first | (n << 27); }
 
-template <int ND, bool COUNT>
+template <int ND, bool COUNT, int KT>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags, const int *only_if)
 {
-  typedef M4<ND> K;
+  typedef typename KSel<ND, KT>::type K;
   if (only_if && !*only_if) return;                   // fallback launch that is not needed
 #ifdef GH_STAMPS
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
-          sph_pair<ND, true>(P, ti, A, nb, dr, r2);
+          sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
           if (COUNT) n_pairs++;
         }
       }
@@ -508,10 +508,10 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
-#define LAUNCH(ND_)                                                                                               \
-    if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_hydro_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#define LAUNCH(ND_, KT_)                                                                                            \
+    if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
+    GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
   gh_phase_end(ctx, GH_T_SPH_FORCES);
@@ -530,10 +530,10 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
   if (nblocks > 0) {
-#define LAUNCH(ND_)                                                                                              \
-    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
-    else hipLaunchKernelGGL((k_grav_forces<ND_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if);
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#define LAUNCH(ND_, KT_)                                                                                           \
+    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
+    else hipLaunchKernelGGL((k_grav_forces<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if);
+    GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
   return GH_OK;

@@ -127,6 +127,15 @@ struct gh_ctx {
   int rank = 0, nranks = 1;
 };
 
+// kernel launch dispatch on (ndim, smoothing kernel): L(ND, KT) is the launch macro of the call site
+#define GH_DISPATCH(ctx, L)                                                                                  \
+  if ((ctx)->cfg.kernel == GH_KERNEL_QUINTIC) {                                                               \
+    if ((ctx)->ndim == 1) { L(1, 1) } else if ((ctx)->ndim == 2) { L(2, 1) } else { L(3, 1) }                 \
+  }                                                                                                           \
+  else {                                                                                                      \
+    if ((ctx)->ndim == 1) { L(1, 0) } else if ((ctx)->ndim == 2) { L(2, 0) } else { L(3, 0) }                 \
+  }
+
 #define GH_CHECK(ctx, call)                                                                   \
   do {                                                                                        \
     hipError_t e__ = (call);                                                                  \

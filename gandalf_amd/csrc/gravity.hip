@@ -40,10 +40,10 @@ struct GravLists {
 // ================================================================================================
 // walk                                                           (Tree.cpp:628-735, Tree.h:413-432)
 // ================================================================================================
-template <int ND>
+template <int ND, int KT>
 __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, GravLists G, int *flags)
 {
-  typedef M4<ND> K;
+  typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
@@ -267,12 +267,13 @@ __device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, doubl
   for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
 }
 
-template <int ND, bool COUNT, int MAXOCC>
+template <int ND, bool COUNT, int MAXOCC, int KT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
                                                    unsigned long long *stats, int *flags)
 {
-  typedef M4<ND> K;
-  constexpr int SPHCAP = MAXOCC <= 4 ? 416 : GH_SPHCAP;   // keeps 16 workgroups per CU inside 160 KB of LDS
+  typedef typename KSel<ND, KT>::type K;
+  // M4: keeps 16 workgroups per CU inside 160 KB of LDS; quintic: (3/2)^3 more neighbours per particle
+  constexpr int SPHCAP = KT == 1 ? 1024 : (MAXOCC <= 4 ? 416 : GH_SPHCAP);
   __shared__ TargetI s_tg[MAXOCC];
   __shared__ int s_sph[MAXOCC][SPHCAP];
   __shared__ RangeRing s_ring;
@@ -396,7 +397,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   int nsph[MAXOCC];
 #pragma unroll
   for (int i = 0; i < MAXOCC; i++) nsph[i] = 0;
-  bool overflow = false;
   auto hyd_process = [&](bool valid, int j, const double4 &q0, double hr2) {
 #pragma unroll
     for (int i = 0; i < MAXOCC; i++) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         const unsigned long long sm = __ballot(sph);
         if (sm) {
           const int pos = nsph[i] + __popcll(sm & lt);
-          if (sph) { if (pos < SPHCAP) s_sph[i][pos] = j; else overflow = true; }
+          if (sph && pos < SPHCAP) s_sph[i][pos] = j;
           nsph[i] += __popcll(sm);
         }
         {
@@ -460,7 +460,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, hyd_tile);
     if (pend) hyd_process(p_valid, p_j, p_q0, p_hr2);
   }
-  if (__any(overflow) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);      // > SPHCAP neighbours of one particle
+  // targets with more than SPHCAP SPH neighbours (a halo particle whose kernel covers the core has O(N)): their
+  // list is dropped and they are redone by streaming, below
+  unsigned int ovfmask = 0;
+#pragma unroll
+  for (int i = 0; i < MAXOCC; i++) if (nsph[i] > SPHCAP) ovfmask |= 1u << i;      // nsph counts dropped entries too
   __syncthreads();
   // ---- SPH pairs, 64 at a time per target particle               (GradhSph.cpp:474-585)
 #pragma unroll
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #if defined(GH_DEBUG_SKIP_PAIRS)
       const int ns = 0;
 #else
-      const int ns = min(nsph[i], SPHCAP);
+      const int ns = ((ovfmask >> i) & 1u) ? 0 : min(nsph[i], SPHCAP);
 #endif
       Accum A;
       for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
-          sph_pair<ND, true>(P, ti, A, nb, dr, r2);
+          sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
         }
       }
       if (COUNT) n_pairs += (unsigned long long) ns;
@@ -515,6 +519,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       const double g1 = wave_sum4(acc[MAXOCC > 4 ? 4 : 0].gpot, acc[MAXOCC > 5 ? 5 : 0].gpot, 0.0, 0.0);
       if (lane == 0) s_out[4][8] += g1;
       if (lane == 32 && Nt > 5) s_out[5][8] += g1;
+    }
+  }
+  // ---- rare: SPH pairs of overflowed targets, streamed straight from the candidate ranges (no list)
+  if (ovfmask) {
+#pragma nounroll
+    for (int i = 0; i < Nt; i++) {
+      if (!((ovfmask >> i) & 1u)) continue;
+      const TargetI ti = s_tg[i];
+      Accum A;
+      for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
+      A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
+      unsigned long long npair = 0;
+      auto slow_tile = [&](bool valid, int j, int) {
+        if (valid) {
+          const double4 *r = d.hrec + 4*(size_t) j;
+          const double4 q0 = r[0], q1 = r[1];
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = q0.x - ti.r[0];
+          if (ND > 1) dr[1] = q0.y - ti.r[1];
+          if (ND > 2) dr[2] = q0.z - ti.r[2];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          if (!(r2 >= ti.hr2 && r2 >= q1.w)) {
+            const double4 q2 = r[2], q3 = r[3];
+            Neib nb;
+            nb.x = q0.x; nb.y = q0.y; nb.z = q0.z; nb.m = q0.w; nb.vx = q1.x; nb.vy = q1.y; nb.vz = q1.z; nb.hr2 = q1.w;
+            nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
+            sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
+            npair++;
+          }
+        }
+      };
+      RangeState R; R.nrb = 0; R.nslots = 0;
+      for (int c0 = 0; c0 < lenh; c0 += 64) {
+        const int e = c0 + lane;
+        int2 ent = make_int2(0, 0);
+        if (e < lenh) ent = hydl[e];
+        const unsigned long long vm = __ballot(ent.y > 0);
+        if (ent.y > 0) { const int pos = R.nrb + __popcll(vm & lt); s_ring.first[pos] = ent.x; s_ring.cnt[pos] = ent.y; s_ring.tag[pos] = 0; }
+        R.nrb += __popcll(vm);
+        R.nslots += wave_sum_i(ent.y);
+        range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, slow_tile);
+      }
+      range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, slow_tile);
+      if (COUNT) n_pairs += wave_sum_u64(npair);
+      double red[9];
+      for (int k = 0; k < 3; k++) { red[k] = wave_sum_d(A.a[k]); red[3 + k] = wave_sum_d(A.at[k]); }
+      red[6] = wave_sum_d(A.dudt); red[7] = wave_sum_d(A.div_v); red[8] = wave_sum_d(A.gpot);
+      if (lane == 0) for (int k = 0; k < 9; k++) s_out[i][k] += red[k];
     }
   }
   __syncthreads();
@@ -593,22 +647,22 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
   gh_phase_begin(ctx, GH_T_GRAV_WALK);
   if (ngroups > 0) {
-#define LAUNCH(ND_) hipLaunchKernelGGL((k_grav_walk<ND_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_grav_walk<ND_, KT_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
+    GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
   gh_phase_end(ctx, GH_T_GRAV_WALK);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (ngroups > 0) {
-#define LAUNCH(ND_)                                                                                            \
+#define LAUNCH(ND_, KT_)                                                                                         \
     if (ctx->leafocc <= 4) { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     } else { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
-    if (ctx->ndim == 1) { LAUNCH(1) } else if (ctx->ndim == 2) { LAUNCH(2) } else { LAUNCH(3) }
+    GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
   // if a list overflowed the evaluation kernel did nothing; the fused kernel (forces.hip) then does the

@@ -135,6 +135,89 @@ template <int ND> struct M4 {
   }
 };
 
+
+// Quintic spline (reference src/Headers/SmoothingKernel.h:281-408, norms src/Hydrodynamics/QuinticKernel.cpp:39-60).
+// Powers are written as products (the reference calls pow(s,n)); wzeta keeps the reference's constants as written.
+template <int ND> struct Quintic {
+  static constexpr double kernrange = 3.0;
+  static constexpr double kernrangesqd = 9.0;
+  __host__ __device__ static constexpr double norm()
+  {
+    return ND == 1 ? (1.0/120.0) : (ND == 2 ? GH_INVPI*(7.0/478.0) : GH_INVPI*(1.0/120.0));
+  }
+  __device__ static __forceinline__ double w0(double s)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2, s5 = s4*s;
+    if (s < 1.0) return norm()*(66.0 - 60.0*s2 + 30.0*s4 - 10.0*s5);
+    else if (s < 2.0) return norm()*(51.0 + 75.0*s - 210.0*s2 + 150.0*s3 - 45.0*s4 + 5.0*s5);
+    else if (s < 3.0) return norm()*(243.0 - 405.0*s + 270.0*s2 - 90.0*s3 + 15.0*s4 - s5);
+    return 0.0;
+  }
+  __device__ static __forceinline__ double w1(double s)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2;
+    if (s < 1.0) return norm()*(-120.0*s + 120.0*s3 - 50.0*s4);
+    else if (s < 2.0) return norm()*(75.0 - 420.0*s + 450.0*s2 - 180.0*s3 + 25.0*s4);
+    else if (s < 3.0) return norm()*(-405.0 + 540.0*s - 270.0*s2 + 60.0*s3 - 5.0*s4);
+    return 0.0;
+  }
+  __device__ static __forceinline__ double womega(double s)
+  {
+#pragma clang fp contract(fast)
+    const double nd = (double) ND;
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2, s5 = s4*s;
+    if (s < 1.0) return norm()*(-66.0*nd + 60.0*(nd + 2.0)*s2 - 30.0*(nd + 4.0)*s4 + 10.0*(nd + 5.0)*s5);
+    else if (s < 2.0)
+      return norm()*(-51.0*nd - 75.0*(nd + 1.0)*s + 210.0*(nd + 2.0)*s2 - 150.0*(nd + 3.0)*s3 + 45.0*(nd + 4.0)*s4 -
+                     5.0*(nd + 5.0)*s5);
+    else if (s < 3.0)
+      return norm()*(-243.0*nd + 405.0*(nd + 1.0)*s - 270.0*(nd + 2.0)*s2 + 90.0*(nd + 3.0)*s3 - 15.0*(nd + 4.0)*s4 +
+                     (nd + 5.0)*s5);
+    return 0.0;
+  }
+  __device__ static __forceinline__ double wzeta(double s)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2, s5 = s4*s, s6 = s3*s3, s7 = s6*s;
+    if (s < 1.0) return 33.0*s2 - 15.0*s4 + 5.0*s6 - 1.42857142857*s7 - 34.14285714;
+    else if (s < 2.0) return 25.5*s2 + 25.0*s3 - 52.5*s4 + 30.0*s5 - 7.5*s6 + 0.7142857143*s7 - 33.785714286;
+    else if (s < 3.0) return 121.5*s2 - 135.0*s3 + 67.5*s4 - 18.0*s5 + 2.5*s6 - 0.142857143*s7 - 52.07142857;
+    return 0.0;
+  }
+  __device__ static __forceinline__ double wgrav_i(double s, double invs)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2, s5 = s4*s, s6 = s3*s3, invs2 = invs*invs;
+    if (s < 1.0) return (12.0/359.0)*(22.0*s - 12.0*s3 + (30.0/7.0)*s5 - (5.0/4.0)*s6);
+    else if (s < 2.0)
+      return (12.0/359.0)*(17.0*s + (75.0/4.0)*s2 - 42.0*s3 + 25.0*s4 - (45.0/7.0)*s5 + (5.0/8.0)*s6 + (5.0/56.0)*invs2);
+    else if (s < 3.0)
+      return (12.0/359.0)*(81.0*s - (405.0/4.0)*s2 + 54.0*s3 - 15.0*s4 + (15.0/7.0)*s5 - (1.0/8.0)*s6 - (507.0/56.0)*invs2);
+    return invs2;
+  }
+  __device__ static __forceinline__ double wpot_i(double s, double invs)
+  {
+#pragma clang fp contract(fast)
+    const double s2 = s*s, s3 = s2*s, s4 = s2*s2, s5 = s4*s, s6 = s3*s3, s7 = s6*s;
+    if (s < 1.0) return (12.0/359.0)*(-11.0*s2 + 3.0*s4 - (5.0/7.0)*s6 + (5.0/28.0)*s7 + (478.0/14.0));
+    else if (s < 2.0)
+      return (12.0/359.0)*(-(17.0/2.0)*s2 - (25.0/4.0)*s3 + (21.0/2.0)*s4 - 5.0*s5 + (15.0/14.0)*s6 - (5.0/56.0)*s7 +
+                           (473.0/14.0) + (5.0/56.0)*invs);
+    else if (s < 3.0)
+      return (12.0/359.0)*(-(81.0/2.0)*s2 + (135.0/4.0)*s3 - (27.0/2.0)*s4 + 3.0*s5 - (5.0/14.0)*s6 + (1.0/56.0)*s7 +
+                           (729.0/14.0) - (507.0/56.0)*invs);
+    return invs;
+  }
+  __device__ static __forceinline__ double wgrav(double s) { return wgrav_i(s, 1.0/s); }
+  __device__ static __forceinline__ double wpot(double s) { return s > 0.0 ? wpot_i(s, 1.0/s) : (12.0/359.0)*(478.0/14.0); }
+};
+
+// kernel selector: KT = gh_config::kernel (GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1)
+template <int ND, int KT> struct KSel { typedef M4<ND> type; };
+template <int ND> struct KSel<ND, 1> { typedef Quintic<ND> type; };
+
 // pow(x, ND) / pow(x, ND+1) as the reference writes hfactor (GradhSph.cpp:192, 264)
 template <int ND> __device__ __forceinline__ double powN(double x)
 {

@@ -49,7 +49,7 @@ struct Cell {                                   // TreeCellBase, TreeCell.h:16-4
 };
 
 struct Params {
-  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads;
+  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -57,33 +57,88 @@ struct Params {
 // ---------------------------------------------------------------------------------------------
 // M4 kernel, SmoothingKernel.h:131-240, M4Kernel.cpp:39-53
 // ---------------------------------------------------------------------------------------------
-struct M4 {
-  int ndim; FLOAT kernnorm, kernrange, kernrangesqd;
-  explicit M4(int nd) : ndim(nd), kernrange(2.0), kernrangesqd(4.0) {
-    kernnorm = nd == 1 ? twothirds : (nd == 2 ? invpi*(FLOAT) (10.0/7.0) : invpi);
+// pow(x, n) with a compile-time integer exponent as the reference's templates see it: g++ folds
+// pow(x,1) -> x and pow(x,2) -> x*x (exactly rounded) even without -ffast-math, higher powers stay libm calls
+static inline FLOAT pow_ref(FLOAT x, int n) { return n == 1 ? x : (n == 2 ? x*x : pow(x, (FLOAT) n)); }
+
+struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKernel.h:281-408, QuinticKernel.cpp:39-60)
+  int ndim, type; FLOAT kernnorm, kernrange, kernrangesqd;
+  explicit M4(int nd, int type_ = 0) : ndim(nd), type(type_) {
+    if (type == 0) {
+      kernrange = 2.0; kernrangesqd = 4.0;
+      kernnorm = nd == 1 ? twothirds : (nd == 2 ? invpi*(FLOAT) (10.0/7.0) : invpi);
+    }
+    else {
+      kernrange = 3.0; kernrangesqd = 9.0;
+      kernnorm = nd == 1 ? (FLOAT) (1.0/120.0) : (nd == 2 ? invpi*(FLOAT) (7.0/478.0) : invpi*(FLOAT) (1/120.));
+    }
   }
   FLOAT w0(FLOAT s) const {
+    if (type == 1) {
+      if (s < 1.0) return (kernnorm)*(66.0 - 60.0*s*s + 30.0*pow(s,4) - 10.0*pow(s,5));
+      else if (s < 2.0) return (kernnorm)*(51.0 + 75.0*s - 210.0*s*s + 150.0*pow(s,3) - 45.0*pow(s,4) + 5.0*pow(s,5));
+      else if (s < 3.0) return (kernnorm)*(243.0 - 405*s + 270.0*s*s - 90.0*pow(s,3) + 15.0*pow(s,4) - pow(s,5));
+      else return 0.0;
+    }
     if (s < 1.0) return kernnorm*(1.0 - 1.5*s*s + 0.75*s*s*s);
     else if (s < 2.0) return 0.25*kernnorm*pow(2.0 - s, 3);
     else return 0.0;
   }
   FLOAT w1(FLOAT s) const {
+    if (type == 1) {
+      if (s < 1.0) return (kernnorm)*(-120.0*s + 120.0*pow(s,3) - 50.0*pow(s,4));
+      else if (s < 2.0) return (kernnorm)*(75.0 - 420.0*s + 450.0*s*s - 180.0*pow(s,3) + 25.0*pow(s,4));
+      else if (s < 3.0) return (kernnorm)*(-405.0 + 540.0*s - 270.0*s*s + 60.0*pow(s,3) - 5.0*pow(s,4));
+      else return 0.0;
+    }
     if (s < 1.0) return kernnorm*(-3.0*s + 2.25*s*s);
     else if (s < 2.0) return -0.75*kernnorm*(2.0 - s)*(2.0 - s);
     else return 0.0;
   }
   FLOAT womega(FLOAT s) const {
+    if (type == 1) {
+      if (s < 1.0)
+        return (kernnorm)*(-66.0*(ndim) + 60.0*((ndim) + 2.0)*s*s - 30.0*((ndim) + 4.0)*pow(s,4) + 10.0*((ndim) + 5.0)*pow(s,5));
+      else if (s < 2.0)
+        return (kernnorm)*(-51.0*(ndim) - 75.0*((ndim) + 1.0)*s + 210.0*((ndim) + 2.0)*s*s - 150.0*((ndim) + 3.0)*pow(s,3) +
+                           45.0*((ndim) + 4.0)*pow(s,4) - 5.0*((ndim) + 5.0)*pow(s,5));
+      else if (s < 3.0)
+        return (kernnorm)*(-243.0*(ndim) + 405.0*((ndim) + 1.0)*s - 270.0*((ndim) + 2.0)*s*s + 90.0*((ndim) + 3.0)*pow(s,3) -
+                           15.0*((ndim) + 4.0)*pow(s,4) + ((ndim) + 5.0)*pow(s,5));
+      else return 0.0;
+    }
     if (s < 1.0) return kernnorm*(-ndim + 1.5*(ndim + 2.0)*s*s - 0.75*(ndim + 3.0)*pow(s, 3));
     else if (s < 2.0)
       return kernnorm*(-2.0*ndim + 3.0*(ndim + 1.0)*s - 1.50*(ndim + 2.0)*s*s + 0.25*(ndim + 3.0)*pow(s, 3));
     else return 0.0;
   }
   FLOAT wzeta(FLOAT s) const {
+    if (type == 1) {
+      if (s < (FLOAT) 1.0)
+        return (FLOAT) 33.0*s*s - (FLOAT) 15.0*pow(s,4) + (FLOAT) 5.0*pow(s,6) - (FLOAT) 1.42857142857*pow(s,7) - (FLOAT) 34.14285714;
+      else if (s < 2.0)
+        return (FLOAT) 25.5*s*s + (FLOAT) 25.0*pow(s,3) - (FLOAT) 52.5*pow(s,4) + (FLOAT) 30.0*pow(s,5) - (FLOAT) 7.5*pow(s,6) +
+               (FLOAT) 0.7142857143*pow(s,7) - 33.785714286;
+      else if (s < (FLOAT) 3.0)
+        return (FLOAT) 121.5*s*s - (FLOAT) 135.0*pow(s,3) + (FLOAT) 67.5*pow(s,4) - (FLOAT) 18.0*pow(s,5) + (FLOAT) 2.5*pow(s,6) -
+               (FLOAT) 0.142857143*pow(s,7) - (FLOAT) 52.07142857;
+      else return 0.0;
+    }
     if (s < 1.0) return 1.4 - 2.0*s*s + 1.5*pow(s, 4) - 0.6*pow(s, 5);
     else if (s < 2.0) return 1.6 - 4.0*s*s + 4.0*pow(s, 3) - 1.5*pow(s, 4) + 0.2*pow(s, 5);
     else return 0.0;
   }
   FLOAT wgrav(FLOAT s) const {
+    if (type == 1) {
+      if (s < 1.0) return (12.0/359.0)*(22.0*s - 12.0*pow(s,3) + (30.0/7.0)*pow(s,5) - (5.0/4.0)*pow(s,6));
+      else if (s < 2.0)
+        return (12.0/359.0)*(17.0*s + (75.0/4.0)*s*s - 42.0*pow(s,3) + 25.0*pow(s,4) - (45.0/7.0)*pow(s,5) + (5.0/8.0)*pow(s,6) +
+                             (5.0/56.0)/(s*s));
+      else if (s < 3.0)
+        return (12.0/359.0)*(81.0*s - (405.0/4.0)*pow_ref(s,2) + 54.0*pow(s,3) - 15.0*pow(s,4) + (15.0/7.0)*pow(s,5) -
+                             (1.0/8.0)*pow(s,6) - (507.0/56.0)/(s*s));
+      else return 1.0/(s*s);
+    }
     if (s < 1.0) return 1.333333333333333333333*s - 1.2*pow(s, 3) + 0.5*pow(s, 4);
     else if (s < 2.0)
       return 2.6666666666666666667*s - 3.0*s*s + 1.2*pow(s, 3) - 0.166666666666666666667*pow(s, 4) -
@@ -91,6 +146,17 @@ struct M4 {
     else return 1.0/(s*s);
   }
   FLOAT wpot(FLOAT s) const {
+    if (type == 1) {
+      if (s < 1.0)
+        return (12.0/359.0)*(-11.0*s*s + 3.0*pow(s,4) - (5.0/7.0)*pow(s,6) + (5.0/28.0)*pow(s,7) + (478.0/14.0));
+      else if (s < 2.0)
+        return (12.0/359.0)*(-(17.0/2.0)*s*s - (25.0/4.0)*pow(s,3) + (21.0/2.0)*pow(s,4) - 5.0*pow(s,5) + (15.0/14.0)*pow(s,6) -
+                             (5.0/56.0)*pow(s,7) + (473.0/14.0) + (5.0/56.0)/s);
+      else if (s < 3.0)
+        return (12.0/359.0)*(-(81.0/2.0)*s*s + (135.0/4.0)*pow(s,3) - (27.0/2.0)*pow(s,4) + 3.0*pow(s,5) - (5.0/14.0)*pow(s,6) +
+                             (1.0/56.0)*pow(s,7) + (729.0/14.0) - (507.0/56.0)/s);
+      else return 1.0/s;
+    }
     if (s < 1.0) return 1.4 - 0.666666666666666666666666*s*s + 0.3*pow(s, 4) - 0.1*pow(s, 5);
     else if (s < 2.0)
       return -1.0/(15.0*s) + 1.6 - 1.33333333333333333333333333*s*s + pow(s, 3) - 0.3*pow(s, 4) +
@@ -98,10 +164,6 @@ struct M4 {
     else return 1.0/s;
   }
 };
-
-// pow(x, n) with a compile-time integer exponent as the reference's templates see it: g++ folds
-// pow(x,1) -> x and pow(x,2) -> x*x (exactly rounded) even without -ffast-math, higher powers stay libm calls
-static inline FLOAT pow_ref(FLOAT x, int n) { return n == 1 ? x : (n == 2 ? x*x : pow(x, (FLOAT) n)); }
 
 static inline FLOAT Dot(const FLOAT *a, const FLOAT *b, int nd)   // InlineFuncs.h:46-54
 {
@@ -367,7 +429,7 @@ struct Oracle {
   KDTree tree, ghosttree;
   int n = 0, Nsteps = 0; double t = 0.0, timestep = 0.0;
   std::string err;
-  explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim), invndim(1.0/pp.ndim) {
+  explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel), invndim(1.0/pp.ndim) {
     tree.P = &P; ghosttree.P = &P; tree.kernrange = kern.kernrange; ghosttree.kernrange = kern.kernrange;
   }
   FLOAT h_rho_func(FLOAT m, FLOAT rho) const { return P.h_fac*pow(m/rho, invndim); }   // Sph.h:259
@@ -931,7 +993,7 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, pad_;
   double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
 
@@ -940,6 +1002,7 @@ Oracle *orc_create(const orc_params *q)
   Params P;
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
+  P.kernel = q->kernel;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
     P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];
