@@ -545,8 +545,9 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
-  if (ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only multipole=monopole, gravity_mac=geometric are built");
+  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE) || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only multipole=monopole|quadrupole, gravity_mac=geometric are built");
+  const bool quad = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE;
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
@@ -554,6 +555,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
     const char *fused = getenv("GH_GRAV_FUSED");
     if (!(fused && fused[0] == '1') && ctx->leafocc <= 6) return gh_grav_lists_impl(ctx, count);
   }
+  if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole needs the list kernels (Nleafmax <= 6)");
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   int rc = gh_grav_fused_launch(ctx, count, nullptr);

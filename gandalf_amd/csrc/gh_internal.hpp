@@ -50,6 +50,11 @@ struct alignas(32) CellCom {       // accepted cells only
   double m;                        // mass
 };
 
+struct alignas(64) CellQuad {      // traceless quadrupole about com (multipole = quadrupole only)
+  double q[5];                     // xx, xy, yy, xz, yz  (zz = -xx-yy), KDTree.cpp:929-944
+  double pad[3];
+};
+
 struct DevicePtrs {                // everything a kernel needs, passed by value
   double *f[D_COUNT];              // current particle arrays (tree order)
   int *iorig;                      // caller-order id of each particle
@@ -59,6 +64,7 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   CellH *ch;
   CellGeo *cgeo;
   CellCom *ccom;
+  CellQuad *cquad;                 // nullptr unless multipole = quadrupole
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
 };
@@ -87,6 +93,7 @@ struct gh_ctx {
   CellH *ch = nullptr;
   CellGeo *cgeo = nullptr;
   CellCom *ccom = nullptr;
+  CellQuad *cquad = nullptr;
   double *dbbmin = nullptr, *dbbmax = nullptr;   // divide-time boxes [Ncell][3]
   int *kdiv = nullptr;
   int *P[2][3] = {};               // presorted permutations, double buffered

@@ -267,7 +267,49 @@ __device__ __forceinline__ void point_mass_pm(const TargetI &ti, PMAcc &A, doubl
   for (int k = 0; k < ND; k++) A.at[k] += dr[k]*minvdr3;
 }
 
-template <int ND, bool COUNT, int MAXOCC, int KT>
+
+// Monopole + quadrupole term of one accepted cell on one target (ComputeQuadropole, NeighbourSearch.h:384-460);
+// dr = r_p - r_cell as the reference writes it.  One reciprocal square root replaces its division + sqrt.
+template <int ND>
+__device__ __forceinline__ void point_mass_quad(const TargetI &ti, PMAcc &A, double x, double y, double z, double m, const double *q)
+{
+#pragma clang fp contract(fast)
+  double dr[3] = {0.0, 0.0, 0.0};
+  dr[0] = ti.r[0] - x;
+  if (ND > 1) dr[1] = ti.r[1] - y;
+  if (ND > 2) dr[2] = ti.r[2] - z;
+  double drsqd = dr[0]*dr[0];
+  if (ND > 1) drsqd += dr[1]*dr[1];
+  if (ND > 2) drsqd += dr[2]*dr[2];
+  drsqd += GH_SMALL;
+  const double invdrmag = fast_rsqrt(drsqd);
+  const double invdrsqd = invdrmag*invdrmag;
+  const double invdr3 = invdrsqd*invdrmag;
+  const double invdr5 = invdrsqd*invdr3;
+  double qscalar, qd[3] = {0.0, 0.0, 0.0};
+  if (ND == 3) {
+    const double qzz = -(q[0] + q[2]);
+    qscalar = q[0]*dr[0]*dr[0] + q[2]*dr[1]*dr[1] + qzz*dr[2]*dr[2] + 2.0*(q[1]*dr[0]*dr[1] + q[3]*dr[0]*dr[2] + q[4]*dr[1]*dr[2]);
+    qd[0] = q[0]*dr[0] + q[1]*dr[1] + q[3]*dr[2];
+    qd[1] = q[1]*dr[0] + q[2]*dr[1] + q[4]*dr[2];
+    qd[2] = q[3]*dr[0] + q[4]*dr[1] + qzz*dr[2];
+  }
+  else if (ND == 2) {
+    qscalar = q[0]*dr[0]*dr[0] + q[2]*dr[1]*dr[1] + 2.0*q[1]*dr[0]*dr[1];
+    qd[0] = q[0]*dr[0] + q[1]*dr[1];
+    qd[1] = q[1]*dr[0] + q[2]*dr[1];
+  }
+  else {
+    qscalar = q[0]*dr[0]*dr[0];
+    qd[0] = q[0]*dr[0];
+  }
+  const double qfactor = 2.5*qscalar*invdr5*invdrsqd;
+  const double mfac = m*invdr3 + qfactor;
+  for (int k = 0; k < ND; k++) A.at[k] += qd[k]*invdr5 - mfac*dr[k];
+  A.gpot += m*invdrmag + 0.5*qscalar*invdr5;
+}
+
+template <int ND, bool COUNT, int MAXOCC, int KT, int MP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_grav_eval(DevicePtrs d, ForceParams P, GravLists G, int leaf_begin,
                                                    unsigned long long *stats, int *flags)
 {
@@ -282,7 +324,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
-  if (*G.fallback) return;                              // a list overflowed: the fused kernel does this call
+  if (*G.fallback) {                                    // a list overflowed: the fused kernel does this call
+    if (MP == 1 && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);     // ... which has no quadrupole terms: report it
+    return;
+  }
   const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
   const int node = (d.gtot - 1) + gl;
   const int first = d.cfirst[node], Nt = d.cN[node];
@@ -351,7 +396,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
       for (int i = 0; i < MAXOCC; i++) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
     };
-    if (ltot_ > 0) {
+    if (MP == 1) {
+      // quadrupole moments: a second 40-byte gather per entry; plain one-ahead prefetch of the ids
+      int idn = ltot_ > 0 ? idfix(idraw(0), 0) : -1;
+      for (int c0 = 0; c0 < ltot_; c0 += 64) {
+        const int id = idn;
+        idn = idfix(idraw(c0 + 64), c0 + 64);
+        const int ic = id < 0 ? 0 : id;
+        double4 v = *((const double4*) &d.ccom[ic]);
+        const CellQuad cq = d.cquad[ic];
+        double q[5];
+        for (int k = 0; k < 5; k++) q[k] = id < 0 ? 0.0 : cq.q[k];
+        v.w = id < 0 ? 0.0 : v.w;
+#pragma unroll
+        for (int i = 0; i < MAXOCC; i++) point_mass_quad<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w, q);
+      }
+    }
+    else if (ltot_ > 0) {
       int id1 = idfix(idraw(0), 0), id2 = idfix(idraw(64), 64);
       double4 vcur, vnext;
       recload(id1, vcur);
@@ -654,20 +715,22 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   gh_phase_end(ctx, GH_T_GRAV_WALK);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (ngroups > 0) {
-#define LAUNCH(ND_, KT_)                                                                                         \
+#define LAUNCHM(ND_, KT_, MP_)                                                                                   \
     if (ctx->leafocc <= 4) { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     } else { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
+#define LAUNCH(ND_, KT_) if (ctx->cquad) { LAUNCHM(ND_, KT_, 1) } else { LAUNCHM(ND_, KT_, 0) }
     GH_DISPATCH(ctx, LAUNCH)
+#undef LAUNCHM
 #undef LAUNCH
   }
   // if a list overflowed the evaluation kernel did nothing; the fused kernel (forces.hip) then does the
   // whole call.  It checks the same word and returns at once otherwise - no host round trip.
-  int rc = gh_grav_fused_launch(ctx, count, G.fallback);
+  int rc = ctx->cquad ? GH_OK : gh_grav_fused_launch(ctx, count, G.fallback);
   gh_phase_end(ctx, GH_T_SPH_FORCES);
   if (rc) return rc;
   GH_CHECK(ctx, hipGetLastError());

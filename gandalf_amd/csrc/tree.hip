@@ -351,11 +351,23 @@ __device__ __forceinline__ void finish_cell(const DevicePtrs &d, const CellBox &
   g.rmax = sqrt(dr2);
 }
 
+// q += m (3 dr dr - |dr|^2 1): the independent components the reference keeps (KDTree.cpp:929-944)
+__device__ __forceinline__ void add_quad(double *q, double mi, const double *dr, int nd)
+{
+  double drsqd = dr[0]*dr[0];
+  if (nd > 1) drsqd += dr[1]*dr[1];
+  if (nd > 2) drsqd += dr[2]*dr[2];
+  q[0] += mi*(3.0*dr[0]*dr[0] - drsqd);
+  if (nd > 1) { q[1] += mi*3.0*dr[0]*dr[1]; q[2] += mi*(3.0*dr[1]*dr[1] - drsqd); }
+  if (nd > 2) { q[3] += mi*3.0*dr[2]*dr[0]; q[4] += mi*3.0*dr[2]*dr[1]; }
+}
+
 // what a parent needs of a child (held in LDS between the levels of one fused launch)
 struct SRec {
   double hbmin[3], hbmax[3], hmax;
   double bbmin[3], bbmax[3];
   double com[3], m;
+  double q[5];
   int N, pad;
 };
 
@@ -370,6 +382,7 @@ __device__ __forceinline__ void srec_load(const DevicePtrs &d, int c, int hmax_o
   const CellCom m = d.ccom[c];
   for (int k = 0; k < 3; k++) { r.bbmin[k] = b.bbmin[k]; r.bbmax[k] = b.bbmax[k]; r.com[k] = m.com[k]; }
   r.m = m.m;
+  if (d.cquad) { const CellQuad cq = d.cquad[c]; for (int k = 0; k < 5; k++) r.q[k] = cq.q[k]; }
 }
 
 // leaf cell from its particles (StockCellProperties KDTree.cpp:808-930); hmax_only = 1 restates
@@ -408,6 +421,18 @@ __device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double ke
     if (cnt > 0) finish_cell(d, b, c, hh.hmax, thetamaxsqd);
     c.hmax = hh.hmax;
     d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
+    if (d.cquad) {                                   // KDTree.cpp:921-950
+      CellQuad cq;
+      for (int k = 0; k < 5; k++) cq.q[k] = 0.0;
+      for (int k = 0; k < 3; k++) cq.pad[k] = 0.0;
+      for (int i = first; i < first + cnt; i++) {
+        double dr[3] = {0.0, 0.0, 0.0};
+        _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) dr[k] = d.f[D_RX + k][i] - cm.com[k];
+        add_quad(cq.q, d.f[D_M][i], dr, d.ndim);
+      }
+      d.cquad[n] = cq;
+      for (int k = 0; k < 5; k++) o.q[k] = cq.q[k];
+    }
   }
   else d.cgeo[n].hmax = hh.hmax;
   for (int k = 0; k < 3; k++) { o.hbmin[k] = hh.hbmin[k]; o.hbmax[k] = hh.hbmax[k]; }
@@ -452,6 +477,26 @@ __device__ __forceinline__ void stock_combine(const DevicePtrs &d, int n, const 
   d.cbox[n] = b; d.cgeo[n] = c; d.ccom[n] = cm;
   for (int k = 0; k < 3; k++) { o.bbmin[k] = b.bbmin[k]; o.bbmax[k] = b.bbmax[k]; o.com[k] = cm.com[k]; }
   o.m = cm.m;
+  if (d.cquad) {                                     // KDTree.cpp:1004-1052: children's moments shifted to the parent's COM
+    CellQuad cq;
+    for (int k = 0; k < 5; k++) cq.q[k] = 0.0;
+    for (int k = 0; k < 3; k++) cq.pad[k] = 0.0;
+    const int nq = d.ndim == 3 ? 5 : (d.ndim == 2 ? 3 : 1);
+    if (r1.m > 0) {
+      double dr[3] = {0.0, 0.0, 0.0};
+      _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) dr[k] = r1.com[k] - cm.com[k];
+      _Pragma("unroll") for (int k = 0; k < 5; k++) if (k < nq) cq.q[k] += r1.q[k];
+      add_quad(cq.q, r1.m, dr, d.ndim);
+    }
+    if (r2.m > 0) {
+      double dr[3] = {0.0, 0.0, 0.0};
+      _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) dr[k] = r2.com[k] - cm.com[k];
+      _Pragma("unroll") for (int k = 0; k < 5; k++) if (k < nq) cq.q[k] += r2.q[k];
+      add_quad(cq.q, r2.m, dr, d.ndim);
+    }
+    d.cquad[n] = cq;
+    for (int k = 0; k < 5; k++) o.q[k] = cq.q[k];
+  }
 }
 
 __global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only)
@@ -467,7 +512,7 @@ __global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int h
 
 // Leaves plus the nlev levels above them in one launch: a workgroup owns the 2^nlev leaves below one cell of
 // level ltot-nlev and passes child records between levels through LDS (a barrier per level instead of a launch).
-#define GH_STOCK_NLEV 8
+#define GH_STOCK_NLEV 7
 __global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs d, double kernrange, double thetamaxsqd,
                                                                       int hmax_only, int nlev)
 {
@@ -496,16 +541,16 @@ __global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs 
 }
 
 // levels ltop .. 0 in one launch of one workgroup: the top of the tree is latency, not bandwidth.  Levels
-// wider than 256 cells hand their results on through global memory, the rest through LDS.
+// wider than 128 cells hand their results on through global memory, the rest through LDS.
 __global__ __launch_bounds__(1024) void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only)
 {
-  __shared__ SRec s_a[256];
-  __shared__ SRec s_b[128];
+  __shared__ SRec s_a[128];
+  __shared__ SRec s_b[64];
   SRec *src = s_a, *dst = s_b;
   bool in_lds = false;
   for (int level = ltop; level >= 0; level--) {
     const int nc = 1 << level;
-    const bool out_lds = nc <= 256;
+    const bool out_lds = nc <= 128;
     SRec *o_buf = in_lds ? dst : s_a;
     for (int j = threadIdx.x; j < nc; j += blockDim.x) {
       const int n = nc - 1 + j;
@@ -532,7 +577,7 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   for (int f = 0; f < D_COUNT; f++) d.f[f] = ctx->fbuf[ctx->cur][f];
   d.iorig = ctx->iorig[ctx->cur];
   d.posm = ctx->posm; d.hrec = ctx->hrec;
-  d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom;
+  d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom; d.cquad = ctx->cquad;
   d.cfirst = ctx->cfirst; d.cN = ctx->cN;
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
@@ -579,6 +624,10 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
+  if (ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE && ctx->cfg.self_gravity) {
+    GH_CHECK(ctx, re((void**) &ctx->cquad, sizeof(CellQuad)*Ncell));
+    GH_CHECK(ctx, hipMemsetAsync(ctx->cquad, 0, sizeof(CellQuad)*Ncell, ctx->stream));
+  }
   GH_CHECK(ctx, re((void**) &ctx->dbbmin, sizeof(double)*3*(Ncell + 2)));
   GH_CHECK(ctx, re((void**) &ctx->dbbmax, sizeof(double)*3*(Ncell + 2)));
   GH_CHECK(ctx, re((void**) &ctx->kdiv, sizeof(int)*Ncell));

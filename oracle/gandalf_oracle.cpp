@@ -46,10 +46,11 @@ struct Part {                                   // Particle.h:133-223 + GradhSph
 struct Cell {                                   // TreeCellBase, TreeCell.h:16-49 (+ KDTreeCell c1, c2)
   int cnext, copen, level, ifirst, ilast, N, Nactive, c1, c2;
   FLOAT cdistsqd, bbmin[3], bbmax[3], hbmin[3], hbmax[3], rcell[3], r[3], v[3], m, rmax, hmax;
+  FLOAT q[5];                                   // traceless quadrupole about r (multipole = quadrupole)
 };
 
 struct Params {
-  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel;
+  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -232,9 +233,28 @@ struct KDTree {
     } while (jguess != jpivot);
     return rpivot;
   }
-  void StockCellProperties(Cell &c, const std::vector<Part> &p) {   // KDTree.cpp:808-1083 (monopole, geometric MAC)
+  // q += m (3 dr dr - |dr|^2 1), the five (3 / 1) independent components kept by KDTree.cpp:929-944
+  static void AddQuad(FLOAT *q, FLOAT mi, const FLOAT *dr, int nd) {
+    const FLOAT drsqd = Dot(dr, dr, nd);
+    if (nd == 3) {
+      q[0] += mi*((FLOAT) 3.0*dr[0]*dr[0] - drsqd);
+      q[1] += mi*(FLOAT) 3.0*dr[0]*dr[1];
+      q[2] += mi*((FLOAT) 3.0*dr[1]*dr[1] - drsqd);
+      q[3] += mi*(FLOAT) 3.0*dr[2]*dr[0];
+      q[4] += mi*(FLOAT) 3.0*dr[2]*dr[1];
+    }
+    else if (nd == 2) {
+      q[0] += mi*((FLOAT) 3.0*dr[0]*dr[0] - drsqd);
+      q[1] += mi*(FLOAT) 3.0*dr[0]*dr[1];
+      q[2] += mi*((FLOAT) 3.0*dr[1]*dr[1] - drsqd);
+    }
+    else q[0] += mi*((FLOAT) 3.0*dr[0]*dr[0] - drsqd);
+  }
+  void StockCellProperties(Cell &c, const std::vector<Part> &p) {   // KDTree.cpp:808-1083 (geometric MAC)
     const int nd = P->ndim;
+    const bool need_quad = P->multipole == 1;
     FLOAT dr[3];
+    for (int k = 0; k < 5; k++) c.q[k] = 0.0;
     c.Nactive = 0; c.N = 0; c.m = 0.0; c.hmax = 0.0; c.rmax = 0.0; c.cdistsqd = big_number;
     for (int k = 0; k < nd; k++) { c.r[k] = 0.0; c.v[k] = 0.0; c.rcell[k] = 0.0; c.bbmin[k] = big_number; c.bbmax[k] = -big_number;
                                    c.hbmin[k] = big_number; c.hbmax[k] = -big_number; }
@@ -263,6 +283,15 @@ struct KDTree {
         c.cdistsqd = std::max(Dot(dr, dr, nd), c.hmax*c.hmax)/P->thetamaxsqd;
         c.rmax = sqrt(Dot(dr, dr, nd));
       }
+      if (need_quad) {                                               // KDTree.cpp:921-950
+        int i = c.ifirst;
+        while (i != -1) {
+          for (int k = 0; k < nd; k++) dr[k] = p[i].r[k] - c.r[k];
+          AddQuad(c.q, p[i].m, dr, nd);
+          if (i == c.ilast) break;
+          i = inext[i];
+        }
+      }
     }
     else {
       const Cell &c1 = cell[c.copen], &c2 = cell[cell[c.copen].cnext];
@@ -284,6 +313,15 @@ struct KDTree {
         for (int k = 0; k < nd; k++) dr[k] = 0.5*(c.bbmax[k] - c.bbmin[k]);
         c.cdistsqd = std::max(Dot(dr, dr, nd), c.hmax*c.hmax)/P->thetamaxsqd;
         c.rmax = sqrt(Dot(dr, dr, nd));
+      }
+      if (need_quad) {                                               // KDTree.cpp:1004-1052
+        for (int q = 0; q < 2; q++) {
+          if (!(ch[q]->m > 0)) continue;
+          for (int k = 0; k < nd; k++) dr[k] = ch[q]->r[k] - c.r[k];
+          const int nq = nd == 3 ? 5 : (nd == 2 ? 3 : 1);
+          for (int k = 0; k < nq; k++) c.q[k] += ch[q]->q[k];
+          AddQuad(c.q, ch[q]->m, dr, nd);
+        }
       }
     }
   }
@@ -684,7 +722,7 @@ struct Oracle {
       // ---- walks: Tree::ComputeNeighbourAndGhostList Tree.cpp:562-617 /
       //             Tree::ComputeGravityInteractionAndGhostList Tree.cpp:628-735
       std::vector<int> tempperneib, tempdirectneib;
-      struct MP { FLOAT r[3], m; };
+      struct MP { FLOAT r[3], m, q[5]; };
       std::vector<MP> gravcell;
       {
         const FLOAT hrangemax = kern.kernrange*cellc.hmax, rmax = cellc.rmax;
@@ -714,7 +752,7 @@ struct Oracle {
           else if (o.N == 0) c = o.cnext;
           else if (!(drsqd < o.cdistsqd)) {                          // !open_cell_for_gravity, Tree.h:413-432 (geometric)
             if (o.copen == -1 && o.N == 1) tempdirectneib.push_back(o.ifirst);
-            else { MP m; for (int k = 0; k < 3; k++) m.r[k] = o.r[k]; m.m = o.m; gravcell.push_back(m); }
+            else { MP m; for (int k = 0; k < 3; k++) m.r[k] = o.r[k]; m.m = o.m; for (int k = 0; k < 5; k++) m.q[k] = o.q[k]; gravcell.push_back(m); }
             c = o.cnext;
           }
           else {
@@ -778,8 +816,41 @@ struct Oracle {
             for (int k = 0; k < nd; k++) pi.atree[k] += g.m*dr[k]*invdr3;
             pi.gpot += g.m*invdrmag;
           }
+          // ComputeCellQuadrupoleForces / ComputeQuadropole, NeighbourSearch.h:384-475
+          if (P.multipole == 1) for (size_t jj = 0; jj < gravcell.size(); jj++) {
+            const MP &cl = gravcell[jj];
+            FLOAT dr[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < nd; k++) dr[k] = pi.r[k] - cl.r[k];
+            const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+            const FLOAT invdrsqd = (FLOAT) 1.0/drsqd;
+            const FLOAT invdrmag = sqrt(invdrsqd);
+            const FLOAT invdr5 = invdrsqd*invdrsqd*invdrmag;
+            for (int k = 0; k < nd; k++) pi.atree[k] -= cl.m*dr[k]*invdrsqd*invdrmag;
+            if (nd == 3) {
+              const FLOAT qscalar = cl.q[0]*dr[0]*dr[0] + cl.q[2]*dr[1]*dr[1] - (cl.q[0] + cl.q[2])*dr[2]*dr[2] +
+                                    2.0*(cl.q[1]*dr[0]*dr[1] + cl.q[3]*dr[0]*dr[2] + cl.q[4]*dr[1]*dr[2]);
+              const FLOAT qfactor = 2.5*qscalar*invdr5*invdrsqd;
+              pi.atree[0] += (cl.q[0]*dr[0] + cl.q[1]*dr[1] + cl.q[3]*dr[2])*invdr5 - qfactor*dr[0];
+              pi.atree[1] += (cl.q[1]*dr[0] + cl.q[2]*dr[1] + cl.q[4]*dr[2])*invdr5 - qfactor*dr[1];
+              pi.atree[2] += (cl.q[3]*dr[0] + cl.q[4]*dr[1] - (cl.q[0] + cl.q[2])*dr[2])*invdr5 - qfactor*dr[2];
+              pi.gpot += cl.m*invdrmag + 0.5*qscalar*invdr5;
+            }
+            else if (nd == 2) {
+              const FLOAT qscalar = cl.q[0]*dr[0]*dr[0] + cl.q[2]*dr[1]*dr[1] + 2.0*cl.q[1]*dr[0]*dr[1];
+              const FLOAT qfactor = 2.5*qscalar*invdr5*invdrsqd;
+              pi.atree[0] += (cl.q[0]*dr[0] + cl.q[1]*dr[1])*invdr5 - qfactor*dr[0];
+              pi.atree[1] += (cl.q[1]*dr[0] + cl.q[2]*dr[1])*invdr5 - qfactor*dr[1];
+              pi.gpot += cl.m*invdrmag + 0.5*qscalar*invdr5;
+            }
+            else {
+              const FLOAT qscalar = cl.q[0]*dr[0]*dr[0];
+              const FLOAT qfactor = 2.5*qscalar*invdr5*invdrsqd;
+              pi.atree[0] += (cl.q[0]*dr[0])*invdr5 - qfactor*dr[0];
+              pi.gpot += cl.m*invdrmag + 0.5*qscalar*invdr5;
+            }
+          }
           // ComputeCellMonopoleForces, NeighbourSearch.h:350-377
-          for (size_t jj = 0; jj < gravcell.size(); jj++) {
+          else for (size_t jj = 0; jj < gravcell.size(); jj++) {
             FLOAT dr[3];
             for (int k = 0; k < nd; k++) dr[k] = gravcell[jj].r[k] - pi.r[k];
             const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
@@ -993,7 +1064,7 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, pad_;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole;
   double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
 
@@ -1002,7 +1073,7 @@ Oracle *orc_create(const orc_params *q)
   Params P;
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
-  P.kernel = q->kernel;
+  P.kernel = q->kernel; P.multipole = q->multipole;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
     P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];
