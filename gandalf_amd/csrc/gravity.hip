@@ -489,22 +489,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       }
     }
   };
-  // one-chunk delay line: the records of chunk c+1 are requested before chunk c is evaluated, so the gather
-  // latency (one 128-byte line per candidate, L2/HBM) overlaps with arithmetic instead of stalling the wave
-  bool pend = false, p_valid = false;
-  int p_j = 0;
-  double4 p_q0; p_q0.x = 1e30; p_q0.y = 1e30; p_q0.z = 1e30; p_q0.w = 0.0;
-  double p_hr2 = 0.0;
   auto hyd_tile = [&](bool valid, int j, int) {
     const double4 *r = d.hrec + 4*(size_t) (valid ? j : 0);
     double4 q0 = r[0];
     double hr2 = r[1].w;
-    __builtin_amdgcn_sched_barrier(0);
-    if (pend) hyd_process(p_valid, p_j, p_q0, p_hr2);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(hr2));
     if (!valid) { q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0; }
-    p_valid = valid; p_j = j; p_q0 = q0; p_hr2 = hr2; pend = true;
+    hyd_process(valid, j, q0, hr2);
   };
   {
     RangeState R; R.nrb = 0; R.nslots = 0;
@@ -519,7 +509,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, hyd_tile);
     }
     range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, hyd_tile);
-    if (pend) hyd_process(p_valid, p_j, p_q0, p_hr2);
   }
   // targets with more than SPHCAP SPH neighbours (a halo particle whose kernel covers the core has O(N)): their
   // list is dropped and they are redone by streaming, below
@@ -527,6 +516,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
   for (int i = 0; i < MAXOCC; i++) if (nsph[i] > SPHCAP) ovfmask |= 1u << i;      // nsph counts dropped entries too
   __syncthreads();
+  // the point-mass sums are complete: reduce them now (rows: at0, at2, at1, gpot) so that their 8 registers per
+  // target are free during the pair loops, which are the register-pressure peak of the kernel
+#pragma unroll
+  for (int i = 0; i < MAXOCC; i++) {
+    if (i < Nt) {
+      const double e = wave_sum4(acc[i].at[0], acc[i].at[1], acc[i].at[2], acc[i].gpot);
+      if ((lane & 15) == 0) { const int q = lane >> 4; s_out[i][q == 0 ? 3 : (q == 1 ? 5 : (q == 2 ? 4 : 8))] += e; }
+    }
+  }
+  double gps[MAXOCC];                                   // SPH part of the potential, reduced together at the end
+#pragma unroll
+  for (int i = 0; i < MAXOCC; i++) gps[i] = 0.0;
   // ---- SPH pairs, 64 at a time per target particle               (GradhSph.cpp:474-585)
 #pragma unroll
   for (int i = 0; i < MAXOCC; i++) {
@@ -561,9 +562,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       if (COUNT) n_pairs += (unsigned long long) ns;
       // reduce this particle's sums over the wave, four values per pass (rows hold values 0,2,1,3);
       // the potential is reduced for all particles together after the loop
-      acc[i].gpot += A.gpot;
+      gps[i] = A.gpot;
       const double e0 = wave_sum4(A.a[0], A.a[1], A.a[2], A.dudt);
-      const double e1 = wave_sum4(A.at[0] + acc[i].at[0], A.at[1] + acc[i].at[1], A.at[2] + acc[i].at[2], A.div_v);
+      const double e1 = wave_sum4(A.at[0], A.at[1], A.at[2], A.div_v);
       if ((lane & 15) == 0) {
         const int q = lane >> 4;                       // row -> value: a0, a2, a1, dudt | at0, at2, at1, div_v
         const int k0 = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 6));
@@ -574,10 +575,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
   }
   {
-    const double g0 = wave_sum4(acc[0].gpot, acc[MAXOCC > 1 ? 1 : 0].gpot, acc[MAXOCC > 2 ? 2 : 0].gpot, acc[MAXOCC > 3 ? 3 : 0].gpot);
+    const double g0 = wave_sum4(gps[0], gps[MAXOCC > 1 ? 1 : 0], gps[MAXOCC > 2 ? 2 : 0], gps[MAXOCC > 3 ? 3 : 0]);
     if ((lane & 15) == 0) { const int q = lane >> 4; const int t = q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3)); if (t < Nt) s_out[t][8] += g0; }
     if (MAXOCC > 4 && Nt > 4) {
-      const double g1 = wave_sum4(acc[MAXOCC > 4 ? 4 : 0].gpot, acc[MAXOCC > 5 ? 5 : 0].gpot, 0.0, 0.0);
+      const double g1 = wave_sum4(gps[MAXOCC > 4 ? 4 : 0], gps[MAXOCC > 5 ? 5 : 0], 0.0, 0.0);
       if (lane == 0) s_out[4][8] += g1;
       if (lane == 32 && Nt > 5) s_out[5][8] += g1;
     }
