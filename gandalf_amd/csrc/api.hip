@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface of libgandalf_hip.so (include/gandalf_hip.h) and the step driver.
 #include "gh_internal.hpp"
 #include "walk.hpp"
+#include "sph_kernels.hpp"
 #include <algorithm>
 #include <cmath>
 
@@ -103,6 +104,57 @@ static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
 // ------------------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------------------
+
+// ---- tabulated kernel: host-side construction of the tables (TabulatedKernel.cpp:57-100, SmoothingKernel.h:581-597)
+namespace {
+struct HostM4 {            // M4Kernel functions as the reference writes them (SmoothingKernel.h:131-240)
+  int nd; double norm;
+  explicit HostM4(int nd_) : nd(nd_) { norm = nd == 1 ? GH_TWOTHIRDS : (nd == 2 ? GH_INVPI*(10.0/7.0) : GH_INVPI); }
+  double w0(double s) const { return s < 1.0 ? norm*(1.0 - 1.5*s*s + 0.75*s*s*s) : (s < 2.0 ? 0.25*norm*std::pow(2.0 - s, 3) : 0.0); }
+  double w1(double s) const { return s < 1.0 ? norm*(-3.0*s + 2.25*s*s) : (s < 2.0 ? -0.75*norm*(2.0 - s)*(2.0 - s) : 0.0); }
+  double womega(double s) const {
+    if (s < 1.0) return norm*(-nd + 1.5*(nd + 2.0)*s*s - 0.75*(nd + 3.0)*std::pow(s, 3));
+    if (s < 2.0) return norm*(-2.0*nd + 3.0*(nd + 1.0)*s - 1.50*(nd + 2.0)*s*s + 0.25*(nd + 3.0)*std::pow(s, 3));
+    return 0.0;
+  }
+  double wzeta(double s) const {
+    if (s < 1.0) return 1.4 - 2.0*s*s + 1.5*std::pow(s, 4) - 0.6*std::pow(s, 5);
+    if (s < 2.0) return 1.6 - 4.0*s*s + 4.0*std::pow(s, 3) - 1.5*std::pow(s, 4) + 0.2*std::pow(s, 5);
+    return 0.0;
+  }
+  double wgrav(double s) const {
+    if (s < 1.0) return 1.333333333333333333333*s - 1.2*std::pow(s, 3) + 0.5*std::pow(s, 4);
+    if (s < 2.0) return 2.6666666666666666667*s - 3.0*s*s + 1.2*std::pow(s, 3) - 0.166666666666666666667*std::pow(s, 4) - 0.06666666666666666667/(s*s);
+    return 1.0/(s*s);
+  }
+  double wpot(double s) const {
+    if (s < 1.0) return 1.4 - 0.666666666666666666666666*s*s + 0.3*std::pow(s, 4) - 0.1*std::pow(s, 5);
+    if (s < 2.0) return -1.0/(15.0*s) + 1.6 - 1.33333333333333333333333333*s*s + std::pow(s, 3) - 0.3*std::pow(s, 4) + (1.0/30.0)*std::pow(s, 5);
+    return 1.0/s;
+  }
+};
+}
+
+static int gh_build_kernel_tables(gh_ctx *ctx)
+{
+  const HostM4 k(ctx->ndim);
+  const int res = GH_TAB_RES;
+  const double R = 2.0, R2 = 4.0;
+  std::vector<double> t((size_t) GH_TAB_COUNT*res);
+  const double step = R/res, stepsq = R2/res;
+  for (int i = 0; i < res; i++) {
+    t[GH_TAB_W1*res + i] = k.w1(step*i);
+    t[GH_TAB_WGRAV*res + i] = k.wgrav(step*i);
+    t[GH_TAB_WPOT*res + i] = k.wpot(step*i);
+    t[GH_TAB_W0S2*res + i] = k.w0(std::sqrt(stepsq*i));
+    t[GH_TAB_WOMEGAS2*res + i] = k.womega(std::sqrt(stepsq*i));
+    t[GH_TAB_WZETAS2*res + i] = k.wzeta(std::sqrt(stepsq*i));
+  }
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->ktab, sizeof(double)*t.size()));
+  GH_CHECK(ctx, hipMemcpy(ctx->ktab, t.data(), sizeof(double)*t.size(), hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
 extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
 {
   if (!cfg || !out) return GH_ERR_INVALID;
@@ -112,8 +164,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   ctx->cfg = *cfg;
   ctx->ndim = cfg->ndim;
   *out = ctx;
-  if (cfg->kernel != GH_KERNEL_M4 && cfg->kernel != GH_KERNEL_QUINTIC)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only kernel = m4 / quintic (tabulated_kernel = 0) are built");
+  if (cfg->kernel != GH_KERNEL_M4 && cfg->kernel != GH_KERNEL_QUINTIC && cfg->kernel != GH_KERNEL_M4_TAB)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic (tabulated_kernel = 0) and m4 with tabulated_kernel = 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -132,6 +184,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
+  if (cfg->kernel == GH_KERNEL_M4_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
   return GH_OK;
 }
 
@@ -158,7 +211,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->ktab, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }

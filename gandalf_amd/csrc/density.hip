@@ -23,6 +23,7 @@ struct DensityParams {
   Domain dom;
   EosParams eos;
   double h_fac, h_converge;
+  const double *ktab; // kernel tables (tabulated_kernel = 1) or nullptr
   int group0;        // first group of this rank's shard
 };
 
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           if (ND > 2) r2 += dr[2]*dr[2];
           {
 #pragma clang fp contract(fast)
-            const double s = gh_fast_sqrt(invhsqd*r2);
-            rho += mj*K::w0(s);
-            omg += mj*invh*K::womega(s);
-            zet += mj*K::wzeta(s);
+            const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
+            rho += mj*K::t_w0s2(s2, P.ktab);
+            omg += mj*invh*K::t_womegas2(s2, P.ktab);
+            zet += mj*K::t_wzetas2(s2, P.ktab);
           }
         }
       }
@@ -305,7 +306,7 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   DensityParams P;
   fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
-  P.h_fac = ctx->cfg.h_fac; P.h_converge = ctx->cfg.h_converge;
+  P.h_fac = ctx->cfg.h_fac; P.h_converge = ctx->cfg.h_converge; P.ktab = ctx->ktab;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;

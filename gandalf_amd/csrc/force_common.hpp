@@ -10,6 +10,7 @@ struct ForceParams {
   EosParams eos;
   double alpha_visc, beta_visc;
   int avisc, acond;
+  const double *ktab;   // kernel tables (tabulated_kernel = 1) or nullptr
   int group0;
 };
 
@@ -60,8 +61,8 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
   }
   const double mj = nb.m;
   const double invh_j = nb.invh;
-  const double wkerni = ti.hfactor*K::w1(drmag*ti.invh);
-  const double wkernj = nb.hfac*K::w1(drmag*invh_j);
+  const double wkerni = ti.hfactor*K::t_w1(drmag*ti.invh, P.ktab);
+  const double wkernj = nb.hfac*K::t_w1(drmag*invh_j, P.ktab);
   double dvdr = 0.0;
   {
     dvdr = (nb.vx - ti.v[0])*dr[0];
@@ -87,10 +88,10 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
   if (GRAV) {
     const double si = drmag*ti.invh, sj = drmag*invh_j;
     const double invsi = gh_fast_rcp(si), invsj = gh_fast_rcp(sj);
-    const double pg = 0.5*(ti.invhsqd*K::wgrav_i(si, invsi) + ti.zeta*wkerni +
-                           invh_j*invh_j*K::wgrav_i(sj, invsj) + nb.zeta*wkernj);
+    const double pg = 0.5*(ti.invhsqd*K::t_wgrav(si, invsi, P.ktab) + ti.zeta*wkerni +
+                           invh_j*invh_j*K::t_wgrav(sj, invsj, P.ktab) + nb.zeta*wkernj);
     for (int k = 0; k < ND; k++) A.at[k] += mj*dr[k]*pg;
-    A.gpot += 0.5*mj*(ti.invh*K::wpot_i(si, invsi) + invh_j*K::wpot_i(sj, invsj));
+    A.gpot += 0.5*mj*(ti.invh*K::t_wpot(si, invsi, P.ktab) + invh_j*K::t_wpot(sj, invsj, P.ktab));
   }
 }
 

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0;
-  A.gpot = (d.f[D_M][i]/d.f[D_H][i])*K::wpot(0.0);      // self term, GradhSphTree.cpp:512
+  A.gpot = (d.f[D_M][i]/d.f[D_H][i])*K::t_wpot0(P.ktab);      // self term, GradhSphTree.cpp:512
   unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
   const int occ = d.leafocc;
 
@@ -489,7 +489,7 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
   gh_fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
   P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
-  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond;
+  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;

@@ -94,6 +94,7 @@ struct gh_ctx {
   CellGeo *cgeo = nullptr;
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
+  double *ktab = nullptr;          // tabulated kernel tables [GH_TAB_COUNT][GH_TAB_RES] (device), or nullptr
   double *dbbmin = nullptr, *dbbmax = nullptr;   // divide-time boxes [Ncell][3]
   int *kdiv = nullptr;
   int *P[2][3] = {};               // presorted permutations, double buffered
@@ -138,6 +139,9 @@ struct gh_ctx {
 #define GH_DISPATCH(ctx, L)                                                                                  \
   if ((ctx)->cfg.kernel == GH_KERNEL_QUINTIC) {                                                               \
     if ((ctx)->ndim == 1) { L(1, 1) } else if ((ctx)->ndim == 2) { L(2, 1) } else { L(3, 1) }                 \
+  }                                                                                                           \
+  else if ((ctx)->cfg.kernel == GH_KERNEL_M4_TAB) {                                                           \
+    if ((ctx)->ndim == 1) { L(1, 2) } else if ((ctx)->ndim == 2) { L(2, 2) } else { L(3, 2) }                 \
   }                                                                                                           \
   else {                                                                                                      \
     if ((ctx)->ndim == 1) { L(1, 0) } else if ((ctx)->ndim == 2) { L(2, 0) } else { L(3, 0) }                 \

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   }
   if (lane < Nt) {
     for (int k = 0; k < 10; k++) s_out[lane][k] = 0.0;
-    s_out[lane][8] = (d.f[D_M][first + lane]/d.f[D_H][first + lane])*K::wpot(0.0);    // self term, GradhSphTree.cpp:512
+    s_out[lane][8] = (d.f[D_M][first + lane]/d.f[D_H][first + lane])*K::t_wpot0(P.ktab);    // self term, GradhSphTree.cpp:512
   }
   __syncthreads();
 #if defined(GH_DEBUG_SKIP_ALL)       /* timing experiments only: drop the point-mass and / or the SPH part */
@@ -699,7 +699,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   gh_fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
   P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
-  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond;
+  P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;

@@ -133,6 +133,14 @@ template <int ND> struct M4 {
              (1.0/30.0)*(s2*s2*s);
     return 1.0/s;
   }
+  // table-aware entry points (tab is ignored by the analytic kernels; see TabK below)
+  __device__ static __forceinline__ double t_w0s2(double s2, const double *) { return w0(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_womegas2(double s2, const double *) { return womega(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_wzetas2(double s2, const double *) { return wzeta(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_w1(double s, const double *) { return w1(s); }
+  __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *) { return wgrav_i(s, invs); }
+  __device__ static __forceinline__ double t_wpot(double s, double invs, const double *) { return wpot_i(s, invs); }
+  __device__ static __forceinline__ double t_wpot0(const double *) { return wpot(0.0); }
 };
 
 
@@ -212,11 +220,56 @@ template <int ND> struct Quintic {
   }
   __device__ static __forceinline__ double wgrav(double s) { return wgrav_i(s, 1.0/s); }
   __device__ static __forceinline__ double wpot(double s) { return s > 0.0 ? wpot_i(s, 1.0/s) : (12.0/359.0)*(478.0/14.0); }
+  // table-aware entry points (tab is ignored by the analytic kernels; see TabK below)
+  __device__ static __forceinline__ double t_w0s2(double s2, const double *) { return w0(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_womegas2(double s2, const double *) { return womega(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_wzetas2(double s2, const double *) { return wzeta(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ double t_w1(double s, const double *) { return w1(s); }
+  __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *) { return wgrav_i(s, invs); }
+  __device__ static __forceinline__ double t_wpot(double s, double invs, const double *) { return wpot_i(s, invs); }
+  __device__ static __forceinline__ double t_wpot0(const double *) { return wpot(0.0); }
 };
 
-// kernel selector: KT = gh_config::kernel (GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1)
+
+// Tabulated kernel (reference TabulatedKernel, SmoothingKernel.h:547-756, TabulatedKernel.cpp:57-100): 1000-entry
+// PIECEWISE-CONSTANT tables of the base kernel, indexed (int)(s*res/R) or (int)(s^2*res/R^2); gravity tables fall
+// back to 1/s^2, 1/s outside the kernel.  The tables are built on the host (api.hip) and passed by pointer.
+#define GH_TAB_RES 1000
+enum { GH_TAB_W1 = 0, GH_TAB_WGRAV, GH_TAB_WPOT, GH_TAB_W0S2, GH_TAB_WOMEGAS2, GH_TAB_WZETAS2, GH_TAB_COUNT };
+template <int ND, class Base> struct TabK {
+  static constexpr double kernrange = Base::kernrange;
+  static constexpr double kernrangesqd = Base::kernrangesqd;
+  __device__ static __forceinline__ double look(const double *tab, int which, double s)
+  {
+    if (s >= kernrange) return 0.0;
+    return tab[which*GH_TAB_RES + (int) (s*((double) GH_TAB_RES/kernrange))];
+  }
+  __device__ static __forceinline__ double looksqd(const double *tab, int which, double s2)
+  {
+    if (s2 >= kernrangesqd) return 0.0;
+    return tab[which*GH_TAB_RES + (int) (s2*((double) GH_TAB_RES/kernrangesqd))];
+  }
+  __device__ static __forceinline__ double t_w0s2(double s2, const double *tab) { return looksqd(tab, GH_TAB_W0S2, s2); }
+  __device__ static __forceinline__ double t_womegas2(double s2, const double *tab) { return looksqd(tab, GH_TAB_WOMEGAS2, s2); }
+  __device__ static __forceinline__ double t_wzetas2(double s2, const double *tab) { return looksqd(tab, GH_TAB_WZETAS2, s2); }
+  __device__ static __forceinline__ double t_w1(double s, const double *tab) { return look(tab, GH_TAB_W1, s); }
+  __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *tab)
+  {
+    if (s >= kernrange) return invs*invs;
+    return tab[GH_TAB_WGRAV*GH_TAB_RES + (int) (s*((double) GH_TAB_RES/kernrange))];
+  }
+  __device__ static __forceinline__ double t_wpot(double s, double invs, const double *tab)
+  {
+    if (s >= kernrange) return invs;
+    return tab[GH_TAB_WPOT*GH_TAB_RES + (int) (s*((double) GH_TAB_RES/kernrange))];
+  }
+  __device__ static __forceinline__ double t_wpot0(const double *tab) { return tab[GH_TAB_WPOT*GH_TAB_RES]; }
+};
+
+// kernel selector: KT = gh_config::kernel (GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2)
 template <int ND, int KT> struct KSel { typedef M4<ND> type; };
 template <int ND> struct KSel<ND, 1> { typedef Quintic<ND> type; };
+template <int ND> struct KSel<ND, 2> { typedef TabK<ND, M4<ND> > type; };
 
 // pow(x, ND) / pow(x, ND+1) as the reference writes hfactor (GradhSph.cpp:192, 264)
 template <int ND> __device__ __forceinline__ double powN(double x)

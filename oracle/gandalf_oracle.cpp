@@ -63,8 +63,12 @@ struct Params {
 static inline FLOAT pow_ref(FLOAT x, int n) { return n == 1 ? x : (n == 2 ? x*x : pow(x, (FLOAT) n)); }
 
 struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKernel.h:281-408, QuinticKernel.cpp:39-60)
-  int ndim, type; FLOAT kernnorm, kernrange, kernrangesqd;
-  explicit M4(int nd, int type_ = 0) : ndim(nd), type(type_) {
+  int ndim, type, tabulated; FLOAT kernnorm, kernrange, kernrangesqd;
+  // TabulatedKernel (SmoothingKernel.h:547-756, TabulatedKernel.cpp:57-100): piecewise-constant tables
+  static const int res = 1000;
+  FLOAT resinvkernrange, resinvkernrangesqd;
+  std::vector<FLOAT> tW0, tW1, tWomega, tWzeta, tWgrav, tWpot, tW0_s2, tWomega_s2, tWzeta_s2;
+  explicit M4(int nd, int type_ = 0, int tab_ = 0) : ndim(nd), type(type_ & 1), tabulated(tab_) {
     if (type == 0) {
       kernrange = 2.0; kernrangesqd = 4.0;
       kernnorm = nd == 1 ? twothirds : (nd == 2 ? invpi*(FLOAT) (10.0/7.0) : invpi);
@@ -73,8 +77,31 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
       kernrange = 3.0; kernrangesqd = 9.0;
       kernnorm = nd == 1 ? (FLOAT) (1.0/120.0) : (nd == 2 ? invpi*(FLOAT) (7.0/478.0) : invpi*(FLOAT) (1/120.));
     }
+    resinvkernrange = res/kernrange; resinvkernrangesqd = res/kernrangesqd;
+    if (tabulated) {
+      const FLOAT step = kernrange/res, stepsq = kernrangesqd/res;
+      tW0.resize(res); tW1.resize(res); tWomega.resize(res); tWzeta.resize(res); tWgrav.resize(res); tWpot.resize(res);
+      tW0_s2.resize(res); tWomega_s2.resize(res); tWzeta_s2.resize(res);
+      for (int i = 0; i < res; i++) {
+        tW0[i] = a_w0(step*i); tW1[i] = a_w1(step*i); tWomega[i] = a_womega(step*i); tWzeta[i] = a_wzeta(step*i);
+        tWgrav[i] = a_wgrav(step*i); tWpot[i] = a_wpot(step*i);
+        tW0_s2[i] = a_w0(sqrt(stepsq*i)); tWomega_s2[i] = a_womega(sqrt(stepsq*i)); tWzeta_s2[i] = a_wzeta(sqrt(stepsq*i));
+      }
+    }
   }
-  FLOAT w0(FLOAT s) const {
+  FLOAT look(const std::vector<FLOAT> &t, FLOAT s) const { if (s >= kernrange) return 0.0; return t[(int) (s*resinvkernrange)]; }
+  FLOAT looksqd(const std::vector<FLOAT> &t, FLOAT s2) const { if (s2 >= kernrangesqd) return 0.0; return t[(int) (s2*resinvkernrangesqd)]; }
+  FLOAT w0(FLOAT s) const { return tabulated ? look(tW0, s) : a_w0(s); }
+  FLOAT w1(FLOAT s) const { return tabulated ? look(tW1, s) : a_w1(s); }
+  FLOAT womega(FLOAT s) const { return tabulated ? look(tWomega, s) : a_womega(s); }
+  FLOAT wzeta(FLOAT s) const { return tabulated ? look(tWzeta, s) : a_wzeta(s); }
+  FLOAT wgrav(FLOAT s) const { if (!tabulated) return a_wgrav(s); if (s >= kernrange) return (FLOAT) 1.0/(s*s); return tWgrav[(int) (s*resinvkernrange)]; }
+  FLOAT wpot(FLOAT s) const { if (!tabulated) return a_wpot(s); if (s >= kernrange) return (FLOAT) 1.0/s; return tWpot[(int) (s*resinvkernrange)]; }
+  // w0_s2 etc.: base kernels take the square root (SmoothingKernel.h:78-92), the tabulated one indexes by s^2
+  FLOAT w0_s2(FLOAT s2) const { return tabulated ? looksqd(tW0_s2, s2) : a_w0(sqrt(s2)); }
+  FLOAT womega_s2(FLOAT s2) const { return tabulated ? looksqd(tWomega_s2, s2) : a_womega(sqrt(s2)); }
+  FLOAT wzeta_s2(FLOAT s2) const { return tabulated ? looksqd(tWzeta_s2, s2) : a_wzeta(sqrt(s2)); }
+  FLOAT a_w0(FLOAT s) const {
     if (type == 1) {
       if (s < 1.0) return (kernnorm)*(66.0 - 60.0*s*s + 30.0*pow(s,4) - 10.0*pow(s,5));
       else if (s < 2.0) return (kernnorm)*(51.0 + 75.0*s - 210.0*s*s + 150.0*pow(s,3) - 45.0*pow(s,4) + 5.0*pow(s,5));
@@ -85,7 +112,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
     else if (s < 2.0) return 0.25*kernnorm*pow(2.0 - s, 3);
     else return 0.0;
   }
-  FLOAT w1(FLOAT s) const {
+  FLOAT a_w1(FLOAT s) const {
     if (type == 1) {
       if (s < 1.0) return (kernnorm)*(-120.0*s + 120.0*pow(s,3) - 50.0*pow(s,4));
       else if (s < 2.0) return (kernnorm)*(75.0 - 420.0*s + 450.0*s*s - 180.0*pow(s,3) + 25.0*pow(s,4));
@@ -96,7 +123,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
     else if (s < 2.0) return -0.75*kernnorm*(2.0 - s)*(2.0 - s);
     else return 0.0;
   }
-  FLOAT womega(FLOAT s) const {
+  FLOAT a_womega(FLOAT s) const {
     if (type == 1) {
       if (s < 1.0)
         return (kernnorm)*(-66.0*(ndim) + 60.0*((ndim) + 2.0)*s*s - 30.0*((ndim) + 4.0)*pow(s,4) + 10.0*((ndim) + 5.0)*pow(s,5));
@@ -113,7 +140,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
       return kernnorm*(-2.0*ndim + 3.0*(ndim + 1.0)*s - 1.50*(ndim + 2.0)*s*s + 0.25*(ndim + 3.0)*pow(s, 3));
     else return 0.0;
   }
-  FLOAT wzeta(FLOAT s) const {
+  FLOAT a_wzeta(FLOAT s) const {
     if (type == 1) {
       if (s < (FLOAT) 1.0)
         return (FLOAT) 33.0*s*s - (FLOAT) 15.0*pow(s,4) + (FLOAT) 5.0*pow(s,6) - (FLOAT) 1.42857142857*pow(s,7) - (FLOAT) 34.14285714;
@@ -129,7 +156,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
     else if (s < 2.0) return 1.6 - 4.0*s*s + 4.0*pow(s, 3) - 1.5*pow(s, 4) + 0.2*pow(s, 5);
     else return 0.0;
   }
-  FLOAT wgrav(FLOAT s) const {
+  FLOAT a_wgrav(FLOAT s) const {
     if (type == 1) {
       if (s < 1.0) return (12.0/359.0)*(22.0*s - 12.0*pow(s,3) + (30.0/7.0)*pow(s,5) - (5.0/4.0)*pow(s,6));
       else if (s < 2.0)
@@ -146,7 +173,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
              0.06666666666666666667/(s*s);
     else return 1.0/(s*s);
   }
-  FLOAT wpot(FLOAT s) const {
+  FLOAT a_wpot(FLOAT s) const {
     if (type == 1) {
       if (s < 1.0)
         return (12.0/359.0)*(-11.0*s*s + 3.0*pow(s,4) - (5.0/7.0)*pow(s,6) + (5.0/28.0)*pow(s,7) + (478.0/14.0));
@@ -467,7 +494,7 @@ struct Oracle {
   KDTree tree, ghosttree;
   int n = 0, Nsteps = 0; double t = 0.0, timestep = 0.0;
   std::string err;
-  explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel), invndim(1.0/pp.ndim) {
+  explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel & 1, (pp.kernel >> 1) & 1), invndim(1.0/pp.ndim) {
     tree.P = &P; ghosttree.P = &P; tree.kernrange = kern.kernrange; ghosttree.kernrange = kern.kernrange;
   }
   FLOAT h_rho_func(FLOAT m, FLOAT rho) const { return P.h_fac*pow(m/rho, invndim); }   // Sph.h:259
@@ -531,10 +558,9 @@ struct Oracle {
         const Part &ngb = p[ngb2[j]];
         for (int k = 0; k < nd; k++) dr[k] = ngb.r[k] - pi.r[k];
         ssqd = invhsqd*Dot(dr, dr, nd);
-        const FLOAT s = sqrt(ssqd);                                  // w0_s2 = w0(sqrt(s)), SmoothingKernel.h:78-80
-        pi.rho += ngb.m*kern.w0(s);
-        pi.invomega += ngb.m*invh*kern.womega(s);
-        pi.zeta += ngb.m*kern.wzeta(s);
+        pi.rho += ngb.m*kern.w0_s2(ssqd);                           // GradhSph.cpp:201-203
+        pi.invomega += ngb.m*invh*kern.womega_s2(ssqd);
+        pi.zeta += ngb.m*kern.wzeta_s2(ssqd);
       }
       pi.rho *= pi.hfactor; pi.invomega *= pi.hfactor; pi.zeta *= invhsqd;
       if (pi.rho > 0.0 && pi.h > h_lower_bound && fabs(pi.h - h_rho_func(pi.m, pi.rho))*invh < P.h_converge) break;

@@ -69,8 +69,9 @@ class Oracle:
         q.gamma_eos = float(p.get("gamma_eos", 1.66666666666666)); q.thetamaxsqd = float(p.get("thetamaxsqd", 0.1))
         q.courant_mult = float(p.get("courant_mult", 0.15)); q.accel_mult = float(p.get("accel_mult", 0.3))
         q.energy_mult = float(p.get("energy_mult", 0.4))
-        assert p.get("kernel", "m4") in ("m4", "quintic") and int(p.get("tabulated_kernel", 0)) == 0
-        q.kernel = 1 if p.get("kernel", "m4") == "quintic" else 0
+        assert p.get("kernel", "m4") in ("m4", "quintic")
+        # bit 0: quintic, bit 1: tabulated_kernel
+        q.kernel = (1 if p.get("kernel", "m4") == "quintic" else 0) | (2 if int(p.get("tabulated_kernel", 0)) else 0)
         assert p.get("multipole", "quadrupole") in ("monopole", "quadrupole") or not q.self_gravity
         q.multipole = 1 if p.get("multipole", "quadrupole") == "quadrupole" else 0
         assert p.get("avisc", "mon97") == "mon97" and p.get("acond", "none") == "none"
