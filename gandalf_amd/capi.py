@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("temp0", C.c_double),
         ("mu_bar", C.c_double), ("rho_bary", C.c_double), ("thetamaxsqd", C.c_double),
         ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double),
+        ("macerror", C.c_double),
     ]
 
 
@@ -126,7 +127,7 @@ _ENUMS = {
     "avisc": {"none": 0, "mon97": 1},
     "acond": {"none": 0, "wadsley2008": 1, "price2008": 2},
     "multipole": {"monopole": 0, "quadrupole": 1},
-    "gravity_mac": {"geometric": 0},
+    "gravity_mac": {"geometric": 0, "gadget2": 1},
 }
 
 
@@ -147,6 +148,7 @@ def config_from_params(p, device=0):
     c.hydro_forces = int(p.get("hydro_forces", 1))
     c.multipole = _ENUMS["multipole"][p.get("multipole", "quadrupole")]
     c.gravity_mac = _ENUMS["gravity_mac"][p.get("gravity_mac", "geometric")]
+    c.macerror = float(p.get("macerror", 0.0001))
     c.Nleafmax = int(p.get("Nleafmax", 6))
     c.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
     c.device = device

@@ -211,7 +211,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->ktab, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -557,8 +557,18 @@ extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
     if ((rc = density_and_hmax(ctx, false))) return rc;
     if ((rc = gh_sync_collect(ctx, "gh_setup/density"))) return rc;
   }
+  // relative MACs need accelerations: the reference runs this force pass with the geometric MAC, rebuilds the tree
+  // (which stocks amin from it) and repeats the pass with the requested MAC (SphSimulation.cpp:381-473)
+  const bool relmac = ctx->cfg.self_gravity && ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;
+  ctx->mac_bootstrap = relmac;
   gh_zero_acc_impl(ctx);
   if ((rc = forces_impl(ctx))) return rc;
+  ctx->mac_bootstrap = false;
+  if (relmac) {
+    if ((rc = build_tree_timed(ctx))) return rc;
+    gh_zero_acc_impl(ctx);
+    if ((rc = forces_impl(ctx))) return rc;
+  }
   // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
   ctx->t = 0.0; ctx->timestep = 0.0; ctx->n = 0;
   if ((rc = push_time(ctx))) return rc;

@@ -11,6 +11,8 @@ struct ForceParams {
   double alpha_visc, beta_visc;
   int avisc, acond;
   const double *ktab;   // kernel tables (tabulated_kernel = 1) or nullptr
+  double macerror;      // gravity_mac = gadget2
+  int mac;              // GH_MAC_*
   int group0;
 };
 

@@ -490,6 +490,7 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
   gh_fill_eos(ctx, P.eos);
   P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
+  P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -545,9 +546,10 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
-  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE) || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "only multipole=monopole|quadrupole, gravity_mac=geometric are built");
-  const bool quad = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE;
+  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE) ||
+      (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.gravity_mac != GH_MAC_GADGET2))
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "built: multipole=monopole|quadrupole, gravity_mac=geometric|gadget2");
+  const bool quad = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.gravity_mac == GH_MAC_GADGET2;   // list kernels only
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
@@ -555,7 +557,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
     const char *fused = getenv("GH_GRAV_FUSED");
     if (!(fused && fused[0] == '1') && ctx->leafocc <= 6) return gh_grav_lists_impl(ctx, count);
   }
-  if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole needs the list kernels (Nleafmax <= 6)");
+  if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole / gravity_mac=gadget2 need the list kernels (Nleafmax <= 6)");
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   int rc = gh_grav_fused_launch(ctx, count, nullptr);

@@ -65,6 +65,7 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   CellGeo *cgeo;
   CellCom *ccom;
   CellQuad *cquad;                 // nullptr unless multipole = quadrupole
+  double *leaf_amin;               // [gtot] min |atree| of each leaf at stock time (gravity_mac = gadget2), or nullptr
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
 };
@@ -94,6 +95,8 @@ struct gh_ctx {
   CellGeo *cgeo = nullptr;
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
+  double *leaf_amin = nullptr;
+  bool mac_bootstrap = false;      // gh_setup's first force pass of a relative MAC runs geometric (SphSimulation.cpp:381-388)
   double *ktab = nullptr;          // tabulated kernel tables [GH_TAB_COUNT][GH_TAB_RES] (device), or nullptr
   double *dbbmin = nullptr, *dbbmax = nullptr;   // divide-time boxes [Ncell][3]
   int *kdiv = nullptr;

@@ -40,13 +40,13 @@ struct GravLists {
 // ================================================================================================
 // walk                                                           (Tree.cpp:628-735, Tree.h:413-432)
 // ================================================================================================
-template <int ND, int KT>
+template <int ND, int KT, int MAC>
 __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, GravLists G, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];
-  __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
+  __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF], s_lamin[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
@@ -59,21 +59,26 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
 
   unsigned int allmask = 0;
   const CellGeo gg = d.cgeo[gnode];
-  double Rg = 0.0, Lm = 0.0, Lr = 0.0;
+  constexpr bool gadget = MAC == GH_MAC_GADGET2;        // relative MAC of open_cell_for_gravity, Tree.h:413-432
+  double Rg = 0.0, Lm = 0.0, Lr = 0.0, Amin = 0.0;
   {
-    double rg = 0.0, lm = 0.0, lr = 0.0;
+    double rg = 0.0, lm = 0.0, lr = 0.0, amn = 9.9e20;
     if (lane < nl) {
       const CellGeo g = d.cgeo[leafnode0 + lane];
       for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
       s_lrmax[lane] = g.rmax;
       s_lhr[lane] = K::kernrange*g.hmax;
+      const double am = gadget ? d.leaf_amin[q*nl + lane] : 0.0;
+      s_lamin[lane] = am;
       if (g.N > 0) {
         double dd = 0.0;
         for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; dd += dx*dx; }
         rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
+        amn = am;
       }
     }
     Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
+    Amin = wave_min(amn);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
   // list lengths: wave-uniform, in scalar registers (loops over leaves are fully unrolled)
@@ -103,7 +108,9 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
       for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; D2 += dx*dx; }
       const double Dm = (sqrt(D2) - Rg)*(1.0 - 1e-12);
       const double Tn = g.rmax + fmax(Lm, Lr + khr);
-      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd) {
+      // gadget2: open if drsqd^2*amin*macerror < rmax^2*m; rm2 is that right-hand side (0 disables the test)
+      const double rm2 = gadget ? g.rmax*g.rmax*d.ccom[n].m : 0.0;
+      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd && !(gadget && (Dm*Dm)*(Dm*Dm)*Amin*P.macerror*(1.0 - 1e-12) < rm2)) {
         if (isleaf && g.N == 1) dirm = fm; else cellm = fm;
       }
       else {
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
             }
           }
           else if (g.N == 0) { }
-          else if (!(drsqd < g.cdistsqd)) {                         // !open_cell_for_gravity (geometric MAC)
+          else if (!(drsqd < g.cdistsqd) && !(gadget && drsqd*drsqd*s_lamin[l]*P.macerror < rm2)) {   // !open_cell_for_gravity
             if (isleaf && g.N == 1) dirm |= 1u << l;
             else cellm |= 1u << l;
           }
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
   if (*G.fallback) {                                    // a list overflowed: the fused kernel does this call
-    if (MP == 1 && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);     // ... which has no quadrupole terms: report it
+    if ((MP == 1 || P.mac != GH_MAC_GEOMETRIC) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);   // ... which has neither quadrupoles nor relative MACs: report it
     return;
   }
   const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
@@ -667,6 +674,9 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
   int cap_c = 4096, cap_d = 256, cap_h = 1024;
+  // small trees: a strict relative MAC (gadget2, small macerror) degenerates towards a direct sum, so let a leaf
+  // list every other leaf while that is cheap (<= 8192 leaves x 2048 entries x 4 B = 64 MB)
+  if (ctx->gtot <= 8192) cap_d = std::max(256, std::min(ctx->gtot, 2048));
   const int cap_g = 4096;
   if (const char *e = getenv("GH_GRAV_CAPS")) {       // test hook: tiny capacities force the overflow fallback
     int a = 0, b = 0, c = 0;
@@ -700,6 +710,8 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   gh_fill_eos(ctx, P.eos);
   P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
+  P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
+  const bool lists_only = ctx->cquad != nullptr || ctx->cfg.gravity_mac == GH_MAC_GADGET2;   // the fused fallback has neither
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -709,7 +721,9 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
   gh_phase_begin(ctx, GH_T_GRAV_WALK);
   if (ngroups > 0) {
-#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_grav_walk<ND_, KT_>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
+#define LAUNCH(ND_, KT_) \
+    if (P.mac == GH_MAC_GADGET2) hipLaunchKernelGGL((k_grav_walk<ND_, KT_, GH_MAC_GADGET2>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_grav_walk<ND_, KT_, GH_MAC_GEOMETRIC>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
@@ -731,7 +745,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   }
   // if a list overflowed the evaluation kernel did nothing; the fused kernel (forces.hip) then does the
   // whole call.  It checks the same word and returns at once otherwise - no host round trip.
-  int rc = ctx->cquad ? GH_OK : gh_grav_fused_launch(ctx, count, G.fallback);
+  int rc = lists_only ? GH_OK : gh_grav_fused_launch(ctx, count, G.fallback);
   gh_phase_end(ctx, GH_T_SPH_FORCES);
   if (rc) return rc;
   GH_CHECK(ctx, hipGetLastError());

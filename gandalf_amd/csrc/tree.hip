@@ -433,6 +433,16 @@ __device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double ke
       d.cquad[n] = cq;
       for (int k = 0; k < 5; k++) o.q[k] = cq.q[k];
     }
+    if (d.leaf_amin) {                               // cell.amin, KDTree.cpp:899-901 (read by the walk of THIS leaf)
+      double amin = BIG;
+      for (int i = first; i < first + cnt; i++) {
+        double a2 = d.f[D_ATX][i]*d.f[D_ATX][i];
+        if (d.ndim > 1) a2 += d.f[D_ATX + 1][i]*d.f[D_ATX + 1][i];
+        if (d.ndim > 2) a2 += d.f[D_ATX + 2][i]*d.f[D_ATX + 2][i];
+        amin = fmin(amin, sqrt(a2));
+      }
+      d.leaf_amin[n - (d.gtot - 1)] = amin;
+    }
   }
   else d.cgeo[n].hmax = hh.hmax;
   for (int k = 0; k < 3; k++) { o.hbmin[k] = hh.hbmin[k]; o.hbmax[k] = hh.hbmax[k]; }
@@ -577,7 +587,7 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   for (int f = 0; f < D_COUNT; f++) d.f[f] = ctx->fbuf[ctx->cur][f];
   d.iorig = ctx->iorig[ctx->cur];
   d.posm = ctx->posm; d.hrec = ctx->hrec;
-  d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom; d.cquad = ctx->cquad;
+  d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom; d.cquad = ctx->cquad; d.leaf_amin = ctx->leaf_amin;
   d.cfirst = ctx->cfirst; d.cN = ctx->cN;
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
@@ -624,6 +634,10 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
+  if (ctx->cfg.gravity_mac == GH_MAC_GADGET2 && ctx->cfg.self_gravity) {
+    GH_CHECK(ctx, re((void**) &ctx->leaf_amin, sizeof(double)*gtot));
+    GH_CHECK(ctx, hipMemsetAsync(ctx->leaf_amin, 0, sizeof(double)*gtot, ctx->stream));
+  }
   if (ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE && ctx->cfg.self_gravity) {
     GH_CHECK(ctx, re((void**) &ctx->cquad, sizeof(CellQuad)*Ncell));
     GH_CHECK(ctx, hipMemsetAsync(ctx->cquad, 0, sizeof(CellQuad)*Ncell, ctx->stream));

@@ -47,10 +47,12 @@ struct Cell {                                   // TreeCellBase, TreeCell.h:16-4
   int cnext, copen, level, ifirst, ilast, N, Nactive, c1, c2;
   FLOAT cdistsqd, bbmin[3], bbmax[3], hbmin[3], hbmax[3], rcell[3], r[3], v[3], m, rmax, hmax;
   FLOAT q[5];                                   // traceless quadrupole about r (multipole = quadrupole)
+  FLOAT amin;                                   // min |atree| of the cell's particles (gravity_mac = gadget2)
 };
 
 struct Params {
-  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole;
+  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac;
+  FLOAT macerror;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -282,6 +284,7 @@ struct KDTree {
     const bool need_quad = P->multipole == 1;
     FLOAT dr[3];
     for (int k = 0; k < 5; k++) c.q[k] = 0.0;
+    c.amin = big_number;
     c.Nactive = 0; c.N = 0; c.m = 0.0; c.hmax = 0.0; c.rmax = 0.0; c.cdistsqd = big_number;
     for (int k = 0; k < nd; k++) { c.r[k] = 0.0; c.v[k] = 0.0; c.rcell[k] = 0.0; c.bbmin[k] = big_number; c.bbmax[k] = -big_number;
                                    c.hbmin[k] = big_number; c.hbmax[k] = -big_number; }
@@ -292,6 +295,7 @@ struct KDTree {
         if (p[i].flags & F_ACTIVE) c.Nactive++;
         c.hmax = std::max(c.hmax, p[i].h);
         c.m += p[i].m;
+        if (P->gravity_mac == 1) c.amin = std::min(c.amin, (FLOAT) sqrt(Dot(p[i].atree, p[i].atree, nd)));   // KDTree.cpp:899-901
         for (int k = 0; k < nd; k++) c.r[k] += p[i].m*p[i].r[k];
         for (int k = 0; k < nd; k++) c.v[k] += p[i].m*p[i].v[k];
         for (int k = 0; k < nd; k++) {
@@ -328,6 +332,7 @@ struct KDTree {
           for (int k = 0; k < nd; k++) { c.bbmin[k] = std::min(ch[q]->bbmin[k], c.bbmin[k]); c.bbmax[k] = std::max(ch[q]->bbmax[k], c.bbmax[k]);
                                          c.hbmin[k] = std::min(ch[q]->hbmin[k], c.hbmin[k]); c.hbmax[k] = std::max(ch[q]->hbmax[k], c.hbmax[k]); }
           c.hmax = std::max(c.hmax, ch[q]->hmax);
+          c.amin = std::min(c.amin, ch[q]->amin);                    // KDTree.cpp:968, 982
         }
       }
       c.N = c1.N + c2.N; c.Nactive = c1.Nactive + c2.Nactive; c.m = c1.m + c2.m;
@@ -489,6 +494,7 @@ struct KDTree {
 // ---------------------------------------------------------------------------------------------
 struct Oracle {
   Params P; M4 kern; FLOAT invndim;
+  int mac_now;                          // MAC in force (geometric during the setup bootstrap, SphSimulation.cpp:381-388)
   std::vector<Part> p;          // [0,Nhydro) real, then periodic ghosts
   int Nhydro = 0, Nghost = 0;
   KDTree tree, ghosttree;
@@ -496,6 +502,7 @@ struct Oracle {
   std::string err;
   explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel & 1, (pp.kernel >> 1) & 1), invndim(1.0/pp.ndim) {
     tree.P = &P; ghosttree.P = &P; tree.kernrange = kern.kernrange; ghosttree.kernrange = kern.kernrange;
+    mac_now = P.gravity_mac;
   }
   FLOAT h_rho_func(FLOAT m, FLOAT rho) const { return P.h_fac*pow(m/rho, invndim); }   // Sph.h:259
   FLOAT h_rho_deriv(FLOAT h, FLOAT rho) const { return -invndim*h/rho; }               // Sph.h:264
@@ -719,6 +726,10 @@ struct Oracle {
       const FLOAT vsignal = pi.sound + nb.sound - P.beta_visc*P.alpha_visc*dvdr;      // mon97
       paux -= P.alpha_visc*vsignal*dvdr*winvrho;
       pi.dudt -= 0.5*nb.m*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;
+      // artificial conductivity, GradhSph.cpp:426-435 / 541-549
+      if (P.acond == 1) pi.dudt += nb.m*dvdr*(nb.u - pi.u)*(invrho_i*wkerni + invrho_j*wkernj);
+      else if (P.acond == 2)
+        pi.dudt += (FLOAT) 0.5*nb.m*(pi.u - nb.u)*winvrho*(invrho_i + invrho_j)*sqrt(fabs(pi.pressure - nb.pressure));
     }
     for (int k = 0; k < nd; k++) pi.a[k] += nb.m*dr[k]*paux;
     if (GRAV) {
@@ -776,7 +787,8 @@ struct Oracle {
           }
           else if (!GRAV) c = o.cnext;
           else if (o.N == 0) c = o.cnext;
-          else if (!(drsqd < o.cdistsqd)) {                          // !open_cell_for_gravity, Tree.h:413-432 (geometric)
+          else if (!(drsqd < o.cdistsqd) &&                          // !open_cell_for_gravity, Tree.h:413-432
+                   !(mac_now == 1 && drsqd*drsqd*cellc.amin*P.macerror < o.rmax*o.rmax*o.m)) {
             if (o.copen == -1 && o.N == 1) tempdirectneib.push_back(o.ifirst);
             else { MP m; for (int k = 0; k < 3; k++) m.r[k] = o.r[k]; m.m = o.m; for (int k = 0; k < 5; k++) m.q[k] = o.q[k]; gravcell.push_back(m); }
             c = o.cnext;
@@ -952,7 +964,12 @@ struct Oracle {
     for (int i = 0; i < Nhydro; i++) p[i].flags |= F_ACTIVE;
     const int npass = h_provided ? 2 : 3;
     for (int q = 0; q < npass; q++) { BuildTree(); DensityPass(); }
+    // relative MAC: first force pass geometric, tree rebuilt (stocks amin), second pass with the MAC (SphSimulation.cpp:381-473)
+    const bool relmac = P.self_gravity && P.gravity_mac != 0;
+    mac_now = 0;
     ZeroAccelerations(); Forces();
+    mac_now = P.gravity_mac;
+    if (relmac) { BuildTree(); ZeroAccelerations(); Forces(); }
     t = 0.0; n = 0;
     ComputeGlobalTimestep(); EndTimestep();
   }
@@ -1090,8 +1107,8 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole;
-  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac;
+  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror;
 };
 
 Oracle *orc_create(const orc_params *q)
@@ -1099,7 +1116,7 @@ Oracle *orc_create(const orc_params *q)
   Params P;
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
-  P.kernel = q->kernel; P.multipole = q->multipole;
+  P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
     P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];

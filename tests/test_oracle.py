@@ -10,12 +10,14 @@ from conftest import PARAMS, load_golden
 from gandalf_amd.params import read_params_file
 from oracle.pyoracle import Oracle
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2"]
 
 
 def make(case, g):
     o = Oracle(read_params_file("%s/%s.dat" % (PARAMS, case)), nthreads=4)
     o.set_particles(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    if "gadget2" in case:        # the relative MAC reads |atree| of the previous force pass when the tree is stocked
+        o.set("atree", g["setup_atree"])
     return o
 
 
@@ -61,6 +63,8 @@ def test_steps_bitwise(case):
     o.set_particles(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
     for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
         o.set(k, s(k))
+    if "setup_atree" in g:       # relative MAC: the first tree build stocks amin from the setup's atree
+        o.set("atree", s("atree"))
     t0, dt0 = s("t_timestep")
     o.set_time(float(t0), float(dt0))
     o.step(int(g["nsteps"][0]))
