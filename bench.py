@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="plummer1m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="estimate only (not a measurement of N GPUs): run rank 0 of a W-rank job on one GPU with the "
+                         "collectives skipped, to time the per-rank compute + pack/unpack of the sharded step")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +96,10 @@ def main():
     sim.set_param("device", local_rank)
     ic = sim.generate_ic()
     N = ic["r"].shape[0]
-    runner = multigpu.ShardedRunner(sim, rank, world)       # world == 1: plain single-GPU stepping
+    if args.simulate_world > 1 and world == 1:
+        runner = multigpu.ShardedRunner(sim, 0, args.simulate_world, simulate=True)
+    else:
+        runner = multigpu.ShardedRunner(sim, rank, world)       # world == 1: plain single-GPU stepping
     runner.setup()
 
     def sync():
@@ -168,6 +174,9 @@ def main():
             "phase_ms_per_step": {k: v/args.steps for k, v in timers.items()},
             "counters": {"density": dens, "forces": forc},
         }
+        if args.simulate_world > 1 and world == 1:
+            out["simulated_world"] = args.simulate_world
+            out["note"] = "ESTIMATE: rank 0 of a %d-rank job on one GPU, collectives skipped - not a measurement" % args.simulate_world
         cb = None if (args.no_cpu or world > 1) else cpu_baseline(args.workload)
         out["cpu_baseline"] = cb
         print(json.dumps(out))

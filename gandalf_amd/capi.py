@@ -82,6 +82,8 @@ SYMBOLS = {
     "gh_exchange_narrays": (C.c_int, [_CTX, C.c_int]),
     "gh_shard_pack": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_int64]),
     "gh_shard_unpack": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "gh_shard_unpack_all": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_int64]),
+    "gh_stream": (C.c_void_p, [_CTX]),
     "gh_update_hmax": (C.c_int, [_CTX]),
     "gh_step_begin": (C.c_int, [_CTX]),
     "gh_step_forces": (C.c_int, [_CTX]),
@@ -355,6 +357,13 @@ class GandalfHip:
 
     def shard_unpack(self, xset, rank, src_ptr, stride):
         self._chk(self.lib.gh_shard_unpack(self.ctx, xset, rank, C.c_void_p(src_ptr), stride))
+
+    def shard_unpack_all(self, xset, src_ptr, stride):
+        self._chk(self.lib.gh_shard_unpack_all(self.ctx, xset, C.c_void_p(src_ptr), int(stride)))
+
+    def stream_handle(self):
+        """hipStream_t of the context as an integer (for torch.cuda.ExternalStream)"""
+        return int(self.lib.gh_stream(self.ctx) or 0)
 
     def update_hmax(self):
         self._chk(self.lib.gh_update_hmax(self.ctx))

@@ -684,36 +684,85 @@ extern "C" int gh_exchange_narrays(gh_ctx *ctx, int set)
   return exchange_list(ctx, set, l);
 }
 
-static int shard_copy(gh_ctx *ctx, int set, int rank, void *buf, int64_t stride, bool pack)
+// pack / unpack kernels: one launch moves every array of the set (and, for unpack, every remote rank's slice);
+// everything is enqueued on the context's stream - the caller orders its collective after / before it
+struct ShardTab { double *fld[16]; long long first[GH_MAX_RANKS], count[GH_MAX_RANKS]; int nfld, nranks, self; };
+
+__global__ void k_shard_pack(ShardTab t, double *dst, long long stride)
 {
-  if (!ctx || !buf) return GH_ERR_INVALID;
-  int64_t first, count;
-  int rc = gh_shard_range(ctx, rank, &first, &count);
-  if (rc) return gh_fail(ctx, rc, "gh_shard_pack/unpack: no tree or bad rank");
-  if (count > stride) return gh_fail(ctx, GH_ERR_INVALID, "gh_shard_pack/unpack: stride smaller than the slice");
+  const int a = blockIdx.y;
+  const long long first = t.first[t.self], count = t.count[t.self];
+  for (long long i = blockIdx.x*(long long) blockDim.x + threadIdx.x; i < count; i += (long long) gridDim.x*blockDim.x)
+    dst[(size_t) a*stride + i] = t.fld[a][first + i];
+}
+
+// src layout: [rank][array][stride]
+__global__ void k_shard_unpack(ShardTab t, const double *src, long long stride, int only_rank)
+{
+  const int a = blockIdx.y;
+  for (int r = 0; r < t.nranks; r++) {
+    if (r == t.self || (only_rank >= 0 && r != only_rank)) continue;
+    const long long first = t.first[r], count = t.count[r];
+    const double *s = src + ((size_t) (only_rank >= 0 ? 0 : r)*t.nfld + a)*stride;
+    for (long long i = blockIdx.x*(long long) blockDim.x + threadIdx.x; i < count; i += (long long) gridDim.x*blockDim.x)
+      t.fld[a][first + i] = s[i];
+  }
+}
+
+static int shard_table(gh_ctx *ctx, int set, ShardTab &t, int64_t stride)
+{
+  if (ctx->nranks > GH_MAX_RANKS) return gh_fail(ctx, GH_ERR_INVALID, "more ranks than GH_MAX_RANKS");
   int l[16];
   const int n = exchange_list(ctx, set, l);
   if (n == 0) return gh_fail(ctx, GH_ERR_INVALID, "bad exchange set");
-  double *b = (double*) buf;
-  for (int a = 0; a < n; a++) {
-    double *fld = ctx->fbuf[ctx->cur][l[a]] + first;
-    if (pack) GH_CHECK(ctx, hipMemcpyAsync(b + (size_t) a*stride, fld, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
-    else GH_CHECK(ctx, hipMemcpyAsync(fld, b + (size_t) a*stride, sizeof(double)*(size_t) count, hipMemcpyDeviceToDevice, ctx->stream));
+  t.nfld = n; t.nranks = ctx->nranks; t.self = ctx->rank;
+  for (int a = 0; a < n; a++) t.fld[a] = ctx->fbuf[ctx->cur][l[a]];
+  for (int r = 0; r < ctx->nranks; r++) {
+    int64_t first, count;
+    const int rc = gh_shard_range(ctx, r, &first, &count);
+    if (rc) return gh_fail(ctx, rc, "gh_shard_pack/unpack: no tree or bad rank");
+    if (count > stride) return gh_fail(ctx, GH_ERR_INVALID, "gh_shard_pack/unpack: stride smaller than the slice");
+    t.first[r] = first; t.count[r] = count;
   }
-  if (!pack) gh_derive_after_unpack(ctx, set, first, count);
-  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
 }
 
 extern "C" int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride)
 {
-  return ctx ? shard_copy(ctx, set, ctx->rank, dst_dev, stride, true) : GH_ERR_INVALID;
+  if (!ctx || !dst_dev) return GH_ERR_INVALID;
+  ShardTab t;
+  int rc = shard_table(ctx, set, t, stride);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_shard_pack, dim3(256, t.nfld), dim3(256), 0, ctx->stream, t, (double*) dst_dev, (long long) stride);
+  GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
+}
+
+static int shard_unpack(gh_ctx *ctx, int set, int only_rank, const void *src_dev, int64_t stride)
+{
+  if (!ctx || !src_dev) return GH_ERR_INVALID;
+  ShardTab t;
+  int rc = shard_table(ctx, set, t, stride);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_shard_unpack, dim3(256, t.nfld), dim3(256), 0, ctx->stream, t, (const double*) src_dev, (long long) stride, only_rank);
+  for (int r = 0; r < ctx->nranks; r++)
+    if (r != ctx->rank && (only_rank < 0 || r == only_rank)) gh_derive_after_unpack(ctx, set, t.first[r], t.count[r]);
+  GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
 }
 
 extern "C" int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride)
 {
-  return shard_copy(ctx, set, rank, const_cast<void*>(src_dev), stride, false);
+  if (!ctx || rank < 0 || rank >= ctx->nranks) return GH_ERR_INVALID;
+  return shard_unpack(ctx, set, rank, src_dev, stride);
 }
+
+extern "C" int gh_shard_unpack_all(gh_ctx *ctx, int set, const void *src_dev, int64_t stride)
+{
+  return shard_unpack(ctx, set, -1, src_dev, stride);
+}
+
+extern "C" void *gh_stream(gh_ctx *ctx) { return ctx ? (void*) ctx->stream : nullptr; }
 
 extern "C" int gh_update_hmax(gh_ctx *ctx)
 {
@@ -733,7 +782,7 @@ extern "C" int gh_step_begin(gh_ctx *ctx)
   gh_phase_end(ctx, GH_T_KDK);
   if ((rc = build_tree_timed(ctx))) return rc;
   if ((rc = density_and_hmax(ctx, false))) return rc;
-  return gh_sync_collect(ctx, "gh_step_begin");
+  return ctx->nranks > 1 ? GH_OK : gh_sync_collect(ctx, "gh_step_begin");   // multi-rank: flags are read in gh_step_end
 }
 
 extern "C" int gh_step_forces(gh_ctx *ctx)
@@ -743,7 +792,7 @@ extern "C" int gh_step_forces(gh_ctx *ctx)
   if (ctx->nranks > 1) gh_update_hmax_impl(ctx);
   gh_zero_acc_impl(ctx);
   if ((rc = forces_impl(ctx))) return rc;
-  return gh_sync_collect(ctx, "gh_step_forces");
+  return ctx->nranks > 1 ? GH_OK : gh_sync_collect(ctx, "gh_step_forces");
 }
 
 extern "C" int gh_step_end(gh_ctx *ctx, double *t, double *timestep)

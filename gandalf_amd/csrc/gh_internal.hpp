@@ -138,6 +138,8 @@ struct gh_ctx {
   int rank = 0, nranks = 1;
 };
 
+#define GH_MAX_RANKS 16
+
 // kernel launch dispatch on (ndim, smoothing kernel): L(ND, KT) is the launch macro of the call site
 #define GH_DISPATCH(ctx, L)                                                                                  \
   if ((ctx)->cfg.kernel == GH_KERNEL_QUINTIC) {                                                               \

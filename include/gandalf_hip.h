@@ -203,10 +203,16 @@ int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count);
 enum { GH_X_DENSITY = 0, GH_X_FORCES = 1 };
 int gh_exchange_narrays(gh_ctx *ctx, int set);
 /* copy this rank's slice of every array of `set` into dst_dev[a*stride .. ) (device memory, doubles),
- * a = 0 .. narrays-1; stride >= the largest slice of any rank.  Synchronous. */
+ * a = 0 .. narrays-1; stride >= the largest slice of any rank.  Enqueued on the context's stream (gh_stream). */
 int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride);
-/* copy the slice of rank `rank` from src_dev (same layout) into the particle arrays.  Synchronous. */
+/* copy the slice of rank `rank` from src_dev ([array][stride]) into the particle arrays and recompute the
+ * fields derived from it.  Enqueued on the context's stream (gh_stream), like gh_shard_pack. */
 int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride);
+/* the same for every remote rank in one launch; src_dev is the all-gathered buffer [rank][array][stride] */
+int gh_shard_unpack_all(gh_ctx *ctx, int set, const void *src_dev, int64_t stride);
+/* the HIP stream (hipStream_t) every entry point enqueues on: a multi-GPU caller issues its collectives on
+ * it (or orders them against it), so that a step needs no host synchronisation between its sections */
+void *gh_stream(gh_ctx *ctx);
 /* replaces: KDTree::UpdateHmaxValues (KDTree.cpp:1128-1208).  gh_update_density calls it itself when
  * nranks == 1; with nranks > 1 the caller calls it after the density exchange. */
 int gh_update_hmax(gh_ctx *ctx);

@@ -48,6 +48,12 @@ class HostDevice:
         for k in range(self.narr):
             self.arr[k, a:a + c] = buf[k*stride:k*stride + c]
 
+    def shard_unpack_all(self, xset, src_ptr, stride):
+        """src: [rank][array][stride], as all_gather_into_tensor lays it out"""
+        for r in range(self.world):
+            if r != self.rank:
+                self.shard_unpack(xset, r, src_ptr + r*self.narr*stride*8, stride)
+
 
 def _worker(rank, world, port, n, narr, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
