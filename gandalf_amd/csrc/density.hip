@@ -24,6 +24,9 @@ struct DensityParams {
   EosParams eos;
   double h_fac, h_converge;
   const double *ktab; // kernel tables (tabulated_kernel = 1) or nullptr
+#ifdef GH_DEBUG_BLOCKTIME
+  double *dbg;        // [ngroups][8] per-group timing / work record (profiling builds only)
+#endif
   int group0;        // first group of this rank's shard
 };
 
@@ -38,12 +41,17 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
   __shared__ double s_x[DB*64], s_y[DB*64], s_z[DB*64], s_m[DB*64];   // a batch of DB candidate tiles
   __shared__ unsigned long long s_mask[DB][64];                       // per tile, per lane: entries in support
   __shared__ __attribute__((aligned(8))) float s_fx[64], s_fy[64], s_fz[64];  // current tile, fp32, relative to the group centre
+  __shared__ double s_lb[16][6], s_lhs[16], s_hl[64];                 // leaf boxes, per-leaf search h, lanes' h
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
+#ifdef GH_DEBUG_BLOCKTIME
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_tiles = 0, dbg_passes = 0;
+#endif
   const bool act = lane < gN;
   const int i = gfirst + (act ? lane : 0);
 
@@ -71,6 +79,12 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
     if (leafn == ln) leafmates = m;
   }
   double hmaxl = 1.05*d.ch[leafn].hmax;
+  const int nleaf = 1 << (d.ltot - d.lgroup);
+  const int leafnode0 = (d.gtot - 1) + (gnode - ((1 << d.lgroup) - 1))*nleaf;
+  if (lane < nleaf) {
+    const CellBox lbx = d.cbox[leafnode0 + lane];
+    for (int k = 0; k < 3; k++) { s_lb[lane][k] = lbx.bbmin[k]; s_lb[lane][3 + k] = lbx.bbmax[k]; }
+  }
 
   // per-lane iteration state (GradhSph.cpp:148-158)
   const double h0 = d.f[D_H][i];
@@ -102,6 +116,28 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       invhsqd = invh*invh;
       rho = 0.0; omg = 0.0; zet = 0.0;
     }
+    // Elongated groups (thin KD cells of a sparse halo that reach into a dense region) would stream every
+    // particle near their bounding box with the largest h of the group: there, cells are also culled against
+    // each leaf box with that leaf's own search radius (wave-uniform switch, below).
+    s_hl[lane] = running ? h : 0.0;
+    __syncthreads();
+    if (lane < nleaf) {
+      const int ln = leafnode0 + lane;
+      double hm = 0.0;
+      for (int j = d.cfirst[ln] - gfirst; j < d.cfirst[ln] - gfirst + d.cN[ln]; j++) hm = fmax(hm, s_hl[j]);
+      s_lhs[lane] = hm;
+    }
+    __syncthreads();
+    bool leafcull = false;
+    {
+      // switch it on when the search radii differ a lot inside the group or the group box is long compared with
+      // the smallest search radius - then the group-level box test lets through far more than the leaves need
+      const double hl = lane < nleaf ? s_lhs[lane] : 0.0;
+      const double hmx = wave_max(hl), hmn = wave_min(hl > 0.0 ? hl : 1e300);
+      double extmax = 0.0;
+      for (int k = 0; k < ND; k++) extmax = fmax(extmax, gb.bbmax[k] - gb.bbmin[k]);
+      leafcull = hmx > 1.3*hmn || extmax > 4.0*K::kernrange*hmn;
+    }
     const unsigned int codes = image_codes(P.dom, ND, lo, hi);
     const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
     auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
@@ -124,6 +160,24 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       // no particle of the cell can be within kernrange*hs of any particle of the group: the reference
       // would list it (box test) and sum zeros for it; skipping it changes nothing
       if (gap2 > rs2cut) return;
+      if (leafcull) {
+        bool any = false;
+        for (int l = 0; l < nleaf && !any; l++) {
+          const double hl = s_lhs[l];
+          if (hl > 0.0) {
+            double g2 = 0.0;
+            for (int k = 0; k < ND; k++) {
+              const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
+              const double gk = fmax(fmax(bmin - s_lb[l][3 + k], s_lb[l][k] - bmax), 0.0);
+              g2 += gk*gk;
+            }
+            const double rl = K::kernrange*hl;
+            any = g2 <= rl*rl*(1.0 + 1e-12);
+          }
+        }
+        if (!any) return;
+        inside = false;        // whole-subtree emission is a group-box shortcut: descend to the leaves instead
+      }
       if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = cn; }
       else open = true;
     };
@@ -208,10 +262,16 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           n_tested += 64;
         }
       }
+#ifdef GH_DEBUG_BLOCKTIME
+      dbg_tiles++;
+#endif
       nb++;
       if (nb == DB) process_batch();
       else __syncthreads();
     };
+#ifdef GH_DEBUG_BLOCKTIME
+    dbg_passes++;
+#endif
     walk_dfs_stream(d, L, codes, cls, tile, flags);
     process_batch();
 
@@ -244,6 +304,14 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
     }
   }
 
+#ifdef GH_DEBUG_BLOCKTIME
+  if (lane == 0 && P.dbg) {
+    double *o = P.dbg + (size_t) q*8;
+    o[0] = (double) (wall_clock64() - dbg_t0); o[1] = (double) dbg_tiles; o[2] = (double) dbg_passes; o[3] = (double) gN;
+    for (int k = 0; k < 3; k++) o[4 + k] = gb.bbmax[k] - gb.bbmin[k];
+    o[7] = d.ch[gnode].hmax;
+  }
+#endif
   // ---- normalise and store (GradhSph.cpp:262-317)
   if (act) {
     h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
@@ -307,6 +375,12 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
   P.h_fac = ctx->cfg.h_fac; P.h_converge = ctx->cfg.h_converge; P.ktab = ctx->ktab;
+#ifdef GH_DEBUG_BLOCKTIME
+  static double *dbgbuf = nullptr;
+  if (!dbgbuf) (void) hipMalloc((void**) &dbgbuf, sizeof(double)*8*(size_t) ctx->ngroups);
+  (void) hipMemset(dbgbuf, 0, sizeof(double)*8*(size_t) ctx->ngroups);
+  P.dbg = dbgbuf;
+#endif
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -321,6 +395,15 @@ int gh_density_impl(gh_ctx *ctx, bool count)
 #undef LAUNCH
   }
   gh_phase_end(ctx, GH_T_SPH_PROPERTIES);
+#ifdef GH_DEBUG_BLOCKTIME
+  if (const char *f = getenv("GH_DEBUG_BLOCKTIME_FILE")) {
+    std::vector<double> h((size_t) 8*ctx->ngroups);
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipMemcpy(h.data(), dbgbuf, sizeof(double)*h.size(), hipMemcpyDeviceToHost);
+    FILE *fp = fopen(f, "wb");
+    if (fp) { fwrite(h.data(), sizeof(double), h.size(), fp); fclose(fp); }
+  }
+#endif
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
