@@ -35,6 +35,9 @@ struct GravLists {
   int *len;                  // [gtot][3]
   int *fallback;             // set when a list overflowed: the fused kernel redoes the call
   int cap_c, cap_d, cap_h, cap_g;
+#ifdef GH_DEBUG_BLOCKTIME
+  double *dbgw, *dbge;       // per-group walk record [ngroups][8], per-leaf eval time [gtot]
+#endif
 };
 
 // ================================================================================================
@@ -53,6 +56,10 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   if (d.cN[gnode] == 0) return;
+#ifdef GH_DEBUG_BLOCKTIME
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_steps = 0, dbg_perleaf = 0;
+#endif
   const int nl = 1 << (d.ltot - d.lgroup);
   const int leaf0 = d.gtot - 1;
   const int leafnode0 = leaf0 + q*nl;
@@ -92,6 +99,9 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
   while (top > 0) {
     const int p = pop_width(top);
     const int newtop = top - p;
+#ifdef GH_DEBUG_BLOCKTIME
+    dbg_steps++;
+#endif
     unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
     int n = 0; bool isleaf = false;
     CellGeo g;
@@ -199,6 +209,13 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
     }
     __syncthreads();
   }
+#ifdef GH_DEBUG_BLOCKTIME
+  if (lane == 0 && G.dbgw) {
+    double *o = G.dbgw + (size_t) q*8;
+    o[0] = (double) (wall_clock64() - dbg_t0); o[1] = (double) dbg_steps; o[2] = (double) len_g; o[3] = (double) len_c[0];
+    o[4] = (double) len_h[0]; o[5] = (double) len_d[0]; o[6] = Rg; o[7] = gg.hmax;
+  }
+#endif
   if (__any(overflow) && lane == 0) atomicOr(G.fallback, 1);
   if (lane == 0) G.glen[q] = min(len_g, G.cap_g);
   if (lane == 0) {
@@ -336,6 +353,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     return;
   }
   const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
+#ifdef GH_DEBUG_BLOCKTIME
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   const int node = (d.gtot - 1) + gl;
   const int first = d.cfirst[node], Nt = d.cN[node];
   if (Nt == 0) return;
@@ -660,6 +680,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     d.f[D_DUDT][i] += dudt;
     d.f[D_DIV_V][i] += div_v;
   }
+#ifdef GH_DEBUG_BLOCKTIME
+  if (lane == 0 && G.dbge) G.dbge[gl] = (double) (wall_clock64() - dbg_t0);
+#endif
   if (COUNT && lane == 0) {
     atomicAdd(&stats[ST_CELLS], n_cells);
     atomicAdd(&stats[ST_PAIRS], n_pairs);
@@ -704,6 +727,12 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   GH_CHECK(ctx, hipMemsetAsync(G.fallback, 0, sizeof(int), ctx->stream));
   G.cap_c = cap_c; G.cap_d = cap_d; G.cap_h = cap_h; G.cap_g = cap_g;
   G.gcells = ctx->gl_gcells; G.glen = ctx->gl_glen;
+#ifdef GH_DEBUG_BLOCKTIME
+  static double *dbgw = nullptr, *dbge = nullptr;
+  if (!dbgw) { (void) hipMalloc((void**) &dbgw, sizeof(double)*8*(size_t) ctx->ngroups); (void) hipMalloc((void**) &dbge, sizeof(double)*(size_t) ctx->gtot); }
+  (void) hipMemset(dbgw, 0, sizeof(double)*8*(size_t) ctx->ngroups); (void) hipMemset(dbge, 0, sizeof(double)*(size_t) ctx->gtot);
+  G.dbgw = dbgw; G.dbge = dbge;
+#endif
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
   gh_fill_domain(ctx, P.dom);
@@ -745,6 +774,18 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   }
   // if a list overflowed the evaluation kernel did nothing; the fused kernel (forces.hip) then does the
   // whole call.  It checks the same word and returns at once otherwise - no host round trip.
+#ifdef GH_DEBUG_BLOCKTIME
+  if (const char *f = getenv("GH_DEBUG_BLOCKTIME_FILE")) {
+    std::vector<double> hw((size_t) 8*ctx->ngroups), he((size_t) ctx->gtot);
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipMemcpy(hw.data(), dbgw, sizeof(double)*hw.size(), hipMemcpyDeviceToHost);
+    (void) hipMemcpy(he.data(), dbge, sizeof(double)*he.size(), hipMemcpyDeviceToHost);
+    std::string fn = std::string(f) + ".walk";
+    FILE *fp = fopen(fn.c_str(), "wb"); if (fp) { fwrite(hw.data(), 8, hw.size(), fp); fclose(fp); }
+    fn = std::string(f) + ".eval";
+    fp = fopen(fn.c_str(), "wb"); if (fp) { fwrite(he.data(), 8, he.size(), fp); fclose(fp); }
+  }
+#endif
   int rc = lists_only ? GH_OK : gh_grav_fused_launch(ctx, count, G.fallback);
   gh_phase_end(ctx, GH_T_SPH_FORCES);
   if (rc) return rc;

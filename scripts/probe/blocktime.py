@@ -23,3 +23,16 @@ for g in order:
     print("group %6d  %8.1f us  tiles %6d  passes %2d  N %2d  ext %.3g %.3g %.3g  hmax %.3g" % (g, t[g], a[g, 1], a[g, 2], a[g, 3], a[g, 4], a[g, 5], a[g, 6], a[g, 7]))
 h, e = np.histogram(t, bins=[0, 20, 40, 60, 80, 100, 150, 200, 300, 500, 1000, 1e9])
 print("histogram (us):", list(zip(e[:-1].astype(int), h)))
+
+if int(sim.get_param("self_gravity")):
+    dev.zero_accelerations()
+    dev.update_forces()
+    w = np.fromfile("/tmp/blocktime.bin.walk").reshape(-1, 8)
+    tw = w[:, 0]/100.0
+    print("WALK groups", len(tw), "mean", tw.mean(), "median", np.median(tw), "p99", np.percentile(tw, 99), "max", tw.max(), " steps mean", w[:, 1].mean(), "max", w[:, 1].max())
+    for g in np.argsort(-tw)[:10]:
+        print("  group %6d %8.1f us steps %5d glen %5d len_c0 %5d len_h0 %5d len_d0 %4d Rg %.3g hmax %.3g" % (g, tw[g], w[g, 1], w[g, 2], w[g, 3], w[g, 4], w[g, 5], w[g, 6], w[g, 7]))
+    print("  histogram (us):", np.histogram(tw, bins=[0, 50, 100, 150, 200, 300, 500, 1000, 1e9])[0])
+    e = np.fromfile("/tmp/blocktime.bin.eval")/100.0
+    print("EVAL leaves", len(e), "mean", e.mean(), "median", np.median(e), "p99", np.percentile(e, 99), "max", e.max())
+    print("  histogram (us):", np.histogram(e, bins=[0, 20, 40, 60, 80, 100, 150, 200, 300, 500, 1e9])[0])
