@@ -16,7 +16,10 @@ def vec_err(a, b):
     return np.max(np.linalg.norm(a - b, axis=1)/np.maximum(nb, nb.mean()))
 
 
-@pytest.mark.parametrize("case,n", [("box3d_4k", 32768), ("plummer_4k", 16384)])
+# ragged sizes: 30000 -> leaves of 3-4 particles, uneven cell splits; 10007 (prime) -> leaves of 4-5 particles, i.e.
+# the 6-wide evaluation kernel; 3001 in 2-D (quadrupole, gadget2 bootstrap are covered by the fixtures)
+@pytest.mark.parametrize("case,n", [("box3d_4k", 32768), ("plummer_4k", 16384), ("box3d_4k", 30000),
+                                    ("plummer_4k", 10007), ("plummer_4k_quadrupole", 9001)])
 def test_setup_and_steps_vs_oracle(case, n):
     """whole PostInitialConditionsSetup + 2 MainLoop steps from the raw IC, HIP vs oracle"""
     from gandalf_amd.host import Simulation
