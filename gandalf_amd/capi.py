@@ -129,7 +129,7 @@ _ENUMS = {
     "avisc": {"none": 0, "mon97": 1},
     "acond": {"none": 0, "wadsley2008": 1, "price2008": 2},
     "multipole": {"monopole": 0, "quadrupole": 1},
-    "gravity_mac": {"geometric": 0, "gadget2": 1},
+    "gravity_mac": {"geometric": 0, "gadget2": 1, "eigenmac": 2},
 }
 
 

@@ -43,7 +43,7 @@ struct alignas(64) CellGeo {       // gravity walk
   double cdistsqd;                 // max(rmax^2, hmax^2)/thetamaxsqd at stock time
   double hmax;                     // copy of CellH::hmax
   int first, N;
-  double pad;
+  double mac;                      // eigenvalue MAC length^2 (gravity_mac = eigenmac; KDTree.cpp:1054-1076), else 0
 };
 struct alignas(32) CellCom {       // accepted cells only
   double com[3];                   // centre of mass
@@ -65,7 +65,9 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   CellGeo *cgeo;
   CellCom *ccom;
   CellQuad *cquad;                 // nullptr unless multipole = quadrupole
-  double *leaf_amin;               // [gtot] min |atree| of each leaf at stock time (gravity_mac = gadget2), or nullptr
+  double *leaf_amin;               // [gtot] per-leaf factor of the relative MACs at stock time: min |atree| (gadget2) or
+                                   // max gpot^(-2/3) (eigenmac); nullptr for the geometric MAC
+  double macerror; int mac_stock;  // what the stocking kernels need of the MAC
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
 };

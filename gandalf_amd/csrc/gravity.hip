@@ -66,26 +66,27 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
 
   unsigned int allmask = 0;
   const CellGeo gg = d.cgeo[gnode];
-  constexpr bool gadget = MAC == GH_MAC_GADGET2;        // relative MAC of open_cell_for_gravity, Tree.h:413-432
-  double Rg = 0.0, Lm = 0.0, Lr = 0.0, Amin = 0.0;
+  constexpr bool gadget = MAC == GH_MAC_GADGET2;        // relative MACs of open_cell_for_gravity, Tree.h:413-432
+  constexpr bool eigen = MAC == GH_MAC_EIGENMAC;
+  double Rg = 0.0, Lm = 0.0, Lr = 0.0, Amin = 0.0, Amax = 0.0;
   {
-    double rg = 0.0, lm = 0.0, lr = 0.0, amn = 9.9e20;
+    double rg = 0.0, lm = 0.0, lr = 0.0, amn = 9.9e20, amx = 0.0;
     if (lane < nl) {
       const CellGeo g = d.cgeo[leafnode0 + lane];
       for (int k = 0; k < 3; k++) s_lrc[lane][k] = g.rcell[k];
       s_lrmax[lane] = g.rmax;
       s_lhr[lane] = K::kernrange*g.hmax;
-      const double am = gadget ? d.leaf_amin[q*nl + lane] : 0.0;
+      const double am = (gadget || eigen) ? d.leaf_amin[q*nl + lane] : 0.0;
       s_lamin[lane] = am;
       if (g.N > 0) {
         double dd = 0.0;
         for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; dd += dx*dx; }
         rg = sqrt(dd); lm = g.rmax + K::kernrange*g.hmax; lr = g.rmax;
-        amn = am;
+        amn = am; amx = am;
       }
     }
     Rg = wave_max(rg)*(1.0 + 1e-12); Lm = wave_max(lm); Lr = wave_max(lr);
-    Amin = wave_min(amn);
+    Amin = wave_min(amn); Amax = wave_max(amx);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
   // list lengths: wave-uniform, in scalar registers (loops over leaves are fully unrolled)
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
       const double Tn = g.rmax + fmax(Lm, Lr + khr);
       // gadget2: open if drsqd^2*amin*macerror < rmax^2*m; rm2 is that right-hand side (0 disables the test)
       const double rm2 = gadget ? g.rmax*g.rmax*d.ccom[n].m : 0.0;
-      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd && !(gadget && (Dm*Dm)*(Dm*Dm)*Amin*P.macerror*(1.0 - 1e-12) < rm2)) {
+      // eigenmac: open if drsqd < cell.mac*macfactor(leaf); the group bound uses the largest factor
+      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd && !(gadget && (Dm*Dm)*(Dm*Dm)*Amin*P.macerror*(1.0 - 1e-12) < rm2) &&
+          !(eigen && !((Dm*Dm)*(1.0 - 1e-12) >= g.mac*Amax))) {
         if (isleaf && g.N == 1) dirm = fm; else cellm = fm;
       }
       else {
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
             }
           }
           else if (g.N == 0) { }
-          else if (!(drsqd < g.cdistsqd) && !(gadget && drsqd*drsqd*s_lamin[l]*P.macerror < rm2)) {   // !open_cell_for_gravity
+          else if (!(drsqd < g.cdistsqd) && !(gadget && drsqd*drsqd*s_lamin[l]*P.macerror < rm2) &&
+                   !(eigen && drsqd < g.mac*s_lamin[l])) {                                          // !open_cell_for_gravity
             if (isleaf && g.N == 1) dirm |= 1u << l;
             else cellm |= 1u << l;
           }
@@ -740,7 +744,8 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
-  const bool lists_only = ctx->cquad != nullptr || ctx->cfg.gravity_mac == GH_MAC_GADGET2;   // the fused fallback has neither
+  const bool quadf = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE;
+  const bool lists_only = quadf || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -752,6 +757,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   if (ngroups > 0) {
 #define LAUNCH(ND_, KT_) \
     if (P.mac == GH_MAC_GADGET2) hipLaunchKernelGGL((k_grav_walk<ND_, KT_, GH_MAC_GADGET2>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags); \
+    else if (P.mac == GH_MAC_EIGENMAC) hipLaunchKernelGGL((k_grav_walk<ND_, KT_, GH_MAC_EIGENMAC>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags); \
     else hipLaunchKernelGGL((k_grav_walk<ND_, KT_, GH_MAC_GEOMETRIC>), dim3(ngroups), dim3(64), 0, s, d, P, G, ctx->d_flags);
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
@@ -767,7 +773,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
       if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
       else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
-#define LAUNCH(ND_, KT_) if (ctx->cquad) { LAUNCHM(ND_, KT_, 1) } else { LAUNCHM(ND_, KT_, 0) }
+#define LAUNCH(ND_, KT_) if (quadf) { LAUNCHM(ND_, KT_, 1) } else { LAUNCHM(ND_, KT_, 0) }
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCHM
 #undef LAUNCH

@@ -362,6 +362,22 @@ __device__ __forceinline__ void add_quad(double *q, double mi, const double *dr,
   if (nd > 2) { q[3] += mi*3.0*dr[2]*dr[0]; q[4] += mi*3.0*dr[2]*dr[1]; }
 }
 
+// cell.mac of the eigenvalue MAC from the cell's quadrupole (KDTree.cpp:1054-1076)
+__device__ __forceinline__ double eigen_mac(const double *q, int nd, double macerror)
+{
+  double lambda;
+  if (nd == 3) {
+    const double p = q[0]*q[2] - (q[0] + q[2])*(q[0] + q[2]) - q[1]*q[1] - q[3]*q[3] - q[4]*q[4];
+    lambda = p >= 0.0 ? 0.0 : 2.0*sqrt(-p/3.0);
+  }
+  else if (nd == 2) {
+    const double p = (q[0] - q[2])*(q[0] - q[2]) + 4*q[1]*q[1];
+    lambda = 0.5*fmax(q[0] + q[2] + sqrt(p), 0.);
+  }
+  else lambda = fabs(q[0]);
+  return pow(0.5*lambda/macerror, 0.66666666666666);
+}
+
 // what a parent needs of a child (held in LDS between the levels of one fused launch)
 struct SRec {
   double hbmin[3], hbmax[3], hmax;
@@ -395,7 +411,7 @@ __device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double ke
   for (int k = 0; k < 3; k++) { hh.hbmin[k] = BIG; hh.hbmax[k] = -BIG; }
   CellBox b; CellGeo c; CellCom cm;
   if (!hmax_only) {
-    cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.pad = 0.0; b.pad = 0.0;
+    cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.mac = 0.0; b.pad = 0.0;
     for (int k = 0; k < 3; k++) { cm.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
     c.first = first; c.N = cnt; b.first = first; b.N = cnt;
   }
@@ -432,8 +448,9 @@ __device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double ke
       }
       d.cquad[n] = cq;
       for (int k = 0; k < 5; k++) o.q[k] = cq.q[k];
+      if (d.mac_stock == GH_MAC_EIGENMAC) d.cgeo[n].mac = eigen_mac(cq.q, d.ndim, d.macerror);
     }
-    if (d.leaf_amin) {                               // cell.amin, KDTree.cpp:899-901 (read by the walk of THIS leaf)
+    if (d.leaf_amin && d.mac_stock == GH_MAC_GADGET2) {   // cell.amin, KDTree.cpp:899-901 (read by the walk of THIS leaf)
       double amin = BIG;
       for (int i = first; i < first + cnt; i++) {
         double a2 = d.f[D_ATX][i]*d.f[D_ATX][i];
@@ -442,6 +459,11 @@ __device__ __forceinline__ void stock_leaf(const DevicePtrs &d, int n, double ke
         amin = fmin(amin, sqrt(a2));
       }
       d.leaf_amin[n - (d.gtot - 1)] = amin;
+    }
+    if (d.leaf_amin && d.mac_stock == GH_MAC_EIGENMAC) {  // cell.macfactor, KDTree.cpp:902-903
+      double mf = 0.0;
+      for (int i = first; i < first + cnt; i++) mf = fmax(mf, pow(d.f[D_GPOT][i], -0.66666666666666666666666));
+      d.leaf_amin[n - (d.gtot - 1)] = mf;
     }
   }
   else d.cgeo[n].hmax = hh.hmax;
@@ -475,7 +497,7 @@ __device__ __forceinline__ void stock_combine(const DevicePtrs &d, int n, const 
   o.N = d.cN[n];
   if (hmax_only) { d.cgeo[n].hmax = hh.hmax; return; }
   CellBox b; CellGeo c; CellCom cm;
-  cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.pad = 0.0; b.pad = 0.0;
+  cm.m = 0.0; c.rmax = 0.0; c.cdistsqd = BIG; c.mac = 0.0; b.pad = 0.0;
   for (int k = 0; k < 3; k++) { cm.com[k] = 0.0; c.rcell[k] = 0.0; b.bbmin[k] = BIG; b.bbmax[k] = -BIG; }
   c.first = d.cfirst[n]; c.N = o.N; b.first = c.first; b.N = c.N;
   if (r1.N > 0) _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) { b.bbmin[k] = fmin(r1.bbmin[k], b.bbmin[k]); b.bbmax[k] = fmax(r1.bbmax[k], b.bbmax[k]); }
@@ -506,6 +528,7 @@ __device__ __forceinline__ void stock_combine(const DevicePtrs &d, int n, const 
     }
     d.cquad[n] = cq;
     for (int k = 0; k < 5; k++) o.q[k] = cq.q[k];
+    if (d.mac_stock == GH_MAC_EIGENMAC) d.cgeo[n].mac = eigen_mac(cq.q, d.ndim, d.macerror);
   }
 }
 
@@ -588,6 +611,7 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   d.iorig = ctx->iorig[ctx->cur];
   d.posm = ctx->posm; d.hrec = ctx->hrec;
   d.cbox = ctx->cbox; d.ch = ctx->ch; d.cgeo = ctx->cgeo; d.ccom = ctx->ccom; d.cquad = ctx->cquad; d.leaf_amin = ctx->leaf_amin;
+  d.macerror = ctx->cfg.macerror; d.mac_stock = ctx->cfg.self_gravity ? ctx->cfg.gravity_mac : GH_MAC_GEOMETRIC;
   d.cfirst = ctx->cfirst; d.cN = ctx->cN;
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
@@ -634,11 +658,11 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
-  if (ctx->cfg.gravity_mac == GH_MAC_GADGET2 && ctx->cfg.self_gravity) {
+  if (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.self_gravity) {
     GH_CHECK(ctx, re((void**) &ctx->leaf_amin, sizeof(double)*gtot));
     GH_CHECK(ctx, hipMemsetAsync(ctx->leaf_amin, 0, sizeof(double)*gtot, ctx->stream));
   }
-  if (ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE && ctx->cfg.self_gravity) {
+  if ((ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.gravity_mac == GH_MAC_EIGENMAC) && ctx->cfg.self_gravity) {
     GH_CHECK(ctx, re((void**) &ctx->cquad, sizeof(CellQuad)*Ncell));
     GH_CHECK(ctx, hipMemsetAsync(ctx->cquad, 0, sizeof(CellQuad)*Ncell, ctx->stream));
   }

@@ -48,6 +48,7 @@ struct Cell {                                   // TreeCellBase, TreeCell.h:16-4
   FLOAT cdistsqd, bbmin[3], bbmax[3], hbmin[3], hbmax[3], rcell[3], r[3], v[3], m, rmax, hmax;
   FLOAT q[5];                                   // traceless quadrupole about r (multipole = quadrupole)
   FLOAT amin;                                   // min |atree| of the cell's particles (gravity_mac = gadget2)
+  FLOAT macfactor, mac;                         // eigenmac: max gpot^(-2/3) of the particles; eigenvalue length^2
 };
 
 struct Params {
@@ -281,10 +282,10 @@ struct KDTree {
   }
   void StockCellProperties(Cell &c, const std::vector<Part> &p) {   // KDTree.cpp:808-1083 (geometric MAC)
     const int nd = P->ndim;
-    const bool need_quad = P->multipole == 1;
+    const bool need_quad = P->multipole == 1 || P->gravity_mac == 2;
     FLOAT dr[3];
     for (int k = 0; k < 5; k++) c.q[k] = 0.0;
-    c.amin = big_number;
+    c.amin = big_number; c.macfactor = 0; c.mac = 0.0;
     c.Nactive = 0; c.N = 0; c.m = 0.0; c.hmax = 0.0; c.rmax = 0.0; c.cdistsqd = big_number;
     for (int k = 0; k < nd; k++) { c.r[k] = 0.0; c.v[k] = 0.0; c.rcell[k] = 0.0; c.bbmin[k] = big_number; c.bbmax[k] = -big_number;
                                    c.hbmin[k] = big_number; c.hbmax[k] = -big_number; }
@@ -296,6 +297,7 @@ struct KDTree {
         c.hmax = std::max(c.hmax, p[i].h);
         c.m += p[i].m;
         if (P->gravity_mac == 1) c.amin = std::min(c.amin, (FLOAT) sqrt(Dot(p[i].atree, p[i].atree, nd)));   // KDTree.cpp:899-901
+        else if (P->gravity_mac == 2) c.macfactor = std::max(c.macfactor, (FLOAT) pow(p[i].gpot, -twothirds));
         for (int k = 0; k < nd; k++) c.r[k] += p[i].m*p[i].r[k];
         for (int k = 0; k < nd; k++) c.v[k] += p[i].m*p[i].v[k];
         for (int k = 0; k < nd; k++) {
@@ -333,6 +335,7 @@ struct KDTree {
                                          c.hbmin[k] = std::min(ch[q]->hbmin[k], c.hbmin[k]); c.hbmax[k] = std::max(ch[q]->hbmax[k], c.hbmax[k]); }
           c.hmax = std::max(c.hmax, ch[q]->hmax);
           c.amin = std::min(c.amin, ch[q]->amin);                    // KDTree.cpp:968, 982
+          c.macfactor = std::max(c.macfactor, ch[q]->macfactor);
         }
       }
       c.N = c1.N + c2.N; c.Nactive = c1.Nactive + c2.Nactive; c.m = c1.m + c2.m;
@@ -355,6 +358,16 @@ struct KDTree {
           AddQuad(c.q, ch[q]->m, dr, nd);
         }
       }
+    }
+    if (P->gravity_mac == 2) {                                       // KDTree.cpp:1054-1076
+      FLOAT lambda, pp;
+      if (nd == 3) {
+        pp = c.q[0]*c.q[2] - (c.q[0] + c.q[2])*(c.q[0] + c.q[2]) - c.q[1]*c.q[1] - c.q[3]*c.q[3] - c.q[4]*c.q[4];
+        if (pp >= (FLOAT) 0.0) lambda = 0; else lambda = (FLOAT) 2.0*sqrt(-pp/(FLOAT) 3.0);
+      }
+      else if (nd == 2) { pp = (c.q[0] - c.q[2])*(c.q[0] - c.q[2]) + 4*c.q[1]*c.q[1]; lambda = 0.5*std::max(c.q[0] + c.q[2] + sqrt(pp), 0.); }
+      else lambda = fabs(c.q[0]);
+      c.mac = pow((FLOAT) 0.5*lambda/P->macerror, (FLOAT) 0.66666666666666);
     }
   }
   void DivideTreeCell(int first, int last, const std::vector<Part> &p, Cell &c) {   // KDTree.cpp:442-595
@@ -788,7 +801,8 @@ struct Oracle {
           else if (!GRAV) c = o.cnext;
           else if (o.N == 0) c = o.cnext;
           else if (!(drsqd < o.cdistsqd) &&                          // !open_cell_for_gravity, Tree.h:413-432
-                   !(mac_now == 1 && drsqd*drsqd*cellc.amin*P.macerror < o.rmax*o.rmax*o.m)) {
+                   !(mac_now == 1 && drsqd*drsqd*cellc.amin*P.macerror < o.rmax*o.rmax*o.m) &&
+                   !(mac_now == 2 && drsqd < o.mac*cellc.macfactor)) {
             if (o.copen == -1 && o.N == 1) tempdirectneib.push_back(o.ifirst);
             else { MP m; for (int k = 0; k < 3; k++) m.r[k] = o.r[k]; m.m = o.m; for (int k = 0; k < 5; k++) m.q[k] = o.q[k]; gravcell.push_back(m); }
             c = o.cnext;

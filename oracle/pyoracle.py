@@ -76,7 +76,7 @@ class Oracle:
         q.multipole = 1 if p.get("multipole", "quadrupole") == "quadrupole" else 0
         assert p.get("avisc", "mon97") == "mon97"
         q.acond = {"none": 0, "wadsley2008": 1, "price2008": 2}[p.get("acond", "none")]
-        q.gravity_mac = {"geometric": 0, "gadget2": 1}[p.get("gravity_mac", "geometric")]
+        q.gravity_mac = {"geometric": 0, "gadget2": 1, "eigenmac": 2}[p.get("gravity_mac", "geometric")]
         q.macerror = float(p.get("macerror", 0.0001))
         self.L, self.ndim, self.N = L, q.ndim, 0
         self.h = C.c_void_p(L.orc_create(C.byref(q)))

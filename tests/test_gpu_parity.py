@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac"]
 
 
 def make(case):
@@ -84,8 +84,9 @@ def test_density_and_forces_match_reference(case):
     g = load_golden(case + "_passes")
     sim, p = make(case)
     sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
-    if "gadget2" in case:        # the relative MAC reads |atree| of the previous force pass when the tree is stocked
+    if "gadget2" in case or "eigenmac" in case:        # the relative MAC reads |atree| of the previous force pass when the tree is stocked
         sim.upload_field("atree", g["setup_atree"])
+        sim.upload_field("gpot", g["setup_gpot"])    # eigenmac: max gpot^(-2/3) per leaf
     sim.build_tree()
     st = sim.update_density(stats=True)
     assert st["n_iterations"] >= st["n_particles"]
@@ -129,6 +130,7 @@ def test_steps_match_reference(case):
         sim.upload_field(k, s(k))
     if "setup_atree" in g:       # relative MAC: the first tree build stocks amin from the setup's atree
         sim.upload_field("atree", s("atree"))
+        sim.upload_field("gpot", s("gpot"))
     t0, dt0 = s("t_timestep")
     sim.set_time(float(t0), float(dt0))
     t, dt = sim.step(int(g["nsteps"][0]))

@@ -10,14 +10,15 @@ from conftest import PARAMS, load_golden
 from gandalf_amd.params import read_params_file
 from oracle.pyoracle import Oracle
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac"]
 
 
 def make(case, g):
     o = Oracle(read_params_file("%s/%s.dat" % (PARAMS, case)), nthreads=4)
     o.set_particles(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
-    if "gadget2" in case:        # the relative MAC reads |atree| of the previous force pass when the tree is stocked
+    if "gadget2" in case or "eigenmac" in case:        # the relative MAC reads |atree| of the previous force pass when the tree is stocked
         o.set("atree", g["setup_atree"])
+        o.set("gpot", g["setup_gpot"])          # eigenmac: max gpot^(-2/3) per leaf
     return o
 
 
@@ -65,6 +66,7 @@ def test_steps_bitwise(case):
         o.set(k, s(k))
     if "setup_atree" in g:       # relative MAC: the first tree build stocks amin from the setup's atree
         o.set("atree", s("atree"))
+        o.set("gpot", s("gpot"))
     t0, dt0 = s("t_timestep")
     o.set_time(float(t0), float(dt0))
     o.step(int(g["nsteps"][0]))
