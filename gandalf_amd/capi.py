@@ -140,9 +140,7 @@ def config_from_params(p, device=0):
     c.ndim = nd
     c.kernel = _ENUMS["kernel"][p.get("kernel", "m4")]
     if int(p.get("tabulated_kernel", 0)) != 0:
-        if p.get("kernel", "m4") != "m4":
-            raise ValueError("tabulated_kernel = 1 is built for kernel = m4 only; set tabulated_kernel = 0")
-        c.kernel = 2                      # GH_KERNEL_M4_TAB
+        c.kernel = 3 if p.get("kernel", "m4") == "quintic" else 2     # GH_KERNEL_QUINTIC_TAB / GH_KERNEL_M4_TAB
     c.gas_eos = _ENUMS["gas_eos"][p.get("gas_eos", "energy_eqn")]
     c.avisc = _ENUMS["avisc"][p.get("avisc", "mon97")]
     c.acond = _ENUMS["acond"][p.get("acond", "none")]

@@ -133,15 +133,50 @@ struct HostM4 {            // M4Kernel functions as the reference writes them (S
     return 1.0/s;
   }
 };
-}
-
-static int gh_build_kernel_tables(gh_ctx *ctx)
+struct HostQuintic {       // QuinticKernel functions as the reference writes them (SmoothingKernel.h:281-408)
+  int nd; double norm;
+  explicit HostQuintic(int nd_) : nd(nd_) { norm = nd == 1 ? (1.0/120.0) : (nd == 2 ? GH_INVPI*(7.0/478.0) : GH_INVPI*(1/120.)); }
+  double w0(double s) const {
+    if (s < 1.0) return norm*(66.0 - 60.0*s*s + 30.0*std::pow(s,4) - 10.0*std::pow(s,5));
+    if (s < 2.0) return norm*(51.0 + 75.0*s - 210.0*s*s + 150.0*std::pow(s,3) - 45.0*std::pow(s,4) + 5.0*std::pow(s,5));
+    if (s < 3.0) return norm*(243.0 - 405*s + 270.0*s*s - 90.0*std::pow(s,3) + 15.0*std::pow(s,4) - std::pow(s,5));
+    return 0.0;
+  }
+  double w1(double s) const {
+    if (s < 1.0) return norm*(-120.0*s + 120.0*std::pow(s,3) - 50.0*std::pow(s,4));
+    if (s < 2.0) return norm*(75.0 - 420.0*s + 450.0*s*s - 180.0*std::pow(s,3) + 25.0*std::pow(s,4));
+    if (s < 3.0) return norm*(-405.0 + 540.0*s - 270.0*s*s + 60.0*std::pow(s,3) - 5.0*std::pow(s,4));
+    return 0.0;
+  }
+  double womega(double s) const {
+    if (s < 1.0) return norm*(-66.0*nd + 60.0*(nd + 2.0)*s*s - 30.0*(nd + 4.0)*std::pow(s,4) + 10.0*(nd + 5.0)*std::pow(s,5));
+    if (s < 2.0) return norm*(-51.0*nd - 75.0*(nd + 1.0)*s + 210.0*(nd + 2.0)*s*s - 150.0*(nd + 3.0)*std::pow(s,3) + 45.0*(nd + 4.0)*std::pow(s,4) - 5.0*(nd + 5.0)*std::pow(s,5));
+    if (s < 3.0) return norm*(-243.0*nd + 405.0*(nd + 1.0)*s - 270.0*(nd + 2.0)*s*s + 90.0*(nd + 3.0)*std::pow(s,3) - 15.0*(nd + 4.0)*std::pow(s,4) + (nd + 5.0)*std::pow(s,5));
+    return 0.0;
+  }
+  double wzeta(double s) const {
+    if (s < 1.0) return 33.0*s*s - 15.0*std::pow(s,4) + 5.0*std::pow(s,6) - 1.42857142857*std::pow(s,7) - 34.14285714;
+    if (s < 2.0) return 25.5*s*s + 25.0*std::pow(s,3) - 52.5*std::pow(s,4) + 30.0*std::pow(s,5) - 7.5*std::pow(s,6) + 0.7142857143*std::pow(s,7) - 33.785714286;
+    if (s < 3.0) return 121.5*s*s - 135.0*std::pow(s,3) + 67.5*std::pow(s,4) - 18.0*std::pow(s,5) + 2.5*std::pow(s,6) - 0.142857143*std::pow(s,7) - 52.07142857;
+    return 0.0;
+  }
+  double wgrav(double s) const {
+    if (s < 1.0) return (12.0/359.0)*(22.0*s - 12.0*std::pow(s,3) + (30.0/7.0)*std::pow(s,5) - (5.0/4.0)*std::pow(s,6));
+    if (s < 2.0) return (12.0/359.0)*(17.0*s + (75.0/4.0)*s*s - 42.0*std::pow(s,3) + 25.0*std::pow(s,4) - (45.0/7.0)*std::pow(s,5) + (5.0/8.0)*std::pow(s,6) + (5.0/56.0)/(s*s));
+    if (s < 3.0) return (12.0/359.0)*(81.0*s - (405.0/4.0)*s*s + 54.0*std::pow(s,3) - 15.0*std::pow(s,4) + (15.0/7.0)*std::pow(s,5) - (1.0/8.0)*std::pow(s,6) - (507.0/56.0)/(s*s));
+    return 1.0/(s*s);
+  }
+  double wpot(double s) const {
+    if (s < 1.0) return (12.0/359.0)*(-11.0*s*s + 3.0*std::pow(s,4) - (5.0/7.0)*std::pow(s,6) + (5.0/28.0)*std::pow(s,7) + (478.0/14.0));
+    if (s < 2.0) return (12.0/359.0)*(-(17.0/2.0)*s*s - (25.0/4.0)*std::pow(s,3) + (21.0/2.0)*std::pow(s,4) - 5.0*std::pow(s,5) + (15.0/14.0)*std::pow(s,6) - (5.0/56.0)*std::pow(s,7) + (473.0/14.0) + (5.0/56.0)/s);
+    if (s < 3.0) return (12.0/359.0)*(-(81.0/2.0)*s*s + (135.0/4.0)*std::pow(s,3) - (27.0/2.0)*std::pow(s,4) + 3.0*std::pow(s,5) - (5.0/14.0)*std::pow(s,6) + (1.0/56.0)*std::pow(s,7) + (729.0/14.0) - (507.0/56.0)/s);
+    return 1.0/s;
+  }
+};
+template <class HK> static void fill_tables(const HK &k, double R, std::vector<double> &t)
 {
-  const HostM4 k(ctx->ndim);
   const int res = GH_TAB_RES;
-  const double R = 2.0, R2 = 4.0;
-  std::vector<double> t((size_t) GH_TAB_COUNT*res);
-  const double step = R/res, stepsq = R2/res;
+  const double R2 = R*R, step = R/res, stepsq = R2/res;
   for (int i = 0; i < res; i++) {
     t[GH_TAB_W1*res + i] = k.w1(step*i);
     t[GH_TAB_WGRAV*res + i] = k.wgrav(step*i);
@@ -150,6 +185,14 @@ static int gh_build_kernel_tables(gh_ctx *ctx)
     t[GH_TAB_WOMEGAS2*res + i] = k.womega(std::sqrt(stepsq*i));
     t[GH_TAB_WZETAS2*res + i] = k.wzeta(std::sqrt(stepsq*i));
   }
+}
+}
+
+static int gh_build_kernel_tables(gh_ctx *ctx)
+{
+  std::vector<double> t((size_t) GH_TAB_COUNT*GH_TAB_RES);
+  if (ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) fill_tables(HostQuintic(ctx->ndim), 3.0, t);
+  else fill_tables(HostM4(ctx->ndim), 2.0, t);
   GH_CHECK(ctx, hipMalloc((void**) &ctx->ktab, sizeof(double)*t.size()));
   GH_CHECK(ctx, hipMemcpy(ctx->ktab, t.data(), sizeof(double)*t.size(), hipMemcpyHostToDevice));
   return GH_OK;
@@ -164,8 +207,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   ctx->cfg = *cfg;
   ctx->ndim = cfg->ndim;
   *out = ctx;
-  if (cfg->kernel != GH_KERNEL_M4 && cfg->kernel != GH_KERNEL_QUINTIC && cfg->kernel != GH_KERNEL_M4_TAB)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic (tabulated_kernel = 0) and m4 with tabulated_kernel = 1");
+  if (cfg->kernel < GH_KERNEL_M4 || cfg->kernel > GH_KERNEL_QUINTIC_TAB)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic, each with tabulated_kernel = 0 or 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -184,7 +227,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
-  if (cfg->kernel == GH_KERNEL_M4_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
+  if (cfg->kernel == GH_KERNEL_M4_TAB || cfg->kernel == GH_KERNEL_QUINTIC_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
   return GH_OK;
 }
 
@@ -903,7 +946,7 @@ extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, 
   GH_CHECK(ctx, hipMalloc((void**) &d_off, sizeof(long long)*(n + 1)));
   Domain dom; gh_fill_domain(ctx, dom);
   DevicePtrs d = gh_dev(ctx);
-  const double kr = ctx->cfg.kernel == GH_KERNEL_QUINTIC ? 3.0 : 2.0;
+  const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
   hipLaunchKernelGGL(k_gather_count_fill, dim3(ctx->ngroups), dim3(64), 0, ctx->stream, d, dom, kr, 0, d_off, d_counts, d_ids, ctx->d_flags);
   int rc = gh_sync_collect(ctx, "gh_gather_neighbours");
   if (rc) { (void) hipFree(d_counts); (void) hipFree(d_off); return rc; }

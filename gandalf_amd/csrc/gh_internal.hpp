@@ -150,6 +150,9 @@ struct gh_ctx {
   else if ((ctx)->cfg.kernel == GH_KERNEL_M4_TAB) {                                                           \
     if ((ctx)->ndim == 1) { L(1, 2) } else if ((ctx)->ndim == 2) { L(2, 2) } else { L(3, 2) }                 \
   }                                                                                                           \
+  else if ((ctx)->cfg.kernel == GH_KERNEL_QUINTIC_TAB) {                                                      \
+    if ((ctx)->ndim == 1) { L(1, 3) } else if ((ctx)->ndim == 2) { L(2, 3) } else { L(3, 3) }                 \
+  }                                                                                                           \
   else {                                                                                                      \
     if ((ctx)->ndim == 1) { L(1, 0) } else if ((ctx)->ndim == 2) { L(2, 0) } else { L(3, 0) }                 \
   }

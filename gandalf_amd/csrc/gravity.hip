@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 {
   typedef typename KSel<ND, KT>::type K;
   // M4: keeps 16 workgroups per CU inside 160 KB of LDS; quintic: (3/2)^3 more neighbours per particle
-  constexpr int SPHCAP = KT == 1 ? 1024 : (MAXOCC <= 4 ? 416 : GH_SPHCAP);
+  constexpr int SPHCAP = (KT == 1 || KT == 3) ? 1024 : (MAXOCC <= 4 ? 416 : GH_SPHCAP);
   __shared__ TargetI s_tg[MAXOCC];
   __shared__ int s_sph[MAXOCC][SPHCAP];
   __shared__ RangeRing s_ring;

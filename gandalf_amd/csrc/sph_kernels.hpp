@@ -266,10 +266,11 @@ template <int ND, class Base> struct TabK {
   __device__ static __forceinline__ double t_wpot0(const double *tab) { return tab[GH_TAB_WPOT*GH_TAB_RES]; }
 };
 
-// kernel selector: KT = gh_config::kernel (GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2)
+// kernel selector: KT = gh_config::kernel (GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2, GH_KERNEL_QUINTIC_TAB = 3)
 template <int ND, int KT> struct KSel { typedef M4<ND> type; };
 template <int ND> struct KSel<ND, 1> { typedef Quintic<ND> type; };
 template <int ND> struct KSel<ND, 2> { typedef TabK<ND, M4<ND> > type; };
+template <int ND> struct KSel<ND, 3> { typedef TabK<ND, Quintic<ND> > type; };
 
 // pow(x, ND) / pow(x, ND+1) as the reference writes hfactor (GradhSph.cpp:192, 264)
 template <int ND> __device__ __forceinline__ double powN(double x)

@@ -22,7 +22,7 @@
 #include "gh_internal.hpp"
 #include <rocprim/rocprim.hpp>
 
-#define KERNRANGE_OF(cfg) ((cfg).kernel == GH_KERNEL_QUINTIC ? 3.0 : 2.0)
+#define KERNRANGE_OF(cfg) (((cfg).kernel == GH_KERNEL_QUINTIC || (cfg).kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0)
 
 static const double BIG = 9.9e20;   // reference Constants.h:72 big_number
 

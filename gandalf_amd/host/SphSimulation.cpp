@@ -84,8 +84,6 @@ static int enum_of(const std::string &v, const char *const *names, int n, const 
 void SphSimulation::ProcessParameters()
 {
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
-  if (ip["tabulated_kernel"] != 0 && sp["kernel"] != "m4")
-    throw GandalfError("tabulated_kernel = 1 is built for kernel = m4 only; set tabulated_kernel = 0");
   if (sp["neib_search"] != "kdtree") throw GandalfError("Unrecognised parameter : neib_search = " + sp["neib_search"]);
   if (sp["sph_integration"] != "lfkdk") throw GandalfError("Unrecognised parameter : sph_integration = " + sp["sph_integration"]);
   if (ip["Nlevels"] != 1) throw GandalfError("Nlevels > 1 (block timesteps) is a 'next' row (SURVEY.md 8f)");
@@ -94,7 +92,8 @@ void SphSimulation::ProcessParameters()
   static const char *mp[] = {"monopole", "quadrupole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic"};
   cfg.ndim = ndim;
   cfg.kernel = enum_of(sp["kernel"], kern, 2, "kernel");
-  if (ip["tabulated_kernel"] != 0) cfg.kernel = GH_KERNEL_M4_TAB;         // TabulatedKernel<ndim>("m4"), Sph constructor
+  if (ip["tabulated_kernel"] != 0)                                       // TabulatedKernel<ndim>(kernel), Sph constructor
+    cfg.kernel = cfg.kernel == GH_KERNEL_QUINTIC ? GH_KERNEL_QUINTIC_TAB : GH_KERNEL_M4_TAB;
   cfg.gas_eos = enum_of(sp["gas_eos"], eos, 3, "gas_eos");
   cfg.avisc = enum_of(sp["avisc"], av, 2, "avisc");
   cfg.acond = enum_of(sp["acond"], ac, 3, "acond");
@@ -119,7 +118,7 @@ void SphSimulation::ProcessParameters()
   cfg.courant_mult = fp["courant_mult"]; cfg.accel_mult = fp["accel_mult"]; cfg.energy_mult = fp["energy_mult"];
   tend = fp["tend"]; Nstepsmax = ip["Nstepsmax"];
   delete sph; delete randnumb;
-  sph = new Sph(ndim, cfg.h_fac, cfg.kernel == GH_KERNEL_QUINTIC ? 3.0 : 2.0);
+  sph = new Sph(ndim, cfg.h_fac, (cfg.kernel == GH_KERNEL_QUINTIC || cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0);
   randnumb = new XorshiftRand((uint64_t) ip["randseed"]);
 }
 

@@ -36,8 +36,8 @@ enum { GH_OK = 0, GH_ERR_CAPACITY = 1, GH_ERR_NOTCONVERGED = 2,
 enum { GH_BOUNDARY_OPEN = 0, GH_BOUNDARY_PERIODIC = 1 };
 /* kernels (reference SmoothingKernel.h: M4Kernel :101-240, QuinticKernel :251-408, TabulatedKernel :547-756).
  * GH_KERNEL_M4_TAB = the reference's default pair kernel = m4, tabulated_kernel = 1: 1000-entry piecewise-constant
- * tables of the M4 functions (TabulatedKernel.cpp:57-100). */
-enum { GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2 };
+ * tables of the M4 functions (TabulatedKernel.cpp:57-100); GH_KERNEL_QUINTIC_TAB likewise for kernel = quintic. */
+enum { GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2, GH_KERNEL_QUINTIC_TAB = 3 };
 /* gas_eos (reference EOS.h; energy_eqn = AdiabaticEOS.cpp, isothermal = IsothermalEOS.cpp,
  * barotropic = BarotropicEOS.cpp) */
 enum { GH_EOS_ENERGY_EQN = 0, GH_EOS_ISOTHERMAL = 1, GH_EOS_BAROTROPIC = 2 };
