@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("temp0", C.c_double),
         ("mu_bar", C.c_double), ("rho_bary", C.c_double), ("thetamaxsqd", C.c_double),
         ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double),
-        ("macerror", C.c_double),
+        ("macerror", C.c_double), ("alpha_visc_min", C.c_double),
     ]
 
 
@@ -143,6 +143,12 @@ def config_from_params(p, device=0):
         c.kernel = 3 if p.get("kernel", "m4") == "quintic" else 2     # GH_KERNEL_QUINTIC_TAB / GH_KERNEL_M4_TAB
     c.gas_eos = _ENUMS["gas_eos"][p.get("gas_eos", "energy_eqn")]
     c.avisc = _ENUMS["avisc"][p.get("avisc", "mon97")]
+    tdav = p.get("time_dependent_avisc", "none")
+    if tdav == "mm97" and c.avisc == 1:
+        c.avisc = 2                       # GH_AVISC_MON97MM97
+    elif tdav != "none":
+        raise ValueError("time_dependent_avisc = %s is not built (none | mm97 with avisc = mon97)" % tdav)
+    c.alpha_visc_min = float(p.get("alpha_visc_min", 0.1))
     c.acond = _ENUMS["acond"][p.get("acond", "none")]
     c.self_gravity = int(p.get("self_gravity", 0))
     c.hydro_forces = int(p.get("hydro_forces", 1))

@@ -334,7 +334,8 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   if ((rc = put(D_H, h, 1, 0, 0.0))) return rc;
   if ((rc = put(D_U, u, 1, 0, 0.0))) return rc;
   if ((rc = put(D_U0, u, 1, 0, 0.0))) return rc;
-  if ((rc = put(D_ALPHA, nullptr, 1, 0, ctx->cfg.alpha_visc))) return rc;
+  // SphSimulation.cpp:252-257: alpha = alpha_visc, or alpha_visc_min with time-dependent viscosity
+  if ((rc = put(D_ALPHA, nullptr, 1, 0, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? ctx->cfg.alpha_visc_min : ctx->cfg.alpha_visc))) return rc;
   std::vector<int> ids(n);
   for (size_t i = 0; i < n; i++) ids[i] = (int) i;
   GH_CHECK(ctx, hipMemcpy(ctx->iorig[0], ids.data(), sizeof(int)*n, hipMemcpyHostToDevice));

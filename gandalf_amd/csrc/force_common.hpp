@@ -9,6 +9,7 @@ struct ForceParams {
   Domain dom;
   EosParams eos;
   double alpha_visc, beta_visc;
+  double alpha_visc_min;   // time_dependent_avisc = mm97
   int avisc, acond;
   const double *ktab;   // kernel tables (tabulated_kernel = 1) or nullptr
   double macerror;      // gravity_mac = gadget2
@@ -17,11 +18,13 @@ struct ForceParams {
 };
 
 // per-neighbour record of the force tiles (reference HydroForcesParticle, Particle.h:313-364)
-enum { T_X = 0, T_Y, T_Z, T_M, T_VX, T_VY, T_VZ, T_HR2, T_INVH, T_HFAC, T_PFAC, T_INVRHO, T_SOUND, T_ZETA, T_U, T_PRESS, T_NF };
+enum { T_X = 0, T_Y, T_Z, T_M, T_VX, T_VY, T_VZ, T_HR2, T_INVH, T_HFAC, T_PFAC, T_INVRHO, T_SOUND, T_ZETA, T_U, T_PRESS, T_NF,
+       T_ALPHA = T_NF, T_NFA };     // T_ALPHA: extra row of the hydro-only kernel's tile (time-dependent viscosity)
 
 struct TargetI {
   double r[3], v[3];
   double invh, hfactor, pfac, invrho, sound, zeta, hr2, u, press, invhsqd;
+  double alpha;            // only read by the hydro-only kernel with mm97 viscosity
 };
 
 struct Accum {
@@ -30,7 +33,7 @@ struct Accum {
 };
 
 // neighbour record in registers (same 16 fields, same order as the T_* tile / hrec layout)
-struct Neib { double x, y, z, m, vx, vy, vz, hr2, invh, hfac, pfac, invrho, sound, zeta, u, press; };
+struct Neib { double x, y, z, m, vx, vy, vz, hr2, invh, hfac, pfac, invrho, sound, zeta, u, press, alpha; };
 
 __device__ __forceinline__ void neib_from_tile(Neib &n, const double (*s_t)[64], int c)
 {
@@ -76,7 +79,16 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
   if (dvdr < 0.0) {
     const double invrho_j = nb.invrho;
     const double winvrho = 0.25*(wkerni + wkernj)*(ti.invrho + invrho_j);
-    if (P.avisc == GH_AVISC_MON97) {
+    // mon97mm97 (GradhSph.cpp:419-424): the pair's mean alpha.  Only the hydro-only driver ever updates alpha
+    // (GradhSphTree.cpp:403; UpdateAllSphForces never writes dalphadt back), so with self-gravity every alpha
+    // stays alpha_visc_min and the host passes that as alpha_visc with avisc = mon97.
+    if (!GRAV && P.avisc == GH_AVISC_MON97MM97) {
+      const double alpha_mean = 0.5*(ti.alpha + nb.alpha);
+      const double vsignal = ti.sound + nb.sound - P.beta_visc*alpha_mean*dvdr;
+      paux -= alpha_mean*vsignal*dvdr*winvrho;
+      A.dudt -= 0.5*mj*alpha_mean*vsignal*dvdr*dvdr*winvrho;
+    }
+    else if (P.avisc == GH_AVISC_MON97) {
       const double vsignal = ti.sound + nb.sound - P.beta_visc*P.alpha_visc*dvdr;
       paux -= P.alpha_visc*vsignal*dvdr*winvrho;
       A.dudt -= 0.5*mj*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;

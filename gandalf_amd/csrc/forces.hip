@@ -30,7 +30,7 @@ template <int ND, bool COUNT, int KT>
 __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   __shared__ WalkLDS<int> L;
-  __shared__ double s_t[T_NF][64];
+  __shared__ double s_t[T_NFA][64];
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
@@ -41,6 +41,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   const int i = gfirst + (act ? lane : 0);
   TargetI ti;
   load_target(d, i, ND, ti);
+  const bool mm97 = P.avisc == GH_AVISC_MON97MM97;
+  ti.alpha = mm97 ? d.f[D_ALPHA][i] : 0.0;
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
       double sh[3];
       code_shift(P.dom, code, sh);
       stage_neib(d, ND, s_t, lane, j, sh, valid);
+      if (mm97) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
     }
     __syncthreads();
     unsigned long long mask = 0;
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         if (ND > 2) r2 += dr[2]*dr[2];
         Neib nbr;
         neib_from_tile(nbr, s_t, c);
+        nbr.alpha = mm97 ? s_t[T_ALPHA][c] : 0.0;
         sph_pair<ND, false, KT>(P, ti, A, nbr, dr, r2);
         if (COUNT) n_pairs++;
       }
@@ -121,6 +125,9 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     for (int k = 0; k < ND; k++) d.f[D_AX + k][i] += A.a[k];
     d.f[D_DUDT][i] += A.dudt;
     d.f[D_DIV_V][i] += A.div_v;
+    // GradhSph.cpp:454-457; the driver ACCUMULATES it on the main array (GradhSphTree.cpp:403) and nothing zeroes
+    // it between steps (Sph::ZeroAccelerations does not) - restated as it is
+    if (mm97) d.f[D_DALPHADT][i] += 0.1*ti.sound*(P.alpha_visc_min - ti.alpha)*ti.invh + fmax(-A.div_v, 0.0)*(P.alpha_visc - ti.alpha);
   }
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_pairs : 0);
@@ -488,8 +495,11 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
 {
   gh_fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
-  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
+  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc; P.alpha_visc_min = ctx->cfg.alpha_visc_min;
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
+  if (ctx->cfg.self_gravity && ctx->cfg.avisc == GH_AVISC_MON97MM97) {      // see sph_pair: alpha never leaves alpha_visc_min
+    P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min;
+  }
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);

@@ -741,8 +741,9 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   ForceParams P;
   gh_fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
-  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc;
+  P.alpha_visc = ctx->cfg.alpha_visc; P.beta_visc = ctx->cfg.beta_visc; P.alpha_visc_min = ctx->cfg.alpha_visc_min;
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
+  if (ctx->cfg.avisc == GH_AVISC_MON97MM97) { P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min; }   // see sph_pair
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
   const bool quadf = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE;
   const bool lists_only = quadf || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither

@@ -22,7 +22,7 @@ __global__ void k_zero_acc(DevicePtrs d)
 // time[0] = t, time[1] = timestep.  advance: t <- t + timestep first (SphSimulation.cpp:587)
 __global__ void k_advance_time(double *time) { time[0] = time[0] + time[1]; }
 
-__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration)
+__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration, int tdavisc)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
@@ -40,6 +40,7 @@ __global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int 
     d.f[D_RX + k][i] = r;
     d.f[D_VX + k][i] = v;
   }
+  if (tdavisc) d.f[D_ALPHA][i] += d.f[D_DALPHADT][i]*time[1];              // SphLeapfrogKDK.cpp:111 (the global timestep)
   if (energy_integration) d.f[D_U][i] = d.f[D_U0][i] + d.f[D_DUDT0][i]*dt;
 }
 
@@ -130,7 +131,7 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int, double, double)
   Domain dom;
   gh_fill_domain(ctx, dom);
   hipLaunchKernelGGL(k_kdk_advance, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), dom,
-                     gh_time_dev(ctx), ctx->cfg.energy_integration);
+                     gh_time_dev(ctx), ctx->cfg.energy_integration, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? 1 : 0);
   return GH_OK;
 }
 

@@ -42,7 +42,7 @@ enum { GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2, GH_KERNEL_
  * barotropic = BarotropicEOS.cpp) */
 enum { GH_EOS_ENERGY_EQN = 0, GH_EOS_ISOTHERMAL = 1, GH_EOS_BAROTROPIC = 2 };
 /* avisc / acond (reference Sph.h aviscenum, acondenum) */
-enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1 };
+enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1, GH_AVISC_MON97MM97 = 2 /* avisc = mon97 + time_dependent_avisc = mm97 */ };
 enum { GH_ACOND_NONE = 0, GH_ACOND_WADSLEY2008 = 1, GH_ACOND_PRICE2008 = 2 };
 /* multipole / gravity_mac (reference Tree.h MAC_Type; NeighbourSearch.h:350-475) */
 enum { GH_MULTIPOLE_MONOPOLE = 0, GH_MULTIPOLE_QUADRUPOLE = 1 };
@@ -79,7 +79,8 @@ typedef struct gh_config {
   double  courant_mult;    /* courant_mult */
   double  accel_mult;      /* accel_mult */
   double  energy_mult;     /* energy_mult */
-  double  macerror;        /* macerror (gravity_mac = gadget2) */
+  double  macerror;        /* macerror (gravity_mac = gadget2 / eigenmac) */
+  double  alpha_visc_min;  /* alpha_visc_min (time_dependent_avisc = mm97) */
 } gh_config;
 
 /* field ids for gh_download / gh_upload_field (values are per particle; vectors are [N][ndim]) */

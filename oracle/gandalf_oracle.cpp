@@ -41,6 +41,7 @@ struct Part {                                   // Particle.h:133-223 + GradhSph
   FLOAT m, h, hrangesqd, hfactor, sound, rho, pressure, u, u0, dudt0, dudt, gpot, gpot_hydro;
   double dt, dt_next, tlast;
   FLOAT div_v, invomega, zeta;
+  FLOAT alpha, dalphadt;                          // time-dependent viscosity (mm97)
 };
 
 struct Cell {                                   // TreeCellBase, TreeCell.h:16-49 (+ KDTreeCell c1, c2)
@@ -52,8 +53,8 @@ struct Cell {                                   // TreeCellBase, TreeCell.h:16-4
 };
 
 struct Params {
-  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac;
-  FLOAT macerror;
+  int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc;
+  FLOAT macerror, alpha_visc_min;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -736,9 +737,17 @@ struct Oracle {
     paux = ((pi.pressure*pi.invomega)/(pi.rho*pi.rho))*wkerni + ((nb.pressure*nb.invomega)/(nb.rho*nb.rho))*wkernj;
     if (dvdr < 0.0) {
       const FLOAT winvrho = 0.25*(wkerni + wkernj)*(invrho_i + invrho_j);
+      if (P.tdavisc) {                                                 // mon97mm97, GradhSph.cpp:419-424 / 533-538
+        const FLOAT alpha_mean = (FLOAT) 0.5*(pi.alpha + nb.alpha);
+        const FLOAT vsignal = pi.sound + nb.sound - P.beta_visc*alpha_mean*dvdr;
+        paux -= alpha_mean*vsignal*dvdr*winvrho;
+        pi.dudt -= 0.5*nb.m*alpha_mean*vsignal*dvdr*dvdr*winvrho;
+      }
+      else {
       const FLOAT vsignal = pi.sound + nb.sound - P.beta_visc*P.alpha_visc*dvdr;      // mon97
       paux -= P.alpha_visc*vsignal*dvdr*winvrho;
       pi.dudt -= 0.5*nb.m*P.alpha_visc*vsignal*dvdr*dvdr*winvrho;
+      }
       // artificial conductivity, GradhSph.cpp:426-435 / 541-549
       if (P.acond == 1) pi.dudt += nb.m*dvdr*(nb.u - pi.u)*(invrho_i*wkerni + invrho_j*wkernj);
       else if (P.acond == 2)
@@ -765,7 +774,7 @@ struct Oracle {
       const int Nactive = ActiveParticles(cellc, activelist);
       for (int j = 0; j < Nactive; j++) {
         activepart[j] = p[activelist[j]];
-        activepart[j].div_v = 0.0; activepart[j].dudt = 0.0;
+        activepart[j].div_v = 0.0; activepart[j].dudt = 0.0; activepart[j].dalphadt = 0.0;   // GradhSphTree.cpp:334-342
         activepart[j].gpot = GRAV ? (activepart[j].m/activepart[j].h)*kern.wpot(0.0) : 0.0;
         for (int k = 0; k < 3; k++) { activepart[j].a[k] = 0.0; if (GRAV) activepart[j].atree[k] = 0.0; }
       }
@@ -856,6 +865,11 @@ struct Oracle {
         const FLOAT invrho_i = 1/pi.rho;
         pi.div_v *= invrho_i;                                         // GradhSph.cpp:452-453 / 577-578
         pi.dudt -= pi.pressure*pi.div_v*invrho_i*pi.invomega;
+        if (P.tdavisc) {                                               // GradhSph.cpp:454-457 / 579-582 (note the sign quirk)
+          const FLOAT invh_i = 1/pi.h;
+          if (!GRAV) pi.dalphadt = (FLOAT) 0.1*pi.sound*(P.alpha_visc_min - pi.alpha)*invh_i + std::max(-pi.div_v, (FLOAT) 0.0)*(P.alpha_visc - pi.alpha);
+          else pi.dalphadt = (FLOAT) 0.1*pi.sound*(P.alpha_visc_min - pi.alpha)*invh_i + std::max(pi.div_v, (FLOAT) 0.0)*(P.alpha_visc - pi.alpha);
+        }
         if (GRAV) {
           // ComputeDirectGravForces, GradhSph.cpp:657-690
           for (size_t jj = 0; jj < directlist.size(); jj++) {
@@ -926,6 +940,7 @@ struct Oracle {
         p[i].gpot += activepart[j].gpot;
         p[i].dudt += activepart[j].dudt;
         p[i].div_v += activepart[j].div_v;
+        if (!GRAV) p[i].dalphadt += activepart[j].dalphadt;          // GradhSphTree.cpp:403 (hydro driver only; never zeroed)
       }
     }
   }
@@ -939,6 +954,7 @@ struct Oracle {
       const FLOAT dt = t - q.tlast;
       for (int k = 0; k < P.ndim; k++) q.r[k] = q.r0[k] + q.v0[k]*dt + 0.5*q.a0[k]*dt*dt;
       for (int k = 0; k < P.ndim; k++) q.v[k] = q.v0[k] + q.a0[k]*dt;
+      if (P.tdavisc) q.alpha += q.dalphadt*timestep;                 // SphLeapfrogKDK.cpp:111
       if (P.energy_integration) q.u = q.u0 + q.dudt0*dt;
       q.flags |= F_ACTIVE;
     }
@@ -1121,8 +1137,8 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac;
-  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, pad_;
+  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min;
 };
 
 Oracle *orc_create(const orc_params *q)
@@ -1130,7 +1146,7 @@ Oracle *orc_create(const orc_params *q)
   Params P;
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
-  P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror;
+  P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
     P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];
@@ -1152,6 +1168,7 @@ void orc_set_particles(Oracle *o, int N, const double *r, const double *v, const
     q.flags = F_ACTIVE; q.iorig = i;
     for (int k = 0; k < nd; k++) { q.r[k] = r[i*nd + k]; q.r0[k] = q.r[k]; q.v[k] = v ? v[i*nd + k] : 0.0; q.v0[k] = q.v[k]; }
     q.m = m[i]; q.h = h[i]; q.u = u ? u[i] : 0.0; q.u0 = q.u;
+    q.alpha = o->P.tdavisc ? o->P.alpha_visc_min : o->P.alpha_visc;   // SphSimulation.cpp:252-257
   }
   o->t = 0.0; o->timestep = 0.0; o->n = 0; o->Nsteps = 0;
 }
@@ -1163,7 +1180,7 @@ static double *field_ptr(Part &q, const char *name, int *ncomp)
 #define S(nm) if (!strcmp(name, #nm)) return &q.nm;
   V(r) V(v) V(a) V(atree) V(r0) V(v0) V(a0)
   S(m) S(h) S(hrangesqd) S(hfactor) S(sound) S(rho) S(pressure) S(u) S(u0) S(dudt0) S(dudt) S(gpot) S(gpot_hydro)
-  S(dt) S(dt_next) S(tlast) S(div_v) S(invomega) S(zeta)
+  S(dt) S(dt_next) S(tlast) S(div_v) S(invomega) S(zeta) S(alpha) S(dalphadt)
 #undef V
 #undef S
   return nullptr;

@@ -13,10 +13,10 @@ _lib = None
 class OrcParams(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("Nleafmax", C.c_int32), ("self_gravity", C.c_int32), ("periodic", C.c_int32*3),
                 ("energy_integration", C.c_int32), ("nthreads", C.c_int32),
-                ("kernel", C.c_int32), ("multipole", C.c_int32), ("acond", C.c_int32), ("gravity_mac", C.c_int32),
+                ("kernel", C.c_int32), ("multipole", C.c_int32), ("acond", C.c_int32), ("gravity_mac", C.c_int32), ("tdavisc", C.c_int32), ("pad_", C.c_int32),
                 ("boxmin", C.c_double*3), ("boxmax", C.c_double*3), ("h_fac", C.c_double), ("h_converge", C.c_double),
                 ("alpha_visc", C.c_double), ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("thetamaxsqd", C.c_double),
-                ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double), ("macerror", C.c_double)]
+                ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double), ("macerror", C.c_double), ("alpha_visc_min", C.c_double)]
 
 
 def lib():
@@ -78,6 +78,9 @@ class Oracle:
         q.acond = {"none": 0, "wadsley2008": 1, "price2008": 2}[p.get("acond", "none")]
         q.gravity_mac = {"geometric": 0, "gadget2": 1, "eigenmac": 2}[p.get("gravity_mac", "geometric")]
         q.macerror = float(p.get("macerror", 0.0001))
+        assert p.get("time_dependent_avisc", "none") in ("none", "mm97")
+        q.tdavisc = 1 if p.get("time_dependent_avisc", "none") == "mm97" else 0
+        q.alpha_visc_min = float(p.get("alpha_visc_min", 0.1))
         self.L, self.ndim, self.N = L, q.ndim, 0
         self.h = C.c_void_p(L.orc_create(C.byref(q)))
 

@@ -23,7 +23,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 PARTICLE_IN = ["r", "v", "m", "h", "u", "iorig", "ptype"]
 DENS_OUT = ["h", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound", "pressure", "u", "div_v"]
 FORCE_OUT = ["a", "atree", "gpot", "gpot_hydro", "dudt", "div_v", "dalphadt", "levelneib"]
-STEP_OUT = ["r", "v", "a", "atree", "h", "rho", "u", "dudt", "gpot", "dt", "iorig", "r0", "v0", "a0", "u0", "dudt0",
+STEP_OUT = ["r", "v", "a", "atree", "alpha", "dalphadt", "h", "rho", "u", "dudt", "gpot", "dt", "iorig", "r0", "v0", "a0", "u0", "dudt0",
             "t_timestep", "n_Nsteps_nresync"]
 TREE = ["tree_Ncell_ltot_gtot_Ntot_Nleafmax", "cell_cnext", "cell_copen", "cell_level", "cell_ifirst",
         "cell_ilast", "cell_N", "cell_Nactive", "cell_cdistsqd", "cell_m", "cell_rmax", "cell_hmax",
@@ -37,7 +37,7 @@ def run(args, cwd):
     subprocess.run([REF] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, env=env)
 
 
-NSTEPS = {"adsod_1d": 20, "adsod_1d_wadsley2008": 20, "adsod_1d_price2008": 20}
+NSTEPS = {"adsod_1d": 20, "adsod_1d_wadsley2008": 20, "adsod_1d_price2008": 20, "adsod_1d_mm97": 20}
 
 
 def passes(name, nsteps=None):

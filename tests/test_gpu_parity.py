@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97"]
 
 
 def make(case):
@@ -128,6 +128,9 @@ def test_steps_match_reference(case):
     sim.upload(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
     for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
         sim.upload_field(k, s(k))
+    if "setup_alpha" in g:       # time-dependent viscosity state
+        sim.upload_field("alpha", s("alpha"))
+        sim.upload_field("dalphadt", s("dalphadt"))
     if "setup_atree" in g:       # relative MAC: the first tree build stocks amin from the setup's atree
         sim.upload_field("atree", s("atree"))
         sim.upload_field("gpot", s("gpot"))

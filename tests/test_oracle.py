@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 from gandalf_amd.params import read_params_file
 from oracle.pyoracle import Oracle
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97"]
 
 
 def make(case, g):
@@ -64,6 +64,9 @@ def test_steps_bitwise(case):
     o.set_particles(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
     for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
         o.set(k, s(k))
+    if "setup_alpha" in g:       # time-dependent viscosity state
+        o.set("alpha", s("alpha"))
+        o.set("dalphadt", s("dalphadt"))
     if "setup_atree" in g:       # relative MAC: the first tree build stocks amin from the setup's atree
         o.set("atree", s("atree"))
         o.set("gpot", s("gpot"))
