@@ -123,7 +123,7 @@ def _dp(a):
 
 
 _ENUMS = {
-    "boundary": {"open": 0, "periodic": 1},
+    "boundary": {"open": 0, "periodic": 1, "mirror": 2},
     "kernel": {"m4": 0, "quintic": 1},
     "gas_eos": {"energy_eqn": 0, "isothermal": 1, "barotropic": 2},
     "avisc": {"none": 0, "mon97": 1},

@@ -899,11 +899,13 @@ __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain d
     const CellBox b = d.cbox[n];
     const int cn = b.N;
     if (cn == 0) return;
-    double sh[3];
-    code_shift(dom, code, sh);
+    double sg[3], sh[3];
+    code_xform(dom, code, sg, sh);
     for (int k = 0; k < d.ndim; k++) {
-      if (lo[k] > b.bbmax[k] + sh[k]) return;
-      if (b.bbmin[k] + sh[k] > hi[k]) return;
+      double bmin, bmax;
+      image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin, bmax);
+      if (lo[k] > bmax) return;
+      if (bmin > hi[k]) return;
     }
     if (n >= d.gtot - 1) { emit = true; first = b.first; c = cn; }
     else open = true;
@@ -911,10 +913,10 @@ __global__ __launch_bounds__(64) void k_gather_count_fill(DevicePtrs d, Domain d
   auto tile = [&](bool valid, int j, int code) {
     double x = 1e30, y = 1e30, z = 1e30; int id = -1;
     if (valid) {
-      double sh[3]; code_shift(dom, code, sh);
-      x = d.f[D_RX][j] + sh[0];
-      y = d.ndim > 1 ? d.f[D_RY][j] + sh[1] : 0.0;
-      z = d.ndim > 2 ? d.f[D_RZ][j] + sh[2] : 0.0;
+      double sg[3], sh[3]; code_xform(dom, code, sg, sh);
+      x = sg[0]*d.f[D_RX][j] + sh[0];
+      y = d.ndim > 1 ? sg[1]*d.f[D_RY][j] + sh[1] : 0.0;
+      z = d.ndim > 2 ? sg[2]*d.f[D_RZ][j] + sh[2] : 0.0;
       id = d.iorig[j];
     }
     s_x[lane] = x; s_y[lane] = y; s_z[lane] = z; s_id[lane] = id;

@@ -34,7 +34,7 @@ struct DensityParams {
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 template <int ND, bool COUNT, int KT>
-__global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ WalkLDS<int> L;
@@ -144,12 +144,13 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
       const CellBox b = d.cbox[n];
       const int cn = b.N;
       if (cn == 0) return;
-      double sh[3];
-      code_shift(P.dom, code, sh);
+      double sg[3], sh[3];
+      code_xform(P.dom, code, sg, sh);
       bool inside = true;
       double gap2 = 0.0;                                  // squared distance between the two boxes
       for (int k = 0; k < ND; k++) {
-        const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
+        double bmin, bmax;
+        image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin, bmax);
         if (lo[k] > bmax) return;                         // BoxOverlap, InlineFuncs.h:362-390 (inclusive)
         if (bmin > hi[k]) return;
         if (bmin < lo[k] || bmax > hi[k]) inside = false;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
           if (hl > 0.0) {
             double g2 = 0.0;
             for (int k = 0; k < ND; k++) {
-              const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
+              double bmin, bmax;
+              image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin, bmax);
               const double gk = fmax(fmax(bmin - s_lb[l][3 + k], s_lb[l][k] - bmax), 0.0);
               g2 += gk*gk;
             }
@@ -225,9 +227,9 @@ __global__ __launch_bounds__(64) void k_density(DevicePtrs d, DensityParams P, u
         double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
         if (valid) {
           const double4 v = d.posm[j];
-          double sh[3];
-          code_shift(P.dom, code, sh);
-          x = v.x + sh[0]; y = v.y + sh[1]; z = v.z + sh[2]; m = v.w;
+          double sg[3], sh[3];
+          code_xform(P.dom, code, sg, sh);
+          x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2]; m = v.w;
         }
         s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
         s_fx[lane] = (float) (x - gc[0]); s_fy[lane] = ND > 1 ? (float) (y - gc[1]) : 0.f; s_fz[lane] = ND > 2 ? (float) (z - gc[2]) : 0.f;
@@ -346,6 +348,8 @@ static void fill_domain(const gh_ctx *ctx, Domain &dom)
   for (int k = 0; k < 3; k++) {
     const bool per = k < ctx->ndim && ctx->cfg.boundary_lhs[k] == GH_BOUNDARY_PERIODIC;
     dom.periodic[k] = per ? 1 : 0;
+    dom.mirror[k][0] = k < ctx->ndim && ctx->cfg.boundary_lhs[k] == GH_BOUNDARY_MIRROR;
+    dom.mirror[k][1] = k < ctx->ndim && ctx->cfg.boundary_rhs[k] == GH_BOUNDARY_MIRROR;
     dom.bmin[k] = ctx->cfg.boxmin[k]; dom.bmax[k] = ctx->cfg.boxmax[k];
     dom.size[k] = per ? ctx->cfg.boxmax[k] - ctx->cfg.boxmin[k] : 0.0;
     dom.half[k] = 0.5*dom.size[k];

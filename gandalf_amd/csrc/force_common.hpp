@@ -141,7 +141,7 @@ static __global__ void k_pack_hydro(DevicePtrs d)
 }
 
 // stage particle j (tree-order index) with image shift sh into tile slot `slot`
-__device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (*s_t)[64], int slot, int j, const double sh[3], bool valid)
+__device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (*s_t)[64], int slot, int j, const double sg[3], const double sh[3], bool valid)
 {
   double4 q0, q1, q2, q3;
   q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0;
@@ -151,7 +151,8 @@ __device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (
   if (valid) {
     const double4 *r = d.hrec + 4*(size_t) j;
     q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3];
-    q0.x += sh[0]; q0.y += sh[1]; q0.z += sh[2];
+    q0.x = sg[0]*q0.x + sh[0]; q0.y = sg[1]*q0.y + sh[1]; q0.z = sg[2]*q0.z + sh[2];     // image position
+    q1.x *= sg[0]; q1.y *= sg[1]; q1.z *= sg[2];                                             // mirror images: v -> -v
   }
   s_t[T_X][slot] = q0.x; s_t[T_Y][slot] = q0.y; s_t[T_Z][slot] = q0.z; s_t[T_M][slot] = q0.w;
   s_t[T_VX][slot] = q1.x; s_t[T_VY][slot] = q1.y; s_t[T_VZ][slot] = q1.z; s_t[T_HR2][slot] = q1.w;

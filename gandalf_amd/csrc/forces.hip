@@ -62,13 +62,15 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     const CellBox b = d.cbox[n];
     const int cn = b.N;
     if (cn == 0) return;
-    double sh[3];
-    code_shift(P.dom, code, sh);
+    double sg[3], sh[3];
+    code_xform(P.dom, code, sg, sh);
     const CellH bh = d.ch[n];
     bool o1 = true, o2 = true, inside = true;
     for (int k = 0; k < ND; k++) {
-      const double bmin = b.bbmin[k] + sh[k], bmax = b.bbmax[k] + sh[k];
-      if (gb.bbmin[k] > bh.hbmax[k] + sh[k] || bh.hbmin[k] + sh[k] > gb.bbmax[k]) o1 = false;
+      double bmin, bmax, hmin, hmax_;
+      image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin, bmax);
+      image_interval(sg[k], sh[k], bh.hbmin[k], bh.hbmax[k], hmin, hmax_);
+      if (gb.bbmin[k] > hmax_ || hmin > gb.bbmax[k]) o1 = false;
       if (gh.hbmin[k] > bmax || bmin > gh.hbmax[k]) o2 = false;
       if (bmin < gh.hbmin[k] || bmax > gh.hbmax[k]) inside = false;
     }
@@ -78,9 +80,9 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   };
   auto tile = [&](bool valid, int j, int code) {
     {
-      double sh[3];
-      code_shift(P.dom, code, sh);
-      stage_neib(d, ND, s_t, lane, j, sh, valid);
+      double sg[3], sh[3];
+      code_xform(P.dom, code, sg, sh);
+      stage_neib(d, ND, s_t, lane, j, sg, sh, valid);
       if (mm97) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
     }
     __syncthreads();
@@ -554,7 +556,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_all_forces: no tree");
   for (int k = 0; k < ctx->ndim; k++)
-    if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN)
+    if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN || ctx->cfg.boundary_rhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
   if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE) ||
       (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.gravity_mac != GH_MAC_GADGET2 && ctx->cfg.gravity_mac != GH_MAC_EIGENMAC))

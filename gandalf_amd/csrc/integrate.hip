@@ -33,12 +33,22 @@ __global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int 
     double r = r0 + v0*dt + 0.5*a0*dt*dt;
     const double v = v0 + a0*dt;
     // TimeIntegration::CheckBoundaries: periodic wrap of r and r0
+    double vv = v;
     if (dom.periodic[k]) {
       if (r < dom.bmin[k]) { r += dom.size[k]; d.f[D_R0X + k][i] = r0 + dom.size[k]; }
       if (r > dom.bmax[k]) { r -= dom.size[k]; d.f[D_R0X + k][i] = d.f[D_R0X + k][i] - dom.size[k]; }
     }
+    // mirror walls: reflect r, r0 and flip v, v0, a, a0 (Integration.cpp:44-51, 66-73)
+    if (dom.mirror[k][0] && r < dom.bmin[k]) {
+      r = 2.0*dom.bmin[k] - r; d.f[D_R0X + k][i] = 2.0*dom.bmin[k] - d.f[D_R0X + k][i];
+      vv = -vv; d.f[D_V0X + k][i] = -d.f[D_V0X + k][i]; d.f[D_AX + k][i] = -d.f[D_AX + k][i]; d.f[D_A0X + k][i] = -d.f[D_A0X + k][i];
+    }
+    if (dom.mirror[k][1] && r > dom.bmax[k]) {
+      r = 2.0*dom.bmax[k] - r; d.f[D_R0X + k][i] = 2.0*dom.bmax[k] - d.f[D_R0X + k][i];
+      vv = -vv; d.f[D_V0X + k][i] = -d.f[D_V0X + k][i]; d.f[D_AX + k][i] = -d.f[D_AX + k][i]; d.f[D_A0X + k][i] = -d.f[D_A0X + k][i];
+    }
     d.f[D_RX + k][i] = r;
-    d.f[D_VX + k][i] = v;
+    d.f[D_VX + k][i] = vv;
   }
   if (tdavisc) d.f[D_ALPHA][i] += d.f[D_DALPHADT][i]*time[1];              // SphLeapfrogKDK.cpp:111 (the global timestep)
   if (energy_integration) d.f[D_U][i] = d.f[D_U0][i] + d.f[D_DUDT0][i]*dt;

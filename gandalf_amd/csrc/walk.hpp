@@ -11,8 +11,9 @@
 #define GH_NODE_BITS 26
 #define GH_NODE_MASK ((1 << GH_NODE_BITS) - 1)
 
-struct Domain {              // reference DomainBox (DomainBox.h): periodic flags and sizes
+struct Domain {              // reference DomainBox (DomainBox.h): periodic flags and sizes, mirror walls
   int periodic[3];
+  int mirror[3][2];          // mirror wall at the lhs / rhs face
   double bmin[3], bmax[3], size[3], half[3];
 };
 
@@ -39,12 +40,23 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 // periodic image code c in [0,27): per dimension 0 = no shift, 1 = +L, 2 = -L
-__device__ __forceinline__ void code_shift(const Domain &dom, int code, double s[3])
+// Image transform of code c (one base-3 digit per dimension): x' = sg*x + sh.  Digit 1 = the image seen beyond the
+// rhs face (periodic: x + L; mirror wall: 2*bmax - x), digit 2 = beyond the lhs face (x - L; 2*bmin - x).
+// Velocities of mirror images change sign in that dimension (Hydrodynamics.cpp:232-246, Particle.h:601-607).
+__device__ __forceinline__ void code_xform(const Domain &dom, int code, double sg[3], double sh[3])
 {
-  const int c0 = code % 3, c1 = (code/3) % 3, c2 = code/9;
-  s[0] = c0 == 0 ? 0.0 : (c0 == 1 ? dom.size[0] : -dom.size[0]);
-  s[1] = c1 == 0 ? 0.0 : (c1 == 1 ? dom.size[1] : -dom.size[1]);
-  s[2] = c2 == 0 ? 0.0 : (c2 == 1 ? dom.size[2] : -dom.size[2]);
+  const int c[3] = {code % 3, (code/3) % 3, code/9};
+  for (int k = 0; k < 3; k++) {
+    sg[k] = 1.0; sh[k] = 0.0;
+    if (c[k] == 1) { if (dom.periodic[k]) sh[k] = dom.size[k]; else { sg[k] = -1.0; sh[k] = 2.0*dom.bmax[k]; } }
+    else if (c[k] == 2) { if (dom.periodic[k]) sh[k] = -dom.size[k]; else { sg[k] = -1.0; sh[k] = 2.0*dom.bmin[k]; } }
+  }
+}
+// image of the interval [bmin, bmax]
+__device__ __forceinline__ void image_interval(double sg, double sh, double bmin, double bmax, double &omin, double &omax)
+{
+  if (sg > 0.0) { omin = bmin + sh; omax = bmax + sh; }
+  else { omin = sh - bmax; omax = sh - bmin; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,9 +214,9 @@ __device__ __forceinline__ unsigned int image_codes(const Domain &dom, int ndim,
   int opt[3][3]; int nopt[3];
   for (int k = 0; k < 3; k++) {
     nopt[k] = 0; opt[k][nopt[k]++] = 0;
-    if (k < ndim && dom.periodic[k]) {
-      if (hi[k] > dom.bmax[k]) opt[k][nopt[k]++] = 1;   // images at x+L
-      if (lo[k] < dom.bmin[k]) opt[k][nopt[k]++] = 2;   // images at x-L
+    if (k < ndim) {
+      if ((dom.periodic[k] || dom.mirror[k][1]) && hi[k] > dom.bmax[k]) opt[k][nopt[k]++] = 1;   // images at x+L / 2 bmax - x
+      if ((dom.periodic[k] || dom.mirror[k][0]) && lo[k] < dom.bmin[k]) opt[k][nopt[k]++] = 2;   // images at x-L / 2 bmin - x
     }
   }
   unsigned int codes = 0;

@@ -89,7 +89,7 @@ void SphSimulation::ProcessParameters()
   if (ip["Nlevels"] != 1) throw GandalfError("Nlevels > 1 (block timesteps) is a 'next' row (SURVEY.md 8f)");
   static const char *kern[] = {"m4", "quintic"}, *eos[] = {"energy_eqn", "isothermal", "barotropic"};
   static const char *av[] = {"none", "mon97"}, *ac[] = {"none", "wadsley2008", "price2008"};
-  static const char *mp[] = {"monopole", "quadrupole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic"};
+  static const char *mp[] = {"monopole", "quadrupole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic", "mirror"};
   cfg.ndim = ndim;
   cfg.kernel = enum_of(sp["kernel"], kern, 2, "kernel");
   if (ip["tabulated_kernel"] != 0)                                       // TabulatedKernel<ndim>(kernel), Sph constructor
@@ -111,8 +111,8 @@ void SphSimulation::ProcessParameters()
   cfg.energy_integration = sp["gas_eos"] == "energy_eqn" ? 1 : 0;     // GradhSphSimulation.cpp:114-122
   for (int k = 0; k < 3; k++) {
     const std::string idx = "[" + std::to_string(k) + "]";
-    cfg.boundary_lhs[k] = enum_of(sp["boundary_lhs" + idx], bd, 2, "boundary_lhs" + idx);
-    cfg.boundary_rhs[k] = enum_of(sp["boundary_rhs" + idx], bd, 2, "boundary_rhs" + idx);
+    cfg.boundary_lhs[k] = enum_of(sp["boundary_lhs" + idx], bd, 3, "boundary_lhs" + idx);
+    cfg.boundary_rhs[k] = enum_of(sp["boundary_rhs" + idx], bd, 3, "boundary_rhs" + idx);
     cfg.boxmin[k] = fp["boxmin" + idx]; cfg.boxmax[k] = fp["boxmax" + idx];
   }
   cfg.h_fac = fp["h_fac"]; cfg.h_converge = fp["h_converge"];

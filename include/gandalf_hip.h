@@ -33,7 +33,7 @@ enum { GH_OK = 0, GH_ERR_CAPACITY = 1, GH_ERR_NOTCONVERGED = 2,
        GH_ERR_INVALID = -1, GH_ERR_HIP = -2, GH_ERR_UNSUPPORTED = -3 };
 
 /* boundary types per face (reference DomainBox.h boundaryEnum: open / periodic / mirror / wall) */
-enum { GH_BOUNDARY_OPEN = 0, GH_BOUNDARY_PERIODIC = 1 };
+enum { GH_BOUNDARY_OPEN = 0, GH_BOUNDARY_PERIODIC = 1, GH_BOUNDARY_MIRROR = 2 };
 /* kernels (reference SmoothingKernel.h: M4Kernel :101-240, QuinticKernel :251-408, TabulatedKernel :547-756).
  * GH_KERNEL_M4_TAB = the reference's default pair kernel = m4, tabulated_kernel = 1: 1000-entry piecewise-constant
  * tables of the M4 functions (TabulatedKernel.cpp:57-100); GH_KERNEL_QUINTIC_TAB likewise for kernel = quintic. */

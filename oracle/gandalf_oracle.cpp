@@ -54,6 +54,7 @@ struct Cell {                                   // TreeCellBase, TreeCell.h:16-4
 
 struct Params {
   int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc;
+  int mirror[3][2];               // mirror wall at the lhs / rhs face of dimension k
   FLOAT macerror, alpha_visc_min;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
@@ -521,27 +522,36 @@ struct Oracle {
   FLOAT h_rho_func(FLOAT m, FLOAT rho) const { return P.h_fac*pow(m/rho, invndim); }   // Sph.h:259
   FLOAT h_rho_deriv(FLOAT h, FLOAT rho) const { return -invndim*h/rho; }               // Sph.h:264
   bool any_periodic() const { return P.periodic[0] || P.periodic[1] || P.periodic[2]; }
+  bool any_mirror() const { for (int k = 0; k < P.ndim; k++) if (P.mirror[k][0] || P.mirror[k][1]) return true; return false; }
+  bool any_special() const { return any_periodic() || any_mirror(); }
 
   // ---- ghosts: HydroTree::SearchBoundaryGhostParticles HydroTree.cpp:495-543, Tree.cpp:1098-1149,
   //      Hydrodynamics.cpp:217-289
   void CheckBoundaryGhostParticle(int i, int j) {
     const FLOAT r = p[i].r[j], h = p[i].h;
-    if (r < P.boxmin[j] + ghost_range*kern.kernrange*h && P.periodic[j]) CreateGhost(i, j, r + P.boxsize[j]);
-    if (r > P.boxmax[j] - ghost_range*kern.kernrange*h && P.periodic[j]) CreateGhost(i, j, r - P.boxsize[j]);
+    const FLOAT v = p[i].v[j];                                       // Hydrodynamics.cpp:217-250 (tghost = 0)
+    if (r < P.boxmin[j] + ghost_range*kern.kernrange*h) {
+      if (P.periodic[j]) CreateGhost(i, j, r + P.boxsize[j], v);
+      if (P.mirror[j][0]) CreateGhost(i, j, 2*P.boxmin[j] - r, -v);
+    }
+    if (r > P.boxmax[j] - ghost_range*kern.kernrange*h) {
+      if (P.periodic[j]) CreateGhost(i, j, r - P.boxsize[j], v);
+      if (P.mirror[j][1]) CreateGhost(i, j, 2*P.boxmax[j] - r, -v);
+    }
   }
-  void CreateGhost(int i, int k, FLOAT rk) {
+  void CreateGhost(int i, int k, FLOAT rk, FLOAT vk) {
     Part g = p[i];
-    g.r[k] = rk; g.flags &= ~F_ACTIVE; g.iorig = i;
+    g.r[k] = rk; g.v[k] = vk; g.flags &= ~F_ACTIVE; g.iorig = i;
     p.push_back(g);
     Nghost++;
   }
   void SearchBoundaryGhostParticles() {
     p.resize(Nhydro); Nghost = 0;
-    if (!any_periodic()) return;
+    if (!any_special()) return;
     const FLOAT grange = ghost_range*kern.kernrange;
     int Ntot = Nhydro;
     for (int j = 0; j < P.ndim; j++) {
-      if (!P.periodic[j]) continue;
+      if (!P.periodic[j] && !P.mirror[j][0] && !P.mirror[j][1]) continue;
       int c = 0;
       while (c < tree.Ncell) {                                       // Tree::GenerateBoundaryGhostParticles (tghost = 0)
         const Cell &x = tree.cell[c];
@@ -682,6 +692,43 @@ struct Oracle {
       else if (dr[k] < -P.boxhalf[k]) { dr[k] += P.boxsize[k]; any = true; }
     }
     return any;
+  }
+  // GhostNeighbourFinder::ConstructGhostsScatterGather + _MakeReflectedScatterGatherGhosts, GhostNeighbours.hpp:253-268, 404-450
+  void ConstructGhostsScatterGather(const Part &src, const Cell &cellc, std::vector<Part> &ngbs) const {
+    ngbs.push_back(src);
+    if (any_periodic()) MakePeriodicGhost(ngbs.back(), cellc.rcell);
+    if (!any_mirror()) return;
+    int nc = 1;
+    const size_t old_size = ngbs.size() - 1;
+    const Part real_particle = ngbs.back();
+    const FLOAT h2 = real_particle.hrangesqd;
+    for (int k = 0; k < P.ndim; k++) {
+      const int Nghost = nc;
+      if (P.mirror[k][0]) {
+        const FLOAT x = 2*P.boxmin[k] - real_particle.r[k];
+        const FLOAT dx = x - cellc.bbmin[k];
+        if (dx*dx < h2 || x > cellc.hbmin[k]) {
+          for (int n = 0; n < Nghost; n++) {
+            ngbs.push_back(ngbs[n + old_size]);
+            Part &g = ngbs.back();
+            g.r[k] = 2*P.boxmin[k] - g.r[k]; g.v[k] *= -1; g.a[k] *= -1;      // reflect(), Particle.h:601-607
+            nc++;
+          }
+        }
+      }
+      if (P.mirror[k][1]) {
+        const FLOAT x = 2*P.boxmax[k] - real_particle.r[k];
+        const FLOAT dx = x - cellc.bbmax[k];
+        if (dx*dx < h2 || x < cellc.hbmax[k]) {
+          for (int n = 0; n < Nghost; n++) {
+            ngbs.push_back(ngbs[n + old_size]);
+            Part &g = ngbs.back();
+            g.r[k] = 2*P.boxmax[k] - g.r[k]; g.v[k] *= -1; g.a[k] *= -1;
+            nc++;
+          }
+        }
+      }
+    }
   }
   void MakePeriodicGhost(Part &q, const FLOAT *centre) const {
     FLOAT dr[3];
@@ -832,18 +879,25 @@ struct Oracle {
         const FLOAT hrangemaxsqd = pow(cellc.rmax + kern.kernrange*cellc.hmax, 2), rmax = cellc.rmax;
         FLOAT dr[3];
         if (GRAV) for (size_t ii = 0; ii < tempdirectneib.size(); ii++) {
-          neibdata.push_back(p[tempdirectneib[ii]]);
-          if (any_periodic()) MakePeriodicGhost(neibdata.back(), cellc.rcell);
+          ConstructGhostsScatterGather(p[tempdirectneib[ii]], cellc, neibdata);
           directlist.push_back((int) neibdata.size() - 1);
         }
+        size_t Nneib = directlist.size();
         for (size_t ii = 0; ii < tempperneib.size(); ii++) {
-          Part q = p[tempperneib[ii]];
-          if (any_periodic()) MakePeriodicGhost(q, cellc.rcell);
-          for (int k = 0; k < nd; k++) dr[k] = q.r[k] - cellc.rcell[k];
-          const FLOAT drsqd = Dot(dr, dr, nd);
-          const FLOAT h2 = rmax + kern.kernrange*q.h;
-          if (drsqd < hrangemaxsqd || drsqd < h2*h2) { neibdata.push_back(q); neiblist.push_back((int) neibdata.size() - 1); }
-          else if (GRAV) { neibdata.push_back(q); directlist.push_back((int) neibdata.size() - 1); }
+          ConstructGhostsScatterGather(p[tempperneib[ii]], cellc, neibdata);     // the particle (nearest image) + mirror copies
+          while (Nneib < neibdata.size()) {                                      // NeighbourManager.h:423-441
+            size_t Nmax = neibdata.size();
+            for (int k = 0; k < nd; k++) dr[k] = neibdata[Nneib].r[k] - cellc.rcell[k];
+            const FLOAT drsqd = Dot(dr, dr, nd);
+            const FLOAT h2 = rmax + kern.kernrange*neibdata[Nneib].h;
+            if (drsqd < hrangemaxsqd || drsqd < h2*h2) { neiblist.push_back((int) Nneib); Nneib++; }
+            else if (GRAV) { directlist.push_back((int) Nneib); Nneib++; }
+            else {
+              Nmax--;
+              if (Nmax > Nneib) neibdata[Nneib] = neibdata[Nmax];
+              neibdata.resize(neibdata.size() - 1);
+            }
+          }
         }
       }
       const size_t NCellDirectNeib = directlist.size();
@@ -958,9 +1012,22 @@ struct Oracle {
       if (P.energy_integration) q.u = q.u0 + q.dudt0*dt;
       q.flags |= F_ACTIVE;
     }
-    for (int i = 0; i < Nhydro; i++) for (int k = 0; k < P.ndim; k++) if (P.periodic[k]) {
-      if (p[i].r[k] < P.boxmin[k]) { p[i].r[k] += P.boxsize[k]; p[i].r0[k] += P.boxsize[k]; }
-      if (p[i].r[k] > P.boxmax[k]) { p[i].r[k] -= P.boxsize[k]; p[i].r0[k] -= P.boxsize[k]; }
+    for (int i = 0; i < Nhydro; i++) for (int k = 0; k < P.ndim; k++) {       // TimeIntegration::CheckBoundaries
+      Part &q = p[i];
+      if (q.r[k] < P.boxmin[k]) {
+        if (P.periodic[k]) { q.r[k] += P.boxsize[k]; q.r0[k] += P.boxsize[k]; }
+        if (P.mirror[k][0]) {
+          q.r[k] = (FLOAT) 2.0*P.boxmin[k] - q.r[k]; q.r0[k] = (FLOAT) 2.0*P.boxmin[k] - q.r0[k];
+          q.v[k] = -q.v[k]; q.v0[k] = -q.v0[k]; q.a[k] = -q.a[k]; q.a0[k] = -q.a0[k];
+        }
+      }
+      if (q.r[k] > P.boxmax[k]) {
+        if (P.periodic[k]) { q.r[k] -= P.boxsize[k]; q.r0[k] -= P.boxsize[k]; }
+        if (P.mirror[k][1]) {
+          q.r[k] = (FLOAT) 2.0*P.boxmax[k] - q.r[k]; q.r0[k] = (FLOAT) 2.0*P.boxmax[k] - q.r0[k];
+          q.v[k] = -q.v[k]; q.v0[k] = -q.v0[k]; q.a[k] = -q.a[k]; q.a0[k] = -q.a0[k];
+        }
+      }
     }
   }
   double Timestep(const Part &q) const {
@@ -1148,7 +1215,8 @@ Oracle *orc_create(const orc_params *q)
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
   P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
   for (int k = 0; k < 3; k++) {
-    P.periodic[k] = q->periodic[k]; P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
+    P.periodic[k] = q->periodic[k] == 1; P.mirror[k][0] = (q->periodic[k] & 2) != 0; P.mirror[k][1] = (q->periodic[k] & 4) != 0;
+    P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
     P.boxsize[k] = q->boxmax[k] - q->boxmin[k]; P.boxhalf[k] = 0.5*P.boxsize[k];
   }
   P.h_fac = q->h_fac; P.h_converge = q->h_converge; P.alpha_visc = q->alpha_visc; P.beta_visc = q->beta_visc; P.gamma = q->gamma_eos;

@@ -61,7 +61,9 @@ class Oracle:
         q.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
         q.nthreads = nthreads or min(os.cpu_count() or 1, 16)
         for k in range(3):
-            q.periodic[k] = 1 if p.get("boundary_lhs[%d]" % k, "open") == "periodic" else 0
+            lhs, rhs = p.get("boundary_lhs[%d]" % k, "open"), p.get("boundary_rhs[%d]" % k, "open")
+            # 1 = periodic (both faces); bit 1 / bit 2 = mirror wall at the lhs / rhs face
+            q.periodic[k] = 1 if lhs == "periodic" else ((2 if lhs == "mirror" else 0) | (4 if rhs == "mirror" else 0))
             q.boxmin[k] = float(p.get("boxmin[%d]" % k, 0.0))
             q.boxmax[k] = float(p.get("boxmax[%d]" % k, 0.0))
         q.h_fac = float(p.get("h_fac", 1.2)); q.h_converge = float(p.get("h_converge", 0.01))

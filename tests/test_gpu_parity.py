@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror"]
 
 
 def make(case):
@@ -100,9 +100,28 @@ def test_density_and_forces_match_reference(case):
     sim.upload_field("h", g["dens_h"])
     offs, ids = sim.gather_neighbours()
     ro, ri = g["dens_gather_offsets"], g["dens_gather_ids"]
-    assert np.array_equal(np.diff(offs), np.diff(ro)), "gather neighbour counts differ"
+    # exact id sets; the only admissible differences are pairs ON the search sphere (|r^2 - (R h)^2| <= 1e-12 r^2,
+    # SURVEY 8d), which exist for exact lattices with h_fac = 1 (adsod_mirror: h = dx, neighbours at exactly 2h) -
+    # there the reference's cell-level sphere test decides by the last bit, and the kernel contributes W(2h) = 0
+    rr, hh = g["in_r"], g["dens_h"]
+    kr = 3.0 if p.get("kernel", "m4") == "quintic" else 2.0
+    box = [float(p.get("boxmax[%d]" % k, 0)) - float(p.get("boxmin[%d]" % k, 0)) for k in range(rr.shape[1])]
+    per = [p.get("boundary_lhs[%d]" % k, "open") == "periodic" for k in range(rr.shape[1])]
+    nexact = 0
     for i in range(len(ro) - 1):
-        assert np.array_equal(np.sort(ids[offs[i]:offs[i + 1]]), np.sort(ri[ro[i]:ro[i + 1]])), i
+        a, b = set(ids[offs[i]:offs[i + 1]].tolist()), set(ri[ro[i]:ro[i + 1]].tolist())
+        if a == b and (offs[i + 1] - offs[i]) == (ro[i + 1] - ro[i]):
+            nexact += 1
+            continue
+        for j in a ^ b:
+            dr = rr[j] - rr[i]
+            for k in range(len(dr)):
+                if per[k]:
+                    dr[k] -= box[k]*np.round(dr[k]/box[k])
+            r2, rs2 = float(dr @ dr), (kr*hh[i])**2
+            assert abs(r2 - rs2) <= 1e-12*rs2, (i, j, r2, rs2)
+    if case != "adsod_mirror":
+        assert nexact == len(ro) - 1, "neighbour id sets differ"
     # force pass on the density state the GPU itself produced
     sim.upload_field("h", sim.download("h"))
     sim.zero_accelerations()
