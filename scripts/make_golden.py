@@ -100,11 +100,29 @@ def nbody(N, softening, nsteps=3):
         print(name, "->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def long_run(name, nsteps, tag):
+    """final state of a long run (setup + nsteps MainLoop) - inputs are the IC of the parameter file"""
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["steps", par, os.path.join(tmp, "s"), str(nsteps)], tmp)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in ["r", "v", "m", "h", "u"]:
+            out["setup_" + k] = setup[k]
+        for k in ["r", "v", "h", "rho", "u", "t_timestep"]:
+            out["final_" + k] = final[k]
+        np.savez_compressed(os.path.join(GOLD, "%s_%s.npz" % (name, tag)), **out)
+        print(name, tag, "->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     cases = sys.argv[1:] or ["box3d_4k", "plummer_4k", "adsod_1d", "nbody"]
     for cfg in cases:
-        if cfg == "nbody":
+        if cfg == "adsod_mirror_full":
+            long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
+        elif cfg == "nbody":
             nbody(256, 0)
             nbody(256, 1)
         else:

@@ -94,3 +94,21 @@ def test_plummer1m_tree_gravity_vs_direct_sum():
     # theta = 0.5 monopole: per-particle error is dominated by the tree approximation (~1e-3) plus the
     # softened near field we left out (a few neighbours out of 1e6): well below 5 %
     assert np.median(err) < 2e-2
+
+
+def test_config1_full_run_vs_reference():
+    """BASELINE configs[0] on the GPU path: root adsod.dat (gradhsph, mirror walls) to tend = 5, 1334 steps, against
+    the reference's final state.  Rounding differences grow through 1334 steps of a shock tube: 1e-8 on r, rho."""
+    from gandalf_amd.host import Simulation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "adsod_mirror_full.npz"))
+    sim = Simulation(os.path.join(PARAMS, "adsod_mirror.dat"))
+    sim.generate_ic()
+    sim.post_ic_setup()
+    sim.main_loop(int(g["nsteps"][0]))
+    dev = sim.device()
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-9
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-8
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-7
+    assert np.max(np.abs(dev.download("v") - g["final_v"])) < 1e-7
+    rho = dev.download("rho")
+    assert 0.2 < rho.min() and rho.max() < 1.1          # between the two initial states (rhofluid2 = 0.25, rhofluid1 = 1)

@@ -90,3 +90,22 @@ def test_setup_from_ic_matches_reference_setup():
     for k in ["h", "rho", "a", "dudt", "dt"]:
         assert np.array_equal(o.get(k), g["setup_" + k]), k
     assert o.timestep == g["setup_t_timestep"][1]
+
+
+def test_config1_full_run_bitwise():
+    """BASELINE configs[0]: the root adsod.dat (gradhsph, mirror walls) to tend = 5 - 1334 steps - oracle vs the
+    reference's final state, bit for bit, from the raw IC of our own generator"""
+    from gandalf_amd.host import Simulation
+    g = load_golden("adsod_mirror_full")
+    pf = "%s/adsod_mirror.dat" % PARAMS
+    sim = Simulation(pf)
+    ic = sim.generate_ic()
+    for k in ("r", "v", "m", "u"):          # h in the fixture is the converged one of the setup, not the IC guess
+        assert np.array_equal(np.asarray(ic[k]).reshape(g["setup_" + k].shape), g["setup_" + k]), k
+    o = Oracle(read_params_file(pf), nthreads=2)
+    o.set_particles(ic["r"], ic["m"], ic["h"], v=ic["v"], u=ic["u"])
+    o.setup(h_provided=ic["initial_h_provided"])
+    o.step(int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ("r", "v", "h", "rho", "u"):
+        assert np.array_equal(o.get(k), g["final_" + k]), k
