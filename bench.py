@@ -27,6 +27,10 @@ WORKLOADS = {
                       desc="3-D Plummer gas sphere, N=1048576, self-gravity KD-tree theta=0.5 monopole (BASELINE configs[2])"),
     "box256k": dict(params="box3d_4k.dat", overrides={"Nhydro": 262144, "run_id": "BOX256K"},
                     desc="3-D uniform-random periodic box, N=262144, hydro only (BASELINE configs[1])"),
+    "plummer1m_fastmono": dict(params="plummer_4k.dat", overrides={"Nhydro": 1048576, "run_id": "PLUM1MFM", "multipole": "fast_monopole"},
+                               desc="3-D Plummer gas sphere, N=1048576, multipole = fast_monopole (not the metric's config)"),
+    "plummer1m_quad": dict(params="plummer_4k.dat", overrides={"Nhydro": 1048576, "run_id": "PLUM1MQ", "multipole": "quadrupole"},
+                           desc="3-D Plummer gas sphere, N=1048576, multipole = quadrupole, the reference's default (not the metric's config)"),
     "plummer64k": dict(params="plummer_4k.dat", overrides={"Nhydro": 65536, "run_id": "PLUM64K"},
                        desc="3-D Plummer gas sphere, N=65536 (reduced; not the metric's config)"),
 }

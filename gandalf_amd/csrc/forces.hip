@@ -558,10 +558,10 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN || ctx->cfg.boundary_rhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
-  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE) ||
+  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE && ctx->cfg.multipole != GH_MULTIPOLE_FAST_MONOPOLE) ||
       (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.gravity_mac != GH_MAC_GADGET2 && ctx->cfg.gravity_mac != GH_MAC_EIGENMAC))
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "built: multipole=monopole|quadrupole, gravity_mac=geometric|gadget2|eigenmac");
-  const bool quad = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // list kernels only
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "built: multipole=monopole|quadrupole|fast_monopole, gravity_mac=geometric|gadget2|eigenmac");
+  const bool quad = ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // list kernels only
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);

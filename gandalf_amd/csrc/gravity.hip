@@ -349,11 +349,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   __shared__ RangeRing s_ring;
   __shared__ int s_pre[64];
   __shared__ double s_out[MAXOCC][10];             // a[3], at[3], dudt, div_v, gpot, spare
+  __shared__ double s_fm[12];                      // fast monopole: pot, a[3], q[6] at the leaf's COM
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
   if (*G.fallback) {                                    // a list overflowed: the fused kernel does this call
-    if ((MP == 1 || P.mac != GH_MAC_GEOMETRIC) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);   // ... which has neither quadrupoles nor relative MACs: report it
+    if ((MP != 0 || P.mac != GH_MAC_GEOMETRIC) && lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW);   // ... which has neither quadrupoles nor relative MACs: report it
     return;
   }
   const int gl = leaf_begin + block_to_group(blockIdx.x, gridDim.x);     // leaf index (tree order)
@@ -427,7 +428,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
       for (int i = 0; i < MAXOCC; i++) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w);
     };
-    if (MP == 1) {
+    if (MP == 2) {
+      // fast monopole (FastMultipoleForces::AddMonopoleContribution / ApplyForcesTaylor, NeighbourSearch.h:561-583,
+      // 737-745): every entry is evaluated ONCE, at the leaf's centre of mass - potential, field and field gradient -
+      // and the particles get the first-order Taylor expansion.  lane = entry, ten sums per lane, one wave reduction.
+      const CellCom lc = d.ccom[node];
+      double f_pot = 0.0, f_a[3] = {0.0, 0.0, 0.0}, f_q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      int idn = ltot_ > 0 ? idfix(idraw(0), 0) : -1;
+      for (int c0 = 0; c0 < ltot_; c0 += 64) {
+        const int id = idn;
+        idn = idfix(idraw(c0 + 64), c0 + 64);
+        const double4 v = *((const double4*) &d.ccom[id < 0 ? 0 : id]);
+        {
+#pragma clang fp contract(fast)
+          double dr[3] = {0.0, 0.0, 0.0};
+          for (int k = 0; k < ND; k++) dr[k] = (k == 0 ? v.x : (k == 1 ? v.y : v.z)) - lc.com[k];
+          double drsqd = dr[0]*dr[0];
+          if (ND > 1) drsqd += dr[1]*dr[1];
+          if (ND > 2) drsqd += dr[2]*dr[2];
+          const double invdrmag = id < 0 ? 0.0 : fast_rsqrt(drsqd);
+          const double invdrsqd = invdrmag*invdrmag;
+          double mc = id < 0 ? 0.0 : v.w;
+          f_pot += mc*invdrmag;
+          mc *= invdrsqd*invdrmag;
+          for (int k = 0; k < ND; k++) f_a[k] += mc*dr[k];
+          f_q[0] += mc*(3.0*dr[0]*dr[0]*invdrsqd - 1);
+          if (ND > 1) { f_q[1] += mc*(3.0*dr[0]*dr[1]*invdrsqd); f_q[2] += mc*(3.0*dr[1]*dr[1]*invdrsqd - 1); }
+          if (ND > 2) { f_q[3] += mc*(3.0*dr[2]*dr[0]*invdrsqd); f_q[4] += mc*(3.0*dr[2]*dr[1]*invdrsqd); f_q[5] += mc*(3.0*dr[2]*dr[2]*invdrsqd - 1); }
+        }
+      }
+      const double r0 = wave_sum4(f_pot, f_a[0], f_a[1], f_a[2]);          // rows: pot, a1, a0, a2
+      const double r1 = wave_sum4(f_q[0], f_q[1], f_q[2], f_q[3]);          // rows: q0, q2, q1, q3
+      const double r2 = wave_sum4(f_q[4], f_q[5], 0.0, 0.0);                // rows: q4, -, q5, -
+      if ((lane & 15) == 0) {
+        const int qd = lane >> 4;
+        s_fm[qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3))] = r0;       // s_fm[0..3] = pot, a0, a1, a2
+        s_fm[4 + (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3)))] = r1;  // s_fm[4..7] = q0..q3
+        if (qd == 0) s_fm[8] = r2;
+        if (qd == 2) s_fm[9] = r2;
+      }
+      __syncthreads();
+      if (lane < Nt) {
+        const TargetI &tt = s_tg[lane];
+        double dr[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < ND; k++) dr[k] = tt.r[k] - lc.com[k];
+        const double *q = s_fm + 4;
+        double a3[3] = {0.0, 0.0, 0.0};
+        if (ND == 3) {
+          a3[0] = s_fm[1] + q[0]*dr[0] + q[1]*dr[1] + q[3]*dr[2];
+          a3[1] = s_fm[2] + q[1]*dr[0] + q[2]*dr[1] + q[4]*dr[2];
+          a3[2] = s_fm[3] + q[3]*dr[0] + q[4]*dr[1] + q[5]*dr[2];
+        }
+        else if (ND == 2) { a3[0] = s_fm[1] + q[0]*dr[0] + q[1]*dr[1]; a3[1] = s_fm[2] + q[1]*dr[0] + q[2]*dr[1]; }
+        else a3[0] = s_fm[1] + q[0]*dr[0];
+        double gp = s_fm[0];
+        for (int k = 0; k < ND; k++) gp += s_fm[1 + k]*dr[k];                // dphi == ac
+        for (int k = 0; k < ND; k++) s_out[lane][3 + k] += a3[k];
+        s_out[lane][8] += gp;
+      }
+      __syncthreads();
+    }
+    else if (MP == 1) {
       // quadrupole moments: a second 40-byte gather per entry; plain one-ahead prefetch of the ids
       int idn = ltot_ > 0 ? idfix(idraw(0), 0) : -1;
       for (int c0 = 0; c0 < ltot_; c0 += 64) {
@@ -745,8 +806,8 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
   if (ctx->cfg.avisc == GH_AVISC_MON97MM97) { P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min; }   // see sph_pair
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
-  const bool quadf = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE;
-  const bool lists_only = quadf || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither
+  const int mpole = ctx->cfg.multipole;
+  const bool lists_only = mpole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -774,7 +835,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
       if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
       else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
-#define LAUNCH(ND_, KT_) if (quadf) { LAUNCHM(ND_, KT_, 1) } else { LAUNCHM(ND_, KT_, 0) }
+#define LAUNCH(ND_, KT_) if (mpole == GH_MULTIPOLE_QUADRUPOLE) { LAUNCHM(ND_, KT_, 1) } else if (mpole == GH_MULTIPOLE_FAST_MONOPOLE) { LAUNCHM(ND_, KT_, 2) } else { LAUNCHM(ND_, KT_, 0) }
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCHM
 #undef LAUNCH

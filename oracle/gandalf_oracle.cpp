@@ -969,8 +969,8 @@ struct Oracle {
               pi.gpot += cl.m*invdrmag + 0.5*qscalar*invdr5;
             }
           }
-          // ComputeCellMonopoleForces, NeighbourSearch.h:350-377
-          else for (size_t jj = 0; jj < gravcell.size(); jj++) {
+          // ComputeCellMonopoleForces, NeighbourSearch.h:350-377 (the fast_* modes add their cell terms after the loop)
+          else if (P.multipole == 0) for (size_t jj = 0; jj < gravcell.size(); jj++) {
             FLOAT dr[3];
             for (int k = 0; k < nd; k++) dr[k] = gravcell[jj].r[k] - pi.r[k];
             const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
@@ -980,9 +980,47 @@ struct Oracle {
             pi.gpot += gravcell[jj].m*invdrmag;
             for (int k = 0; k < nd; k++) pi.atree[k] += gravcell[jj].m*dr[k]*invdr3;
           }
-          pi.gpot_hydro = pi.gpot;
         }
       }
+      if (GRAV && P.multipole == 2) {
+        // ComputeFastMonopoleForces, NeighbourSearch.h:768-794: field, gradient and potential of all cells at the leaf's
+        // COM (AddMonopoleContribution :561-583), first-order Taylor expansion to the particles (:737-745)
+        FLOAT rc[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, dphi[3] = {0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0}, pot = 0;
+        for (int k = 0; k < nd; k++) rc[k] = cellc.r[k];
+        for (size_t cc2 = 0; cc2 < gravcell.size(); cc2++) {
+          FLOAT dr[3] = {0, 0, 0};
+          for (int k = 0; k < nd; k++) dr[k] = gravcell[cc2].r[k] - rc[k];
+          const FLOAT invdrmag = sqrt((FLOAT) 1.0/Dot(dr, dr, nd));
+          const FLOAT invdrsqd = invdrmag*invdrmag;
+          const FLOAT invdr3 = invdrsqd*invdrmag;
+          FLOAT mc = gravcell[cc2].m;
+          pot += mc*invdrmag;
+          mc *= invdr3;
+          for (int k = 0; k < nd; k++) ac[k] += mc*dr[k];
+          for (int k = 0; k < nd; k++) dphi[k] += mc*dr[k];
+          q[0] += mc*(3.0*dr[0]*dr[0]*invdrsqd - 1);
+          if (nd > 1) { q[1] += mc*(3.0*dr[0]*dr[1]*invdrsqd); q[2] += mc*(3.0*dr[1]*dr[1]*invdrsqd - 1); }
+          if (nd > 2) { q[3] += mc*(3.0*dr[2]*dr[0]*invdrsqd); q[4] += mc*(3.0*dr[2]*dr[1]*invdrsqd); q[5] += mc*(3.0*dr[2]*dr[2]*invdrsqd - 1); }
+        }
+        for (int j = 0; j < Nactive; j++) {
+          Part &pi = activepart[j];
+          FLOAT dr[3] = {0, 0, 0};
+          for (int k = 0; k < nd; k++) dr[k] = pi.r[k] - rc[k];
+          if (nd == 3) {
+            pi.atree[0] += ac[0] + q[0]*dr[0] + q[1]*dr[1] + q[3]*dr[2];
+            pi.atree[1] += ac[1] + q[1]*dr[0] + q[2]*dr[1] + q[4]*dr[2];
+            pi.atree[2] += ac[2] + q[3]*dr[0] + q[4]*dr[1] + q[5]*dr[2];
+            pi.gpot += pot + dphi[0]*dr[0] + dphi[1]*dr[1] + dphi[2]*dr[2];
+          }
+          else if (nd == 2) {
+            pi.atree[0] += ac[0] + q[0]*dr[0] + q[1]*dr[1];
+            pi.atree[1] += ac[1] + q[1]*dr[0] + q[2]*dr[1];
+            pi.gpot += pot + dphi[0]*dr[0] + dphi[1]*dr[1];
+          }
+          else { pi.atree[0] += ac[0] + q[0]*dr[0]; pi.gpot += pot + dphi[0]*dr[0]; }
+        }
+      }
+      if (GRAV) for (int j = 0; j < Nactive; j++) activepart[j].gpot_hydro = activepart[j].gpot;   // GradhSphTree.cpp:595-598
       for (int j = 0; j < Nactive; j++) {                             // GradhSphTree.cpp:396-404 / 610-619
         const int i = activelist[j];
         for (int k = 0; k < nd; k++) p[i].a[k] += activepart[j].a[k];
