@@ -489,19 +489,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       __syncthreads();
     }
     else if (MP == 1) {
-      // quadrupole moments: a second 40-byte gather per entry; plain one-ahead prefetch of the ids
-      int idn = ltot_ > 0 ? idfix(idraw(0), 0) : -1;
-      for (int c0 = 0; c0 < ltot_; c0 += 64) {
-        const int id = idn;
-        idn = idfix(idraw(c0 + 64), c0 + 64);
-        const int ic = id < 0 ? 0 : id;
-        double4 v = *((const double4*) &d.ccom[ic]);
-        const CellQuad cq = d.cquad[ic];
-        double q[5];
-        for (int k = 0; k < 5; k++) q[k] = id < 0 ? 0.0 : cq.q[k];
-        v.w = id < 0 ? 0.0 : v.w;
+      // quadrupole moments: a second 40-byte gather per entry.  Same software pipeline as the monopole loop below:
+      // ids two chunks ahead, both records one chunk ahead of the arithmetic, pinned with the asm statement.
+      if (ltot_ > 0) {
+        auto qload = [&](int id, double4 &v, double *q) {
+          const int ic = id < 0 ? 0 : id;
+          v = *((const double4*) &d.ccom[ic]);
+          const double4 qa = *((const double4*) &d.cquad[ic]);
+          const double qb = d.cquad[ic].q[4];
+          q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb;
+        };
+        int id1 = idfix(idraw(0), 0), id2 = idfix(idraw(64), 64);
+        double4 vcur, vnext;
+        double qcur[5], qnext[5];
+        qload(id1, vcur, qcur);
+        if (id1 < 0) { vcur.w = 0.0; for (int k = 0; k < 5; k++) qcur[k] = 0.0; }
+        for (int c0 = 0; c0 < ltot_; c0 += 64) {
+          int id3 = idraw(c0 + 128);
+          qload(id2, vnext, qnext);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MAXOCC; i++) point_mass_quad<ND>(s_tg[i], acc[i], v.x, v.y, v.z, v.w, q);
+          for (int i = 0; i < MAXOCC; i++) point_mass_quad<ND>(s_tg[i], acc[i], vcur.x, vcur.y, vcur.z, vcur.w, qcur);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" : "+v"(vnext.x), "+v"(vnext.y), "+v"(vnext.z), "+v"(vnext.w), "+v"(id3),
+                            "+v"(qnext[0]), "+v"(qnext[1]), "+v"(qnext[2]), "+v"(qnext[3]), "+v"(qnext[4]));
+          if (id2 < 0) { vnext.w = 0.0; for (int k = 0; k < 5; k++) qnext[k] = 0.0; }
+          vcur = vnext;
+          for (int k = 0; k < 5; k++) qcur[k] = qnext[k];
+          id2 = idfix(id3, c0 + 128);
+        }
       }
     }
     else if (ltot_ > 0) {
