@@ -434,27 +434,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       // and the particles get the first-order Taylor expansion.  lane = entry, ten sums per lane, one wave reduction.
       const CellCom lc = d.ccom[node];
       double f_pot = 0.0, f_a[3] = {0.0, 0.0, 0.0}, f_q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      int idn = ltot_ > 0 ? idfix(idraw(0), 0) : -1;
-      for (int c0 = 0; c0 < ltot_; c0 += 64) {
-        const int id = idn;
-        idn = idfix(idraw(c0 + 64), c0 + 64);
-        const double4 v = *((const double4*) &d.ccom[id < 0 ? 0 : id]);
-        {
-#pragma clang fp contract(fast)
-          double dr[3] = {0.0, 0.0, 0.0};
-          for (int k = 0; k < ND; k++) dr[k] = (k == 0 ? v.x : (k == 1 ? v.y : v.z)) - lc.com[k];
-          double drsqd = dr[0]*dr[0];
-          if (ND > 1) drsqd += dr[1]*dr[1];
-          if (ND > 2) drsqd += dr[2]*dr[2];
-          const double invdrmag = id < 0 ? 0.0 : fast_rsqrt(drsqd);
-          const double invdrsqd = invdrmag*invdrmag;
-          double mc = id < 0 ? 0.0 : v.w;
-          f_pot += mc*invdrmag;
-          mc *= invdrsqd*invdrmag;
-          for (int k = 0; k < ND; k++) f_a[k] += mc*dr[k];
-          f_q[0] += mc*(3.0*dr[0]*dr[0]*invdrsqd - 1);
-          if (ND > 1) { f_q[1] += mc*(3.0*dr[0]*dr[1]*invdrsqd); f_q[2] += mc*(3.0*dr[1]*dr[1]*invdrsqd - 1); }
-          if (ND > 2) { f_q[3] += mc*(3.0*dr[2]*dr[0]*invdrsqd); f_q[4] += mc*(3.0*dr[2]*dr[1]*invdrsqd); f_q[5] += mc*(3.0*dr[2]*dr[2]*invdrsqd - 1); }
+      // same software pipeline as the monopole loop: ids two chunks ahead, records one chunk ahead
+      auto fm_term = [&](int id, const double4 &v) {
+        #pragma clang fp contract(fast)
+        double dr[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < ND; k++) dr[k] = (k == 0 ? v.x : (k == 1 ? v.y : v.z)) - lc.com[k];
+        double drsqd = dr[0]*dr[0];
+        if (ND > 1) drsqd += dr[1]*dr[1];
+        if (ND > 2) drsqd += dr[2]*dr[2];
+        const double invdrmag = id < 0 ? 0.0 : fast_rsqrt(drsqd);
+        const double invdrsqd = invdrmag*invdrmag;
+        double mc = id < 0 ? 0.0 : v.w;
+        f_pot += mc*invdrmag;
+        mc *= invdrsqd*invdrmag;
+        for (int k = 0; k < ND; k++) f_a[k] += mc*dr[k];
+        f_q[0] += mc*(3.0*dr[0]*dr[0]*invdrsqd - 1);
+        if (ND > 1) { f_q[1] += mc*(3.0*dr[0]*dr[1]*invdrsqd); f_q[2] += mc*(3.0*dr[1]*dr[1]*invdrsqd - 1); }
+        if (ND > 2) { f_q[3] += mc*(3.0*dr[2]*dr[0]*invdrsqd); f_q[4] += mc*(3.0*dr[2]*dr[1]*invdrsqd); f_q[5] += mc*(3.0*dr[2]*dr[2]*invdrsqd - 1); }
+      };
+      if (ltot_ > 0) {
+        int id1 = idfix(idraw(0), 0), id2 = idfix(idraw(64), 64);
+        double4 vcur, vnext;
+        vcur = *((const double4*) &d.ccom[id1 < 0 ? 0 : id1]);
+        for (int c0 = 0; c0 < ltot_; c0 += 64) {
+          int id3 = idraw(c0 + 128);
+          vnext = *((const double4*) &d.ccom[id2 < 0 ? 0 : id2]);
+          __builtin_amdgcn_sched_barrier(0);
+          fm_term(id1, vcur);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" : "+v"(vnext.x), "+v"(vnext.y), "+v"(vnext.z), "+v"(vnext.w), "+v"(id3));
+          vcur = vnext; id1 = id2; id2 = idfix(id3, c0 + 128);
         }
       }
       const double r0 = wave_sum4(f_pot, f_a[0], f_a[1], f_a[2]);          // rows: pot, a1, a0, a2
