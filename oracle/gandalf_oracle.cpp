@@ -30,13 +30,15 @@ static const double small_number_dp = 1.0e-50;  // Constants.h:90
 static const double big_number_dp = 9.9e50;     // Constants.h:89
 static const FLOAT twopi = 6.28318530717959;    // Constants.h:61
 static const FLOAT invpi = 0.31830988618379;    // Constants.h:63
+static const FLOAT invlogetwo = 1.44269504088896;  // Constants.h:64
 static const FLOAT twothirds = 0.66666666666666666666666;
 static const FLOAT ghost_range = 2.5;           // Hydrodynamics.h:52
 
-enum { F_DEAD = 1, F_ACTIVE = 2 };
+enum { F_DEAD = 1, F_ACTIVE = 2, F_END = 4 };      // dead / active / end_timestep (Flags.h)
 
 struct Part {                                   // Particle.h:133-223 + GradhSphParticle :285-368 (hot fields)
   int flags, iorig;
+  int level, levelneib, nstep, nlast;             // block timesteps (Particle.h:137-142)
   FLOAT r[3], v[3], a[3], atree[3], r0[3], v0[3], a0[3];
   FLOAT m, h, hrangesqd, hfactor, sound, rho, pressure, u, u0, dudt0, dudt, gpot, gpot_hydro;
   double dt, dt_next, tlast;
@@ -56,6 +58,7 @@ struct Params {
   int ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc;
   int mirror[3][2];               // mirror wall at the lhs / rhs face of dimension k
   FLOAT macerror, alpha_visc_min;
+  int Nlevels, level_diff_max, sph_single_timestep;   // block timesteps (Simulation.cpp:1209-1223)
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -514,6 +517,7 @@ struct Oracle {
   int Nhydro = 0, Nghost = 0;
   KDTree tree, ghosttree;
   int n = 0, Nsteps = 0; double t = 0.0, timestep = 0.0;
+  int nresync = 0, level_max = 0, level_step = 1, integration_step = 1; double dt_max = 0.0;   // Simulation.cpp:159-198
   std::string err;
   explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel & 1, (pp.kernel >> 1) & 1), invndim(1.0/pp.ndim) {
     tree.P = &P; ghosttree.P = &P; tree.kernrange = kern.kernrange; ghosttree.kernrange = kern.kernrange;
@@ -679,6 +683,7 @@ struct Oracle {
   void ZeroAccelerations() {                                        // Sph.cpp:126-140
     for (int i = 0; i < Nhydro; i++) {
       if (!(p[i].flags & F_ACTIVE)) continue;
+      p[i].levelneib = 0;
       p[i].div_v = 0.0; p[i].dudt = 0.0; p[i].gpot = 0.0; p[i].gpot_hydro = 0.0;
       for (int k = 0; k < 3; k++) { p[i].a[k] = 0.0; p[i].atree[k] = 0.0; }
     }
@@ -822,6 +827,7 @@ struct Oracle {
       for (int j = 0; j < Nactive; j++) {
         activepart[j] = p[activelist[j]];
         activepart[j].div_v = 0.0; activepart[j].dudt = 0.0; activepart[j].dalphadt = 0.0;   // GradhSphTree.cpp:334-342
+        activepart[j].levelneib = 0;
         activepart[j].gpot = GRAV ? (activepart[j].m/activepart[j].h)*kern.wpot(0.0) : 0.0;
         for (int k = 0; k < 3; k++) { activepart[j].a[k] = 0.0; if (GRAV) activepart[j].atree[k] = 0.0; }
       }
@@ -874,13 +880,14 @@ struct Oracle {
         }
       }
       // ---- NeighbourManager::_EndSearch, NeighbourManager.h:368-474
-      std::vector<Part> neibdata; std::vector<int> neiblist, directlist;
+      std::vector<Part> neibdata; std::vector<int> neiblist, directlist, neib_idx;
       {
         const FLOAT hrangemaxsqd = pow(cellc.rmax + kern.kernrange*cellc.hmax, 2), rmax = cellc.rmax;
         FLOAT dr[3];
         if (GRAV) for (size_t ii = 0; ii < tempdirectneib.size(); ii++) {
           ConstructGhostsScatterGather(p[tempdirectneib[ii]], cellc, neibdata);
           directlist.push_back((int) neibdata.size() - 1);
+          neib_idx.resize(neibdata.size(), tempdirectneib[ii]);
         }
         size_t Nneib = directlist.size();
         for (size_t ii = 0; ii < tempperneib.size(); ii++) {
@@ -898,7 +905,9 @@ struct Oracle {
               neibdata.resize(neibdata.size() - 1);
             }
           }
+          neib_idx.resize(neibdata.size(), tempperneib[ii]);             // NeighbourManager.h:427,432: index of the real particle
         }
+        for (size_t ii = 0; ii < neibdata.size(); ii++) neibdata[ii].levelneib = 0;       // HydroForcesParticle ctor, Particle.h:322
       }
       const size_t NCellDirectNeib = directlist.size();
       // ---- per particle: TrimNeighbourLists NeighbourManager.h:483-543, then the force operators
@@ -915,7 +924,12 @@ struct Oracle {
           if (drsqd >= pi.hrangesqd && drsqd >= nb.hrangesqd) { if (GRAV) directlist.push_back(neiblist[jj]); }
           else culled.push_back(neiblist[jj]);
         }
-        for (size_t jj = 0; jj < culled.size(); jj++) SphPair<GRAV>(pi, neibdata[culled[jj]], neibdata[culled[jj]].r);
+        for (size_t jj = 0; jj < culled.size(); jj++) {
+          Part &nb = neibdata[culled[jj]];
+          SphPair<GRAV>(pi, nb, nb.r);
+          pi.levelneib = std::max(pi.levelneib, nb.level);               // GradhSph.cpp:445-446 / 569-570
+          nb.levelneib = std::max(nb.levelneib, pi.level);
+        }
         const FLOAT invrho_i = 1/pi.rho;
         pi.div_v *= invrho_i;                                         // GradhSph.cpp:452-453 / 577-578
         pi.dudt -= pi.pressure*pi.div_v*invrho_i*pi.invomega;
@@ -1034,6 +1048,16 @@ struct Oracle {
         p[i].div_v += activepart[j].div_v;
         if (!GRAV) p[i].dalphadt += activepart[j].dalphadt;          // GradhSphTree.cpp:403 (hydro driver only; never zeroed)
       }
+      if (P.Nlevels > 1) {
+        // levelneib of the active particles and of every neighbour copy back to the real particle it was made from
+        // (GradhSphTree.cpp:375-382, 405, 412-417 / 619-640; integer max, so the per-thread buffers of the reference
+        // reduce to one max per particle)
+#pragma omp critical(levelneib)
+        {
+          for (int j = 0; j < Nactive; j++) p[activelist[j]].levelneib = std::max(p[activelist[j]].levelneib, activepart[j].levelneib);
+          for (size_t ii = 0; ii < neibdata.size(); ii++) p[neib_idx[ii]].levelneib = std::max(p[neib_idx[ii]].levelneib, neibdata[ii].levelneib);
+        }
+      }
     }
   }
   void Forces() { if (P.self_gravity) UpdateForces<true>(); else UpdateForces<false>(); }
@@ -1048,7 +1072,7 @@ struct Oracle {
       for (int k = 0; k < P.ndim; k++) q.v[k] = q.v0[k] + q.a0[k]*dt;
       if (P.tdavisc) q.alpha += q.dalphadt*timestep;                 // SphLeapfrogKDK.cpp:111
       if (P.energy_integration) q.u = q.u0 + q.dudt0*dt;
-      q.flags |= F_ACTIVE;
+      if (P.Nlevels == 1 || n - q.nlast == q.nstep) q.flags |= F_ACTIVE; else q.flags &= ~F_ACTIVE;   // SphLeapfrogKDK.cpp:117-118
     }
     for (int i = 0; i < Nhydro; i++) for (int k = 0; k < P.ndim; k++) {       // TimeIntegration::CheckBoundaries
       Part &q = p[i];
@@ -1081,7 +1105,136 @@ struct Oracle {
     timestep = dt_min; n = 0;
     for (int i = 0; i < Nhydro; i++) p[i].dt_next = timestep;
   }
+  // InlineFuncs.h:550-558
+  static int ComputeTimestepLevel(double dt, double dt_max) { return std::max((int) (invlogetwo*log(dt_max/dt)) + 1, 0); }
+  static int ipow2(int e) { return (int) pow(2.0, e); }
+  // Simulation::ComputeBlockTimesteps, Simulation.cpp:1764-2200 (hydro particles only: no stars, no sinks)
+  void ComputeBlockTimesteps() {
+    if (n == nresync) {                                                // resynchronise: rebuild the level structure
+      n = 0; timestep = big_number_dp;
+      double dt_min_hydro = big_number_dp;
+      for (int i = 0; i < Nhydro; i++) {
+        const double dt = Timestep(p[i]);
+        timestep = std::min(timestep, dt); dt_min_hydro = std::min(dt_min_hydro, dt);
+        p[i].dt_next = dt;
+      }
+      level_max = P.Nlevels - 1;
+      level_step = level_max + integration_step - 1;
+      dt_max = timestep*pow(2.0, level_max);
+      const int level_max_hydro = std::min(ComputeTimestepLevel(dt_min_hydro, dt_max), level_max);
+      for (int i = 0; i < Nhydro; i++) {
+        Part &q = p[i];
+        const int level = P.sph_single_timestep ? level_max_hydro : std::min(ComputeTimestepLevel(q.dt_next, dt_max), level_max);
+        q.level = level; q.levelneib = level;
+        q.nstep = ipow2(level_step - q.level);
+        q.nlast = n;
+        q.dt_next = q.nstep*timestep;                                  // NB: 'timestep' is still the minimum dt here (:1913)
+        q.flags |= F_END;
+      }
+      nresync = ipow2(level_step);
+      timestep = dt_max/(double) nresync;
+    }
+    else {
+      const int level_max_old = level_max;
+      level_max = 0;
+      int level_max_hydro = 0;
+      for (int i = 0; i < Nhydro; i++) {
+        Part &q = p[i];
+        if (n - q.nlast == q.nstep && q.nstep != ipow2(level_step - q.level)) {   // step cut short by CheckTimesteps (:1956-1966)
+          const double dt = Timestep(q);
+          const int level = std::max(ComputeTimestepLevel(dt, dt_max), q.levelneib - P.level_diff_max);
+          q.level = std::max(q.level, level);
+          q.levelneib = q.level;
+          q.nlast = n;
+          q.nstep = ipow2(level_step - q.level);
+          q.dt_next = q.nstep*timestep;
+          q.flags |= F_END;
+        }
+        else if (n - q.nlast == q.nstep) {                             // natural end of step (:1968-1992)
+          const int nstep = q.nstep, last_level = q.level;
+          const double dt = Timestep(q);
+          const int level = std::max(ComputeTimestepLevel(dt, dt_max), q.levelneib - P.level_diff_max);
+          if (level < last_level && last_level > 1 && n%(2*nstep) == 0) q.level = last_level - 1;
+          else if (level > last_level) q.level = level;
+          else q.level = last_level;
+          q.levelneib = level;
+          q.nlast = n;
+          q.nstep = ipow2(level_step - q.level);
+          q.dt_next = q.nstep*timestep;
+          q.flags |= F_END;
+        }
+        level_max_hydro = std::max(level_max_hydro, q.level);
+        level_max = std::max(level_max, q.level);
+      }
+      if (P.sph_single_timestep) for (int i = 0; i < Nhydro; i++) if (p[i].nlast == n) p[i].level = level_max_hydro;
+      const int istep = ipow2(level_step - level_max_old + 1);
+      if (level_max > level_max_old) {                                 // levels added: refine the integer clock (:2101-2112)
+        const int nfactor = ipow2(level_max - level_max_old);
+        n *= nfactor;
+        for (int i = 0; i < Nhydro; i++) { p[i].nstep *= nfactor; p[i].nlast *= nfactor; }
+      }
+      else if (level_max <= level_max_old - 1 && level_max_old > 1 && n%istep == 0) {   // one level removed (:2113-2127)
+        level_max = level_max_old - 1;
+        const int nfactor = ipow2(level_max_old - level_max);
+        n /= nfactor;
+        for (int i = 0; i < Nhydro; i++) { p[i].nlast /= nfactor; p[i].nstep /= nfactor; }
+      }
+      else level_max = level_max_old;
+      level_step = level_max + integration_step - 1;
+      nresync = ipow2(level_step);
+      timestep = dt_max/(double) nresync;
+      for (int i = 0; i < Nhydro; i++) if (p[i].nlast == n) p[i].nstep = ipow2(level_step - p[i].level);
+    }
+  }
+  // SphLeapfrogKDK::CheckTimesteps, SphLeapfrogKDK.cpp:284-330
+  int CheckTimesteps() {
+    int activecount = 0;
+    for (int i = 0; i < Nhydro; i++) {
+      Part &q = p[i];
+      const int dn = n - q.nlast;
+      if (dn == q.nstep) continue;
+      if (q.levelneib - q.level > P.level_diff_max) {
+        const int level_new = q.levelneib - P.level_diff_max;
+        const int nnewstep = ipow2(level_step - level_new);
+        if (dn%nnewstep == 0) {
+          if (dn > 0) q.nstep = dn;
+          q.level = level_new;
+          q.flags |= F_ACTIVE;
+          activecount++;
+        }
+      }
+    }
+    return activecount;
+  }
+  void UpdateActiveParticleCounters() {                              // KDTree.cpp:1217-1254 (leaf cells only)
+    for (int c = 0; c < tree.Ncell; c++) {
+      Cell &x = tree.cell[c];
+      x.Nactive = 0;
+      if (x.level != tree.ltot) continue;
+      int i = x.ifirst;
+      while (i != -1) {
+        if (i < Nhydro && (p[i].flags & F_ACTIVE)) x.Nactive++;
+        if (i == x.ilast) break;
+        i = tree.inext[i];
+      }
+    }
+  }
+  void EndTimestepBlock() {                                          // SphLeapfrogKDK.cpp:219-272
+    for (int i = 0; i < Nhydro; i++) {
+      Part &q = p[i];
+      if (!(q.flags & F_END)) continue;
+      for (int k = 0; k < P.ndim; k++) q.v[k] += 0.5*q.dt*(q.a[k] - q.a0[k]);
+      for (int k = 0; k < P.ndim; k++) { q.r0[k] = q.r[k]; q.v0[k] = q.v[k]; q.a0[k] = q.a[k]; }
+      if (P.energy_integration) {
+        q.u += 0.5*(q.dudt - q.dudt0)*q.dt;
+        if (q.u <= 0.0) q.u = q.u0 + q.dudt0*q.dt;
+        q.u0 = q.u; q.dudt0 = q.dudt;
+      }
+      q.nlast = n; q.tlast = t; q.dt = q.dt_next; q.dt_next = 0; q.flags &= ~(F_ACTIVE | F_END);
+    }
+  }
   void EndTimestep() {
+    if (P.Nlevels > 1) { EndTimestepBlock(); return; }
     for (int i = 0; i < Nhydro; i++) {
       Part &q = p[i];
       for (int k = 0; k < P.ndim; k++) q.v[k] += 0.5*q.dt*(q.a[k] - q.a0[k]);
@@ -1105,12 +1258,33 @@ struct Oracle {
     ZeroAccelerations(); Forces();
     mac_now = P.gravity_mac;
     if (relmac) { BuildTree(); ZeroAccelerations(); Forces(); }
-    t = 0.0; n = 0;
-    ComputeGlobalTimestep(); EndTimestep();
+    t = 0.0; n = 0; nresync = 0;
+    if (P.Nlevels > 1) ComputeBlockTimesteps(); else ComputeGlobalTimestep();
+    EndTimestep();
   }
   void MainLoop() {                                                  // SphSimulation.cpp:574-880
     n++; Nsteps++; t = t + timestep;
     AdvanceParticles();
+    if (P.Nlevels > 1) {
+      BuildTree(); SearchBoundaryGhostParticles(); BuildGhostTree();
+      int activecount = 0;
+      do {                                                             // SphSimulation.cpp:654-755
+        if (activecount > 0) UpdateActiveParticleCounters();
+        UpdateAllSphProperties();
+        ZeroAccelerations();
+        // SphSimulation.cpp:665-679 (nradstep = 1): thermal properties of ALL particles from the predicted u - a no-op with
+        // a global timestep, but with block timesteps this is what refreshes pressure / sound of the inactive neighbours
+        for (int i = 0; i < Nhydro; i++) {
+          p[i].sound = sqrt(P.gamma*(P.gamma - 1.0)*p[i].u);
+          p[i].pressure = (P.gamma - 1.0)*p[i].rho*p[i].u;
+        }
+        Forces();
+        for (int i = 0; i < Nhydro; i++) p[i].flags &= ~F_ACTIVE;
+        activecount = CheckTimesteps();
+      } while (activecount > 0);
+      ComputeBlockTimesteps(); EndTimestep();
+      return;
+    }
     BuildTree(); DensityPass();
     ZeroAccelerations(); Forces();
     ComputeGlobalTimestep(); EndTimestep();
@@ -1242,7 +1416,7 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, pad_;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep;
   double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min;
 };
 
@@ -1252,6 +1426,7 @@ Oracle *orc_create(const orc_params *q)
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
   P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
+  P.Nlevels = q->Nlevels > 1 ? q->Nlevels : 1; P.level_diff_max = q->level_diff_max; P.sph_single_timestep = q->sph_single_timestep;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k] == 1; P.mirror[k][0] = (q->periodic[k] & 2) != 0; P.mirror[k][1] = (q->periodic[k] & 4) != 0;
     P.boxmin[k] = q->boxmin[k]; P.boxmax[k] = q->boxmax[k];
@@ -1312,6 +1487,26 @@ int orc_set(Oracle *o, const char *name, const double *in)
   return 0;
 }
 void orc_set_time(Oracle *o, double t, double timestep) { o->t = t; o->timestep = timestep; }
+static int *ifield_ptr(Part &q, const char *name)
+{
+#define I(nm) if (!strcmp(name, #nm)) return &q.nm;
+  I(level) I(levelneib) I(nstep) I(nlast) I(flags)
+#undef I
+  return nullptr;
+}
+int orc_get_int(Oracle *o, const char *name, int *out)
+{
+  for (int i = 0; i < o->Nhydro; i++) { int *f = ifield_ptr(o->p[i], name); if (!f) return -1; out[i] = *f; }
+  return 0;
+}
+int orc_set_int(Oracle *o, const char *name, const int *in)
+{
+  for (int i = 0; i < o->Nhydro; i++) { int *f = ifield_ptr(o->p[i], name); if (!f) return -1; *f = in[i]; }
+  return 0;
+}
+// block-timestep clock: {n, nresync, level_max, level_step} and dt_max
+void orc_set_block(Oracle *o, const int *v, double dt_max) { o->n = v[0]; o->nresync = v[1]; o->level_max = v[2]; o->level_step = v[3]; o->dt_max = dt_max; }
+double orc_get_block(Oracle *o, int *v) { v[0] = o->n; v[1] = o->nresync; v[2] = o->level_max; v[3] = o->level_step; return o->dt_max; }
 double orc_time(Oracle *o) { return o->t; }
 double orc_timestep(Oracle *o) { return o->timestep; }
 void orc_set_all_active(Oracle *o) { for (int i = 0; i < o->Nhydro; i++) o->p[i].flags |= F_ACTIVE; }

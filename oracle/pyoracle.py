@@ -13,7 +13,8 @@ _lib = None
 class OrcParams(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("Nleafmax", C.c_int32), ("self_gravity", C.c_int32), ("periodic", C.c_int32*3),
                 ("energy_integration", C.c_int32), ("nthreads", C.c_int32),
-                ("kernel", C.c_int32), ("multipole", C.c_int32), ("acond", C.c_int32), ("gravity_mac", C.c_int32), ("tdavisc", C.c_int32), ("pad_", C.c_int32),
+                ("kernel", C.c_int32), ("multipole", C.c_int32), ("acond", C.c_int32), ("gravity_mac", C.c_int32), ("tdavisc", C.c_int32),
+                ("Nlevels", C.c_int32), ("level_diff_max", C.c_int32), ("sph_single_timestep", C.c_int32),
                 ("boxmin", C.c_double*3), ("boxmax", C.c_double*3), ("h_fac", C.c_double), ("h_converge", C.c_double),
                 ("alpha_visc", C.c_double), ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("thetamaxsqd", C.c_double),
                 ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double), ("macerror", C.c_double), ("alpha_visc_min", C.c_double)]
@@ -83,6 +84,8 @@ class Oracle:
         assert p.get("time_dependent_avisc", "none") in ("none", "mm97")
         q.tdavisc = 1 if p.get("time_dependent_avisc", "none") == "mm97" else 0
         q.alpha_visc_min = float(p.get("alpha_visc_min", 0.1))
+        q.Nlevels = int(p.get("Nlevels", 1)); q.level_diff_max = int(p.get("level_diff_max", 1))
+        q.sph_single_timestep = int(p.get("sph_single_timestep", 0))
         self.L, self.ndim, self.N = L, q.ndim, 0
         self.h = C.c_void_p(L.orc_create(C.byref(q)))
 
@@ -114,6 +117,27 @@ class Oracle:
     def set(self, name, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         assert self.L.orc_set(self.h, name.encode(), self._dp(arr)) == 0, name
+
+    def get_int(self, name):
+        """level / levelneib / nstep / nlast / flags (bit 1 active, bit 2 end_timestep)"""
+        out = np.empty(self.N, dtype=np.int32)
+        assert self.L.orc_get_int(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)) == 0, name
+        return out
+
+    def set_int(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        assert self.L.orc_set_int(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p)) == 0, name
+
+    def set_block(self, n, nresync, level_max, level_step, dt_max):
+        """block-timestep clock of Simulation (n, nresync, level_max, level_step, dt_max)"""
+        v = np.array([n, nresync, level_max, level_step], dtype=np.int32)
+        self.L.orc_set_block(self.h, v.ctypes.data_as(C.c_void_p), C.c_double(dt_max))
+
+    def get_block(self):
+        v = np.zeros(4, dtype=np.int32)
+        self.L.orc_get_block.restype = C.c_double
+        dt_max = self.L.orc_get_block(self.h, v.ctypes.data_as(C.c_void_p))
+        return [int(x) for x in v], float(dt_max)
 
     def set_time(self, t, dt):
         self.L.orc_set_time(self.h, C.c_double(t), C.c_double(dt))

@@ -105,6 +105,8 @@ static void dump_particles(Dump &out, Simulation<ndim> *sim)
   PSCAL(invomega) PSCAL(zeta)
   { vector<double> v; v.push_back(sim->t); v.push_back(sim->timestep); out.d("t_timestep", v); }
   { vector<int> v; v.push_back(sim->n); v.push_back(sim->Nsteps); v.push_back(sim->nresync); out.i("n_Nsteps_nresync", v); }
+  { vector<int> v; v.push_back(sim->level_max); v.push_back(sim->level_step); v.push_back(sim->Nlevels); v.push_back(sim->level_diff_max); out.i("levelmax_levelstep_Nlevels_diffmax", v); }
+  { vector<double> v; v.push_back(sim->dt_max); out.d("dt_max", v); }
 }
 
 #define CSCAL(field)  { vector<double> v(Nc); for (int c=0;c<Nc;c++) v[c]=cd[c].field; out.d("cell_" #field, v); }

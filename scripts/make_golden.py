@@ -81,6 +81,26 @@ def passes(name, nsteps=None):
         print(name, "steps ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+LEVEL_OUT = ["level", "levelneib", "nstep", "nlast", "flags", "tlast", "dt_next", "levelmax_levelstep_Nlevels_diffmax", "dt_max", "div_v",
+             "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd"]
+
+
+def levels(name, nsteps=40):
+    """block timesteps (Nlevels > 1): setup state (incl. the level structure) and the state after nsteps MainLoop calls"""
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["steps", par, os.path.join(tmp, "s"), str(nsteps)], tmp)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"], "nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in STEP_OUT + LEVEL_OUT:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        out["setup_m"] = setup["m"]
+        np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
+        print(name, "levels ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 NBODY_FIELDS = ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt", "t_dt"]
 
 
@@ -122,6 +142,8 @@ if __name__ == "__main__":
     for cfg in cases:
         if cfg == "adsod_mirror_full":
             long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
+        elif cfg.endswith("_levels"):
+            levels(cfg)
         elif cfg == "nbody":
             nbody(256, 0)
             nbody(256, 1)

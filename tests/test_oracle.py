@@ -109,3 +109,42 @@ def test_config1_full_run_bitwise():
     assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
     for k in ("r", "v", "h", "rho", "u"):
         assert np.array_equal(o.get(k), g["final_" + k]), k
+
+
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels"]
+
+
+def upload_block_state(o, g, pre):
+    """particle + clock state of a block-timestep run (Nlevels > 1) from a fixture"""
+    s = lambda k: g[pre + k]  # noqa: E731
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt", "tlast", "dt_next", "div_v",
+              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot"]:
+        o.set(k, s(k))         # inactive particles keep these from their last density / force pass
+    for k in ["level", "levelneib", "nstep", "nlast"]:
+        o.set_int(k, s(k))
+    n, _, nresync = [int(x) for x in s("n_Nsteps_nresync")]
+    lmax, lstep = [int(x) for x in s("levelmax_levelstep_Nlevels_diffmax")[:2]]
+    o.set_block(n, nresync, lmax, lstep, float(s("dt_max")[0]))
+    t0, dt0 = s("t_timestep")
+    o.set_time(float(t0), float(dt0))
+
+
+@pytest.mark.parametrize("case", LEVEL_CASES)
+def test_block_timesteps_bitwise(case):
+    """hierarchical block timesteps (Nlevels = 5): 40 MainLoop calls from the reference's post-setup state - level
+    structure (level, levelneib, nstep, nlast), integer clock and every particle field bit for bit"""
+    g = load_golden(case + "_steps")
+    o = Oracle(read_params_file("%s/%s.dat" % (PARAMS, case)), nthreads=4)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    o.set_particles(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    upload_block_state(o, g, "setup_")
+    o.step(int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    blk, dt_max = o.get_block()
+    n, _, nresync = [int(x) for x in g["final_n_Nsteps_nresync"]]
+    assert blk == [n, nresync] + [int(x) for x in g["final_levelmax_levelstep_Nlevels_diffmax"][:2]]
+    assert dt_max == float(g["final_dt_max"][0])
+    for k in ["level", "levelneib", "nstep", "nlast"]:
+        assert np.array_equal(o.get_int(k), g["final_" + k]), k
+    for k in ["r", "v", "a", "h", "rho", "u", "dudt", "dt", "tlast", "r0", "v0", "a0", "pressure", "sound"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
