@@ -11,7 +11,8 @@ GH_T_NAMES = ["BUILD_TREE", "SPH_PROPERTIES", "SPH_FORCES", "KDK", "GRAV_WALK"]
 FIELDS = {name: i for i, name in enumerate(
     ["r", "v", "a", "atree", "r0", "v0", "a0",
      "m", "h", "u", "u0", "dudt", "dudt0", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound",
-     "pressure", "div_v", "gpot", "gpot_hydro", "alpha", "dalphadt", "dt", "dt_next", "tlast"])}
+     "pressure", "div_v", "gpot", "gpot_hydro", "alpha", "dalphadt", "dt", "dt_next", "tlast",
+     "level", "levelneib", "nstep", "nlast", "flags"])}      # block timesteps: integers carried as doubles
 VECTOR_FIELDS = {"r", "v", "a", "atree", "r0", "v0", "a0"}
 
 
@@ -28,6 +29,7 @@ class Config(C.Structure):
         ("multipole", C.c_int32), ("gravity_mac", C.c_int32), ("Nleafmax", C.c_int32),
         ("energy_integration", C.c_int32), ("device", C.c_int32),
         ("boundary_lhs", C.c_int32 * 3), ("boundary_rhs", C.c_int32 * 3),
+        ("Nlevels", C.c_int32), ("level_diff_max", C.c_int32),
         ("boxmin", C.c_double * 3), ("boxmax", C.c_double * 3),
         ("h_fac", C.c_double), ("h_converge", C.c_double), ("alpha_visc", C.c_double),
         ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("temp0", C.c_double),
@@ -73,6 +75,8 @@ SYMBOLS = {
     "gh_setup": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_set_time": (C.c_int, [_CTX, C.c_double, C.c_double]),
     "gh_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
+    "gh_set_block_clock": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "gh_get_block_clock": (C.c_int, [_CTX, _PI, _PD]),
     "gh_gather_neighbours": (C.c_int, [_CTX, C.c_int64, _PL, _PI]),
     "gh_get_timers": (C.c_int, [_CTX, _PD, C.POINTER(Stats), C.POINTER(Stats)]),
     "gh_reset_timers": (C.c_int, [_CTX]),
@@ -156,6 +160,10 @@ def config_from_params(p, device=0):
     c.gravity_mac = _ENUMS["gravity_mac"][p.get("gravity_mac", "geometric")]
     c.macerror = float(p.get("macerror", 0.0001))
     c.Nleafmax = int(p.get("Nleafmax", 6))
+    c.Nlevels = int(p.get("Nlevels", 1))
+    c.level_diff_max = int(p.get("level_diff_max", 1))
+    if c.Nlevels > 1 and int(p.get("sph_single_timestep", 0)):
+        raise ValueError("sph_single_timestep = 1 is not built")
     c.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
     c.device = device
     for k in range(3):
@@ -312,6 +320,16 @@ class GandalfHip:
         dt = C.c_double()
         self._chk(self.lib.gh_setup(self.ctx, 1 if initial_h_provided else 0, C.byref(dt)))
         return dt.value
+
+    def set_block_clock(self, n, nresync, level_max, level_step, dt_max):
+        """integer clock of a block-timestep run (Simulation: n, nresync, level_max, level_step) and dt_max"""
+        self._chk(self.lib.gh_set_block_clock(self.ctx, n, nresync, level_max, level_step, dt_max))
+
+    def get_block_clock(self):
+        v = np.zeros(4, dtype=np.int32)
+        dt_max = np.zeros(1)
+        self._chk(self.lib.gh_get_block_clock(self.ctx, v.ctypes.data_as(_PI), _dp(dt_max)))
+        return [int(x) for x in v], float(dt_max[0])
 
     def set_time(self, t, timestep):
         self._chk(self.lib.gh_set_time(self.ctx, t, timestep))

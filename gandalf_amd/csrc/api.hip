@@ -227,6 +227,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_blk, sizeof(int)*8));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*8));
   if (cfg->kernel == GH_KERNEL_M4_TAB || cfg->kernel == GH_KERNEL_QUINTIC_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
   return GH_OK;
 }
@@ -336,13 +338,16 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   if ((rc = put(D_U0, u, 1, 0, 0.0))) return rc;
   // SphSimulation.cpp:252-257: alpha = alpha_visc, or alpha_visc_min with time-dependent viscosity
   if ((rc = put(D_ALPHA, nullptr, 1, 0, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? ctx->cfg.alpha_visc_min : ctx->cfg.alpha_visc))) return rc;
+  if ((rc = put(D_FLAGS, nullptr, 1, 0, 1.0))) return rc;              // every particle active until the first EndTimestep
   std::vector<int> ids(n);
   for (size_t i = 0; i < n; i++) ids[i] = (int) i;
   GH_CHECK(ctx, hipMemcpy(ctx->iorig[0], ids.data(), sizeof(int)*n, hipMemcpyHostToDevice));
   ctx->tree_valid = false;
   ctx->n = 0; ctx->Nsteps = 0; ctx->t = 0.0; ctx->timestep = 0.0;
-  double tt[2] = {0.0, 0.0};
+  ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
+  double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*8));
   return GH_OK;
 }
 
@@ -529,6 +534,40 @@ static int push_time(gh_ctx *ctx)
   return GH_OK;
 }
 
+__global__ void k_block_tick(int *blk) { blk[0] = blk[0] + 1; }
+
+// block-timestep clock: host mirror <-> device {n, nresync, level_max, level_step}, dt_max = time[2]
+static int push_block(gh_ctx *ctx)
+{
+  int blk[8] = {ctx->n, ctx->nresync, ctx->level_max, ctx->level_step, 0, 0, 1, 1};
+  GH_CHECK(ctx, hipMemcpy(ctx->d_blk, blk, sizeof(blk), hipMemcpyHostToDevice));
+  GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx) + 2, &ctx->dt_max, sizeof(double), hipMemcpyHostToDevice));
+  return GH_OK;
+}
+static int pull_block(gh_ctx *ctx)
+{
+  int blk[8];
+  GH_CHECK(ctx, hipMemcpy(blk, ctx->d_blk, sizeof(blk), hipMemcpyDeviceToHost));
+  ctx->n = blk[0]; ctx->nresync = blk[1]; ctx->level_max = blk[2]; ctx->level_step = blk[3];
+  GH_CHECK(ctx, hipMemcpy(&ctx->dt_max, gh_time_dev(ctx) + 2, sizeof(double), hipMemcpyDeviceToHost));
+  return GH_OK;
+}
+
+extern "C" int gh_set_block_clock(gh_ctx *ctx, int n, int nresync, int level_max, int level_step, double dt_max)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  ctx->n = n; ctx->nresync = nresync; ctx->level_max = level_max; ctx->level_step = level_step; ctx->dt_max = dt_max;
+  return push_block(ctx);
+}
+
+extern "C" int gh_get_block_clock(gh_ctx *ctx, int32_t *clock4, double *dt_max)
+{
+  if (!ctx) return GH_ERR_INVALID;
+  if (clock4) { clock4[0] = ctx->n; clock4[1] = ctx->nresync; clock4[2] = ctx->level_max; clock4[3] = ctx->level_step; }
+  if (dt_max) *dt_max = ctx->dt_max;
+  return GH_OK;
+}
+
 static int pull_time(gh_ctx *ctx)
 {
   double tt[2];
@@ -616,10 +655,17 @@ extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
   // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
   ctx->t = 0.0; ctx->timestep = 0.0; ctx->n = 0;
   if ((rc = push_time(ctx))) return rc;
-  gh_timestep_impl(ctx);                                 // ComputeGlobalTimestep (:532)
+  if (ctx->cfg.Nlevels > 1) {
+    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
+    ctx->nresync = 0;
+    if ((rc = push_block(ctx))) return rc;
+    gh_block_timesteps_impl(ctx);                        // ComputeBlockTimesteps (:539): n == nresync == 0, resynchronise
+  }
+  else gh_timestep_impl(ctx);                            // ComputeGlobalTimestep (:538)
   gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // hydroint->EndTimestep (:551)
   if ((rc = gh_sync_collect(ctx, "gh_setup"))) return rc;
   if ((rc = pull_time(ctx))) return rc;
+  if (ctx->cfg.Nlevels > 1 && (rc = pull_block(ctx))) return rc;
   if (timestep) *timestep = ctx->timestep;
   return GH_OK;
 }
@@ -631,10 +677,51 @@ extern "C" int gh_set_time(gh_ctx *ctx, double t, double timestep)
   return push_time(ctx);
 }
 
+// one MainLoop call with hierarchical block timesteps (SphSimulation.cpp:574-880, Nlevels > 1): only the particles at
+// the end of their own step are active (density, forces, kick); neighbours on longer steps are drifted (r, v, u) and
+// their pressure / sound refreshed; CheckTimesteps may wake neighbours of fast particles, which repeats the passes
+static int block_step(gh_ctx *ctx)
+{
+  int rc;
+  hipLaunchKernelGGL(k_block_tick, dim3(1), dim3(1), 0, ctx->stream, ctx->d_blk);   // n = n + 1 (:585)
+  ctx->n++; ctx->Nsteps++;
+  gh_advance_time_impl(ctx);
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // all particles drift; active = end of own step
+  gh_phase_end(ctx, GH_T_KDK);
+  if ((rc = build_tree_timed(ctx))) return rc;
+  for (;;) {
+    if ((rc = density_and_hmax(ctx, false))) return rc;
+    gh_zero_acc_impl(ctx);
+    gh_thermal_all_impl(ctx);                            // :665-679, nradstep = 1
+    if ((rc = forces_impl(ctx))) return rc;
+    gh_check_timesteps_impl(ctx);                        // all active flags off, then CheckTimesteps (:739-750)
+    if ((rc = gh_sync_collect(ctx, "gh_step/block"))) return rc;
+    int blk[8];
+    GH_CHECK(ctx, hipMemcpy(blk, ctx->d_blk, sizeof(blk), hipMemcpyDeviceToHost));
+    if (blk[5] == 0) break;
+    GH_CHECK(ctx, hipMemsetAsync(ctx->d_blk + 5, 0, sizeof(int), ctx->stream));
+  }
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_block_timesteps_impl(ctx);                          // ComputeBlockTimesteps (:842)
+  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // EndTimestep of the particles that finished their step
+  gh_phase_end(ctx, GH_T_KDK);
+  if ((rc = gh_sync_collect(ctx, "gh_step/block"))) return rc;
+  return pull_block(ctx);
+}
+
 extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
 {
   if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
   int rc;
+  if (ctx->cfg.Nlevels > 1) {
+    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
+    for (int s = 0; s < nsteps; s++) if ((rc = block_step(ctx))) return rc;
+    if ((rc = pull_time(ctx))) return rc;
+    if (t) *t = ctx->t;
+    if (timestep) *timestep = ctx->timestep;
+    return GH_OK;
+  }
   for (int s = 0; s < nsteps; s++) {
     // SphSimulation::MainLoop (SphSimulation.cpp:585-876), Nlevels = 1, no stars
     ctx->n++; ctx->Nsteps++;

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   const unsigned long long dbg_t0 = wall_clock64();
   unsigned long long dbg_tiles = 0, dbg_passes = 0;
 #endif
-  const bool act = lane < gN;
+  // block timesteps: only the active particles are targets (GradhSphTree.cpp:128-131)
+  const bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   const int i = gfirst + (act ? lane : 0);
 
   const double invndim = 1.0/(double) ND;

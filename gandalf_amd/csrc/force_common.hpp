@@ -162,6 +162,15 @@ __device__ __forceinline__ void stage_neib(const DevicePtrs &d, int ND, double (
 
 // 1/sqrt(x) for x > 0: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps in FMA form; ends within
 // 1-2 ulp.  (ocml's rsqrt also handles denormals/inf/nan, which cannot occur here: x >= 1e-20.)
+// block timesteps: a target of level `mylevel` raises levelneib of neighbour j to its level (GradhSph.cpp:446 with
+// GradhSphTree.cpp:375-417: integer max, propagated to the real particle whatever image was used).  levelneib only
+// grows during a force pass, so a plain read that already shows >= mylevel makes the atomic unnecessary.
+__device__ __forceinline__ void raise_levelneib(const DevicePtrs &d, int j, int mylevel)
+{
+  if ((int) d.f[D_LEVELNEIB][j] < mylevel)
+    atomicMax((unsigned long long*) &d.f[D_LEVELNEIB][j], (unsigned long long) __double_as_longlong((double) mylevel));
+}
+
 // far-field entry evaluation: a += m dr/(dr^2+eps)^(3/2), gpot += m/(dr^2+eps)^(1/2).  The reference
 // writes this once with 1/x and sqrt (cells, NeighbourSearch.h:364-372) and once with 1/sqrt(x) (direct
 // particles, GradhSph.cpp:675-681); both are evaluated here with one rsqrt (<= 2 ulp from either).

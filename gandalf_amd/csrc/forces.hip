@@ -31,14 +31,21 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 {
   __shared__ WalkLDS<int> L;
   __shared__ double s_t[T_NFA][64];
+  __shared__ int s_tj[64], s_tlv[64];                   // block timesteps: particle index and level of every tile slot
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
-  const bool act = lane < gN;
+  // block timesteps (Nlevels > 1) always run the COUNT instantiation: targets are the active particles only and the
+  // pair loop also maintains levelneib
+  const bool lv = COUNT && d.levels;
+  const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  if (lv && !__any(act)) return;
   const int i = gfirst + (act ? lane : 0);
+  const int mylevel = lv ? (int) d.f[D_LEVEL][i] : 0;
+  int lnmax = 0;
   TargetI ti;
   load_target(d, i, ND, ti);
   const bool mm97 = P.avisc == GH_AVISC_MON97MM97;
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
       code_xform(P.dom, code, sg, sh);
       stage_neib(d, ND, s_t, lane, j, sg, sh, valid);
       if (mm97) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
+      if (lv) { s_tj[lane] = valid ? j : 0; s_tlv[lane] = valid ? (int) d.f[D_LEVEL][j] : 0; }
     }
     __syncthreads();
     unsigned long long mask = 0;
@@ -114,6 +122,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         nbr.alpha = mm97 ? s_t[T_ALPHA][c] : 0.0;
         sph_pair<ND, false, KT>(P, ti, A, nbr, dr, r2);
         if (COUNT) n_pairs++;
+        if (lv) { lnmax = max(lnmax, s_tlv[c]); raise_levelneib(d, s_tj[c], mylevel); }
       }
     }
     __syncthreads();
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     // GradhSph.cpp:454-457; the driver ACCUMULATES it on the main array (GradhSphTree.cpp:403) and nothing zeroes
     // it between steps (Sph::ZeroAccelerations does not) - restated as it is
     if (mm97) d.f[D_DALPHADT][i] += 0.1*ti.sound*(P.alpha_visc_min - ti.alpha)*ti.invh + fmax(-A.div_v, 0.0)*(P.alpha_visc - ti.alpha);
+    if (lv) raise_levelneib(d, i, lnmax);                 // GradhSph.cpp:445, GradhSphTree.cpp:405
   }
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_pairs : 0);
@@ -183,8 +193,11 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
-  const bool act = lane < gN;
+  const bool lv = COUNT && d.levels;                  // block timesteps: see k_hydro_forces
+  const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   const int i = gfirst + (act ? lane : 0);
+  const int mylevel = lv ? (int) d.f[D_LEVEL][i] : 0;
+  int lnmax = 0;
   const int nl = 1 << (d.ltot - d.lgroup);            // leaves in this group (<= 16)
   const int leafnode0 = (d.gtot - 1) + q*nl;
 
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           if (ND > 2) r2 += dr[2]*dr[2];
           sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
           if (COUNT) n_pairs++;
+          if (lv && act) { lnmax = max(lnmax, (int) d.f[D_LEVEL][first + k]); raise_levelneib(d, first + k, mylevel); }
         }
       }
     }
@@ -482,6 +496,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     d.f[D_GPOT_HYDRO][i] += A.gpot;
     d.f[D_DUDT][i] += A.dudt;
     d.f[D_DIV_V][i] += A.div_v;
+    if (lv) raise_levelneib(d, i, lnmax);
   }
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_pairs : 0), b = wave_sum_u64(act ? n_direct : 0), c = wave_sum_u64(act ? n_cells : 0);
@@ -510,6 +525,7 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
 
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
 {
+  if (ctx->cfg.Nlevels > 1) count = true;                // the instrumented instantiation carries the block-timestep code
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_hydro_forces: no tree");
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
@@ -535,6 +551,7 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
 // launch of the fused gravity kernel; with only_if != NULL the kernel returns at once unless *only_if is set
 int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
 {
+  if (ctx->cfg.Nlevels > 1) count = true;
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
   fill_force_params(ctx, P);

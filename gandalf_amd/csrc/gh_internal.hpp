@@ -22,8 +22,12 @@ enum FieldD {
   D_R0X, D_R0Y, D_R0Z, D_V0X, D_V0Y, D_V0Z, D_A0X, D_A0Y, D_A0Z,
   D_M, D_H, D_U, D_U0, D_DUDT, D_DUDT0, D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD,
   D_SOUND, D_PRESSURE, D_DIV_V, D_GPOT, D_GPOT_HYDRO, D_ALPHA, D_DALPHADT, D_DT, D_DT_NEXT,
-  D_TLAST, D_COUNT
+  D_TLAST,
+  // block timesteps (Nlevels > 1): integers carried as doubles so that they travel with the particle through the
+  // tree-order permutation; D_FLAGS bit 0 = active, bit 1 = end_timestep.  Untouched (and not permuted) for Nlevels = 1.
+  D_LEVEL, D_LEVELNEIB, D_NSTEP, D_NLAST, D_FLAGS, D_COUNT
 };
+#define D_COUNT_BASE D_LEVEL      /* fields of a global-timestep run */
 
 // KD-tree cell records (heap order), split by consumer so that every walk touches one 64-byte line per
 // node.  Field meanings follow TreeCellBase (reference TreeCell.h:16-49).
@@ -70,6 +74,7 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   double macerror; int mac_stock;  // what the stocking kernels need of the MAC
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
+  int levels;                      // Nlevels > 1: targets are the ACTIVE particles only (flags bit 0)
 };
 
 struct gh_ctx {
@@ -135,6 +140,10 @@ struct gh_ctx {
   // time integration state (reference SimulationBase: n, Nsteps, t, timestep)
   int n = 0, Nsteps = 0;
   double t = 0.0, timestep = 0.0;
+  // block-timestep clock (Simulation.h: nresync, level_max, level_step, dt_max); the device copy is authoritative
+  int nresync = 0, level_max = 0, level_step = 0;
+  double dt_max = 0.0;
+  int *d_blk = nullptr;            // device {n, nresync, level_max, level_step, level_max_new, activecount, nfactor_mul, nfactor_div}
 
   // multi-GPU work shard
   int rank = 0, nranks = 1;
@@ -197,6 +206,10 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int n, double t, double timestep);
 int gh_kdk_end_impl(gh_ctx *ctx, int n, double t, double timestep);
 int gh_timestep_impl(gh_ctx *ctx);          // leaves min dt in ctx->redbuf[0] and writes dt_next
 int gh_pack_posm(gh_ctx *ctx);
+// block timesteps (integrate.hip)
+int gh_thermal_all_impl(gh_ctx *ctx);
+int gh_block_timesteps_impl(gh_ctx *ctx);
+int gh_check_timesteps_impl(gh_ctx *ctx);
 // phase timing with HIP events on ctx->stream; read back by gh_sync_collect
 int gh_phase_begin(gh_ctx *ctx, int phase);
 int gh_phase_end(gh_ctx *ctx, int phase);

@@ -366,6 +366,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   if (Nt == 0) return;
   if (Nt > MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
   const int occ = d.leafocc;
+  // block timesteps (Nlevels > 1, always the COUNT instantiation): a leaf without active particles has no work
+  // (Tree::ComputeActiveCellList, Tree.cpp:91-115); otherwise all of its particles are evaluated, the active ones stored
+  const bool lv = COUNT && d.levels;
+  unsigned int actmask = ~0u;
+  if (lv) {
+    actmask = 0;
+    for (int t = 0; t < Nt; t++) if ((int) d.f[D_FLAGS][first + t] & 1) actmask |= 1u << t;
+    if (!actmask) return;
+  }
 
   // slots >= Nt of a partly filled leaf hold a copy of particle 0: the point-mass loops then run unguarded
   // over all MAXOCC slots (independent chains the scheduler can interleave); their sums are never stored
@@ -658,6 +667,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       Accum A;
       for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
       A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
+      const int mylevel = lv ? (int) d.f[D_LEVEL][first + i] : 0;
+      int lnm = 0;
       for (int c0 = 0; c0 < ns; c0 += 64) {
         if (c0 + lane < ns) {
           const int j = s_sph[i][c0 + lane];
@@ -674,7 +685,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
           sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
+          if (lv && ((actmask >> i) & 1u)) { lnm = max(lnm, (int) d.f[D_LEVEL][j]); raise_levelneib(d, j, mylevel); }
         }
+      }
+      if (lv && ((actmask >> i) & 1u) && ns > 0) {         // GradhSph.cpp:569, GradhSphTree.cpp:619
+        for (int off = 32; off > 0; off >>= 1) lnm = max(lnm, __shfl_xor(lnm, off));
+        if (lane == 0) raise_levelneib(d, first + i, lnm);
       }
       if (COUNT) n_pairs += (unsigned long long) ns;
       // reduce this particle's sums over the wave, four values per pass (rows hold values 0,2,1,3);
@@ -710,6 +726,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
       A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
       unsigned long long npair = 0;
+      const int mylevel = lv ? (int) d.f[D_LEVEL][first + i] : 0;
+      int lnm = 0;
       auto slow_tile = [&](bool valid, int j, int) {
         if (valid) {
           const double4 *r = d.hrec + 4*(size_t) j;
@@ -728,6 +746,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             nb.invh = q2.x; nb.hfac = q2.y; nb.pfac = q2.z; nb.invrho = q2.w; nb.sound = q3.x; nb.zeta = q3.y; nb.u = q3.z; nb.press = q3.w;
             sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
             npair++;
+            if (lv && ((actmask >> i) & 1u)) { lnm = max(lnm, (int) d.f[D_LEVEL][j]); raise_levelneib(d, j, mylevel); }
           }
         }
       };
@@ -744,6 +763,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       }
       range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, slow_tile);
       if (COUNT) n_pairs += wave_sum_u64(npair);
+      if (lv && ((actmask >> i) & 1u)) {
+        for (int off = 32; off > 0; off >>= 1) lnm = max(lnm, __shfl_xor(lnm, off));
+        if (lane == 0) raise_levelneib(d, first + i, lnm);
+      }
       double red[9];
       for (int k = 0; k < 3; k++) { red[k] = wave_sum_d(A.a[k]); red[3 + k] = wave_sum_d(A.at[k]); }
       red[6] = wave_sum_d(A.dudt); red[7] = wave_sum_d(A.div_v); red[8] = wave_sum_d(A.gpot);
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
   }
   __syncthreads();
-  if (lane < Nt) {
+  if (lane < Nt && ((actmask >> lane) & 1u)) {
     // GradhSph.cpp:577-578 then GradhSphTree.cpp:596-619
     const int i = first + lane;
     const TargetI &ti = s_tg[lane];
@@ -785,6 +808,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // ================================================================================================
 int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
+  if (ctx->cfg.Nlevels > 1) count = true;                // the instrumented instantiation carries the block-timestep code
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
   int cap_c = 4096, cap_d = 256, cap_h = 1024;
   // small trees: a strict relative MAC (gadget2, small macerror) degenerates towards a direct sum, so let a leaf

@@ -15,6 +15,12 @@ __global__ void k_zero_acc(DevicePtrs d)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
+  if (d.levels) {
+    // block timesteps: active particles only (Sph.cpp:130).  The reference zeroes levelneib here and the particle's own
+    // pair (always inside its kernel) raises it to its level again (GradhSph.cpp:445): start from the level
+    if (!((int) d.f[D_FLAGS][i] & 1)) return;
+    d.f[D_LEVELNEIB][i] = d.f[D_LEVEL][i];
+  }
   d.f[D_DIV_V][i] = 0.0; d.f[D_DUDT][i] = 0.0; d.f[D_GPOT][i] = 0.0; d.f[D_GPOT_HYDRO][i] = 0.0;
   for (int k = 0; k < 3; k++) { d.f[D_AX + k][i] = 0.0; d.f[D_ATX + k][i] = 0.0; }
 }
@@ -22,7 +28,7 @@ __global__ void k_zero_acc(DevicePtrs d)
 // time[0] = t, time[1] = timestep.  advance: t <- t + timestep first (SphSimulation.cpp:587)
 __global__ void k_advance_time(double *time) { time[0] = time[0] + time[1]; }
 
-__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration, int tdavisc)
+__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration, int tdavisc, const int *blk)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
@@ -52,25 +58,38 @@ __global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int 
   }
   if (tdavisc) d.f[D_ALPHA][i] += d.f[D_DALPHADT][i]*time[1];              // SphLeapfrogKDK.cpp:111 (the global timestep)
   if (energy_integration) d.f[D_U][i] = d.f[D_U0][i] + d.f[D_DUDT0][i]*dt;
+  if (d.levels) {                                                         // SphLeapfrogKDK.cpp:117-118
+    const int fl = (int) d.f[D_FLAGS][i];
+    const bool active = blk[0] - (int) d.f[D_NLAST][i] == (int) d.f[D_NSTEP][i];
+    d.f[D_FLAGS][i] = (double) (active ? (fl | 1) : (fl & ~1));
+  }
 }
 
 struct TimestepParams { double courant_mult, accel_mult, energy_mult; int energy_integration, hydro_forces; };
+
+// SphIntegration::Timestep, SphIntegration.cpp:81-134
+__device__ __forceinline__ double particle_timestep(const DevicePtrs &d, const TimestepParams &tp, int i)
+{
+  const double h = d.f[D_H][i];
+  const double divv = fabs(d.f[D_DIV_V][i]);
+  double ts;
+  if (tp.hydro_forces) ts = tp.courant_mult*h/(d.f[D_SOUND][i] + h*divv + GH_SMALL_DP);
+  else ts = tp.courant_mult*h/(h*divv + GH_SMALL_DP);
+  double a2 = 0.0;
+  for (int k = 0; k < d.ndim; k++) { const double a = d.f[D_AX + k][i]; a2 += a*a; }
+  const double amag = sqrt(a2);
+  ts = fmin(ts, tp.accel_mult*sqrt(h/(amag + GH_SMALL_DP)));
+  if (tp.energy_integration) ts = fmin(ts, tp.energy_mult*(d.f[D_U][i]/(fabs(d.f[D_DUDT][i]) + GH_SMALL)));
+  return ts;
+}
 
 __global__ void k_timestep_partial(DevicePtrs d, TimestepParams tp, double *partial)
 {
   __shared__ double s[256];
   double dtmin = 9.9e50;                                   // big_number_dp
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
-    const double h = d.f[D_H][i];
-    const double divv = fabs(d.f[D_DIV_V][i]);
-    double ts;
-    if (tp.hydro_forces) ts = tp.courant_mult*h/(d.f[D_SOUND][i] + h*divv + GH_SMALL_DP);
-    else ts = tp.courant_mult*h/(h*divv + GH_SMALL_DP);
-    double a2 = 0.0;
-    for (int k = 0; k < d.ndim; k++) { const double a = d.f[D_AX + k][i]; a2 += a*a; }
-    const double amag = sqrt(a2);
-    ts = fmin(ts, tp.accel_mult*sqrt(h/(amag + GH_SMALL_DP)));
-    if (tp.energy_integration) ts = fmin(ts, tp.energy_mult*(d.f[D_U][i]/(fabs(d.f[D_DUDT][i]) + GH_SMALL)));
+    const double ts = particle_timestep(d, tp, i);
+    if (d.levels) d.f[D_DT_NEXT][i] = ts;                  // resynchronisation of the block structure, Simulation.cpp:1816
     dtmin = fmin(dtmin, ts);
   }
   s[threadIdx.x] = dtmin;
@@ -102,10 +121,15 @@ __global__ void k_set_dt_next(DevicePtrs d, const double *time)
   if (i < d.N) d.f[D_DT_NEXT][i] = time[1];
 }
 
-__global__ void k_kdk_end(DevicePtrs d, const double *time, int energy_integration)
+__global__ void k_kdk_end(DevicePtrs d, const double *time, int energy_integration, const int *blk)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
+  if (d.levels) {                                          // only particles at the end of their step (SphLeapfrogKDK.cpp:241)
+    if (!((int) d.f[D_FLAGS][i] & 2)) return;
+    d.f[D_NLAST][i] = (double) blk[0];
+    d.f[D_FLAGS][i] = 0.0;
+  }
   const double dt = d.f[D_DT][i];
   for (int k = 0; k < d.ndim; k++) {
     const double a = d.f[D_AX + k][i];
@@ -141,7 +165,7 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int, double, double)
   Domain dom;
   gh_fill_domain(ctx, dom);
   hipLaunchKernelGGL(k_kdk_advance, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), dom,
-                     gh_time_dev(ctx), ctx->cfg.energy_integration, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? 1 : 0);
+                     gh_time_dev(ctx), ctx->cfg.energy_integration, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? 1 : 0, ctx->d_blk);
   return GH_OK;
 }
 
@@ -166,6 +190,195 @@ int gh_timestep_impl(gh_ctx *ctx)
 int gh_kdk_end_impl(gh_ctx *ctx, int, double, double)
 {
   hipLaunchKernelGGL(k_kdk_end, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), gh_time_dev(ctx),
-                     ctx->cfg.energy_integration);
+                     ctx->cfg.energy_integration, ctx->d_blk);
+  return GH_OK;
+}
+
+// ================================================================================================
+// hierarchical block timesteps (Nlevels > 1)
+//   Simulation::ComputeBlockTimesteps (Simulation.cpp:1764-2200, hydro particles only),
+//   SphLeapfrogKDK::CheckTimesteps (SphLeapfrogKDK.cpp:284-330) and the all-particle thermal refresh of the main loop
+//   (SphSimulation.cpp:665-679).  The integer clock lives on the device:
+//     blk = {n, nresync, level_max, level_step, level_max_new, activecount, nfactor_mul, nfactor_div};  time[2] = dt_max.
+// ================================================================================================
+// (int) pow(2, e) of the reference: 0 for e < 0 (a particle that moves to a level created in the same call gets
+// nstep = 0 and therefore dt_next = 0 until the next pass refreshes nstep, Simulation.cpp:1989-1990 with :2141-2146)
+__device__ __forceinline__ int ipow2(int e) { return e >= 0 ? (1 << e) : 0; }
+
+enum { B_N = 0, B_NRESYNC, B_LMAX, B_LSTEP, B_LMAXNEW, B_ACTIVE, B_MUL, B_DIV };
+
+// ComputeTimestepLevel, InlineFuncs.h:550-558
+__device__ __forceinline__ int timestep_level(double dt, double dt_max)
+{
+  const int l = (int) (1.44269504088896*log(dt_max/dt)) + 1;
+  return l > 0 ? l : 0;
+}
+
+__global__ void k_thermal_all(DevicePtrs d, EosParams eos)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  double u = d.f[D_U][i], sound, press;
+  eos_eval(eos, d.f[D_RHO][i], u, sound, press);
+  d.f[D_U][i] = u; d.f[D_SOUND][i] = sound; d.f[D_PRESSURE][i] = press;
+}
+
+// resynchronisation (:1795-1924): time[1] holds the minimum timestep found by k_timestep_partial/final
+__global__ void k_block_resync_clock(int *blk, double *time, int Nlevels)
+{
+  blk[B_N] = 0;
+  blk[B_LMAX] = Nlevels - 1;
+  blk[B_LSTEP] = Nlevels - 1;                                // level_max + integration_step - 1, integration_step = 1 (lfkdk)
+  time[2] = time[1]*(double) (1 << (Nlevels - 1));           // dt_max = timestep*2^level_max
+}
+__global__ void k_block_resync_assign(DevicePtrs d, const int *blk, const double *time)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  const int level_max = blk[B_LMAX], level_step = blk[B_LSTEP];
+  int level = timestep_level(d.f[D_DT_NEXT][i], time[2]);
+  level = level < level_max ? level : level_max;
+  const int nstep = ipow2(level_step - level);
+  d.f[D_LEVEL][i] = (double) level; d.f[D_LEVELNEIB][i] = (double) level;
+  d.f[D_NSTEP][i] = (double) nstep; d.f[D_NLAST][i] = 0.0;
+  d.f[D_DT_NEXT][i] = (double) nstep*time[1];                // with the minimum timestep, :1913
+  d.f[D_FLAGS][i] = (double) ((int) d.f[D_FLAGS][i] | 2);
+}
+__global__ void k_block_resync_finish(int *blk, double *time)
+{
+  blk[B_NRESYNC] = 1 << blk[B_LSTEP];
+  time[1] = time[2]/(double) blk[B_NRESYNC];
+}
+
+// no resynchronisation (:1929-2150), pass 1: particles that end their step pick their new level
+__global__ void k_block_levels(DevicePtrs d, TimestepParams tp, int *blk, const double *time, int level_diff_max)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  int mylevel = 0;
+  if (i < d.N) {
+    const int n = blk[B_N], level_step = blk[B_LSTEP];
+    const int nlast = (int) d.f[D_NLAST][i], nstep = (int) d.f[D_NSTEP][i];
+    int level_i = (int) d.f[D_LEVEL][i];
+    if (n - nlast == nstep) {
+      const int levelneib = (int) d.f[D_LEVELNEIB][i];
+      const double dt = particle_timestep(d, tp, i);
+      int level = timestep_level(dt, time[2]);
+      level = max(level, levelneib - level_diff_max);
+      if (nstep != ipow2(level_step - level_i)) {          // step cut short by CheckTimesteps (:1956-1966)
+        level_i = max(level_i, level);
+        d.f[D_LEVELNEIB][i] = (double) level_i;
+      }
+      else {                                                 // natural end of the step (:1968-1992)
+        const int last_level = level_i;
+        if (level < last_level && last_level > 1 && n%(2*nstep) == 0) level_i = last_level - 1;
+        else if (level > last_level) level_i = level;
+        d.f[D_LEVELNEIB][i] = (double) level;
+      }
+      const int ns = ipow2(level_step - level_i);
+      d.f[D_LEVEL][i] = (double) level_i;
+      d.f[D_NLAST][i] = (double) n;
+      d.f[D_NSTEP][i] = (double) ns;
+      d.f[D_DT_NEXT][i] = (double) ns*time[1];
+      d.f[D_FLAGS][i] = (double) ((int) d.f[D_FLAGS][i] | 2);
+    }
+    mylevel = level_i;
+  }
+  int wm = mylevel;
+  for (int off = 32; off > 0; off >>= 1) wm = max(wm, __shfl_xor(wm, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(&blk[B_LMAXNEW], wm);
+}
+// pass 2: the clock (:2097-2136)
+__global__ void k_block_clock(int *blk, double *time)
+{
+  const int level_max_old = blk[B_LMAX], level_step_old = blk[B_LSTEP];
+  int level_max = blk[B_LMAXNEW], n = blk[B_N];
+  const int istep = 1 << (level_step_old - level_max_old + 1);
+  int mul = 1, div = 1;
+  if (level_max > level_max_old) { mul = 1 << (level_max - level_max_old); n *= mul; }
+  else if (level_max <= level_max_old - 1 && level_max_old > 1 && n%istep == 0) { level_max = level_max_old - 1; div = 2; n /= 2; }
+  else level_max = level_max_old;
+  blk[B_N] = n; blk[B_LMAX] = level_max; blk[B_LSTEP] = level_max;
+  blk[B_NRESYNC] = 1 << level_max;
+  blk[B_MUL] = mul; blk[B_DIV] = div; blk[B_LMAXNEW] = 0;
+  time[1] = time[2]/(double) blk[B_NRESYNC];
+}
+// pass 3: rescale the integer times, refresh nstep of the particles that just ended their step (:2101-2146)
+__global__ void k_block_rescale(DevicePtrs d, const int *blk)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  const int mul = blk[B_MUL], div = blk[B_DIV];
+  int nstep = (int) d.f[D_NSTEP][i], nlast = (int) d.f[D_NLAST][i];
+  nstep = nstep*mul/div; nlast = nlast*mul/div;
+  if (nlast == blk[B_N]) nstep = ipow2(blk[B_LSTEP] - (int) d.f[D_LEVEL][i]);
+  d.f[D_NSTEP][i] = (double) nstep; d.f[D_NLAST][i] = (double) nlast;
+}
+
+// all active flags off, then CheckTimesteps: particles whose neighbours run on much shorter steps end theirs early
+__global__ void k_check_timesteps(DevicePtrs d, int *blk, int level_diff_max)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  int woke = 0;
+  if (i < d.N) {
+    int fl = (int) d.f[D_FLAGS][i] & ~1;
+    const int dn = blk[B_N] - (int) d.f[D_NLAST][i];
+    const int level = (int) d.f[D_LEVEL][i], levelneib = (int) d.f[D_LEVELNEIB][i];
+    if (dn != (int) d.f[D_NSTEP][i] && levelneib - level > level_diff_max) {
+      const int level_new = levelneib - level_diff_max;
+      const int nnewstep = ipow2(blk[B_LSTEP] - level_new);
+      if (dn%nnewstep == 0) {
+        if (dn > 0) d.f[D_NSTEP][i] = (double) dn;
+        d.f[D_LEVEL][i] = (double) level_new;
+        fl |= 1; woke = 1;
+      }
+    }
+    d.f[D_FLAGS][i] = (double) fl;
+  }
+  const unsigned long long m = __ballot(woke);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&blk[B_ACTIVE], __popcll(m));
+}
+
+static TimestepParams fill_tp(gh_ctx *ctx)
+{
+  TimestepParams tp;
+  tp.courant_mult = ctx->cfg.courant_mult; tp.accel_mult = ctx->cfg.accel_mult; tp.energy_mult = ctx->cfg.energy_mult;
+  tp.energy_integration = ctx->cfg.energy_integration; tp.hydro_forces = ctx->cfg.hydro_forces;
+  return tp;
+}
+
+int gh_thermal_all_impl(gh_ctx *ctx)
+{
+  EosParams eos;
+  gh_fill_eos(ctx, eos);
+  hipLaunchKernelGGL(k_thermal_all, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), eos);
+  return GH_OK;
+}
+
+// Simulation::ComputeBlockTimesteps; the host knows n and nresync (read back after every step)
+int gh_block_timesteps_impl(gh_ctx *ctx)
+{
+  hipStream_t s = ctx->stream;
+  const int nb = cdiv(ctx->N, 256);
+  DevicePtrs d = gh_dev(ctx);
+  double *time = gh_time_dev(ctx);
+  if (ctx->n == ctx->nresync) {
+    const int nblk = 256;
+    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, s, d, fill_tp(ctx), ctx->redbuf);
+    hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
+    hipLaunchKernelGGL(k_block_resync_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time, ctx->cfg.Nlevels);
+    hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time);
+    hipLaunchKernelGGL(k_block_resync_finish, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
+  }
+  else {
+    hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
+    hipLaunchKernelGGL(k_block_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
+    hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk);
+  }
+  return GH_OK;
+}
+
+int gh_check_timesteps_impl(gh_ctx *ctx)
+{
+  hipLaunchKernelGGL(k_check_timesteps, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->d_blk, ctx->cfg.level_diff_max);
   return GH_OK;
 }

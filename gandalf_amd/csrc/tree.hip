@@ -615,6 +615,7 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   d.cfirst = ctx->cfirst; d.cN = ctx->cN;
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
+  d.levels = ctx->cfg.Nlevels > 1 ? 1 : 0;
   return d;
 }
 
@@ -778,7 +779,7 @@ int gh_tree_build_impl(gh_ctx *ctx)
   // gather every particle array into tree order (perm[new] = old position).  The two pointer tables
   // (buffer 0 -> 1 and 1 -> 0) live in device memory since allocation: no host synchronisation here.
   const int *perm = ctx->P[pb][0];
-  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), D_COUNT), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, N);
+  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, N);
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
   ctx->cur ^= 1;
   stock_tree(ctx, 0);

@@ -26,6 +26,8 @@ void Parameters::SetDefaultValues()
   floatparams["accel_mult"] = 0.3;
   floatparams["courant_mult"] = 0.15;
   intparams["Nlevels"] = 1;
+  intparams["level_diff_max"] = 1;
+  intparams["sph_single_timestep"] = 0;
   stringparams["sph_integration"] = "lfkdk";
   stringparams["kernel"] = "m4";
   intparams["tabulated_kernel"] = 1;

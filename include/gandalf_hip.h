@@ -65,6 +65,8 @@ typedef struct gh_config {
   int32_t device;          /* HIP device ordinal */
   int32_t boundary_lhs[3]; /* boundary_lhs[k] */
   int32_t boundary_rhs[3]; /* boundary_rhs[k] */
+  int32_t Nlevels;         /* Nlevels: 1 = global timestep, > 1 = hierarchical block timesteps (Simulation.cpp:1764-2200) */
+  int32_t level_diff_max;  /* level_diff_max: largest level difference tolerated between SPH neighbours (SphLeapfrogKDK.cpp:284-330) */
   double  boxmin[3];       /* boxmin[k] */
   double  boxmax[3];       /* boxmax[k] */
   double  h_fac;           /* h_fac */
@@ -89,6 +91,9 @@ enum {
   GH_F_M, GH_F_H, GH_F_U, GH_F_U0, GH_F_DUDT, GH_F_DUDT0, GH_F_RHO, GH_F_INVOMEGA, GH_F_ZETA,
   GH_F_HFACTOR, GH_F_HRANGESQD, GH_F_SOUND, GH_F_PRESSURE, GH_F_DIV_V, GH_F_GPOT, GH_F_GPOT_HYDRO,
   GH_F_ALPHA, GH_F_DALPHADT, GH_F_DT, GH_F_DT_NEXT, GH_F_TLAST,                 /* scalars */
+  /* block timesteps (Particle.h:137-142), integers carried as doubles: level, levelneib, nstep, nlast and the flag
+   * word (bit 0 active, bit 1 end_timestep) */
+  GH_F_LEVEL, GH_F_LEVELNEIB, GH_F_NSTEP, GH_F_NLAST, GH_F_FLAGS,
   GH_F_COUNT
 };
 
@@ -132,6 +137,14 @@ int gh_build_tree(gh_ctx *ctx);
 /* tree export for parity tests, in the reference's pre-order cell numbering (KDTree.cpp:362-433).
  * Any pointer may be NULL.  Ncell = 2*gtot-1.  cell_first/cell_N index the `order` array:
  * order[cell_first[c] .. +cell_N[c]) are the caller-order ids of the particles of cell c. */
+/* Hierarchical block timesteps (Nlevels > 1).  Replaces Simulation::ComputeBlockTimesteps (Simulation.cpp:1764-2200),
+ * SphLeapfrogKDK::CheckTimesteps (SphLeapfrogKDK.cpp:284-330) and the active-particle bookkeeping of
+ * SphSimulation::MainLoop (SphSimulation.cpp:574-880); gh_setup / gh_step run them when cfg.Nlevels > 1.  The integer
+ * clock of the reference's Simulation object (n, nresync, level_max, level_step) and dt_max can be set and read for
+ * restarts: clock4 = {n, nresync, level_max, level_step}. */
+int gh_set_block_clock(gh_ctx *ctx, int n, int nresync, int level_max, int level_step, double dt_max);
+int gh_get_block_clock(gh_ctx *ctx, int32_t *clock4, double *dt_max);
+
 int gh_tree_size(gh_ctx *ctx, int32_t *Ncell, int32_t *ltot, int32_t *gtot);
 int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_first, int32_t *cell_N,
                    double *bbmin, double *bbmax, double *hboxmin, double *hboxmax, double *rcell,

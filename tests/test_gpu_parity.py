@@ -181,3 +181,42 @@ def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):
     assert st["n_cells"] > 0
     assert vec_err(sim.download("a"), g["force_a"]) < 1e-11
     assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
+
+
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels"]
+
+
+@pytest.mark.parametrize("case", LEVEL_CASES)
+def test_block_timesteps_match_reference(case):
+    """hierarchical block timesteps (Nlevels = 5): 40 MainLoop calls from the reference's post-setup state.  The level
+    structure and the integer clock are integers and must be identical; particle fields within the step tolerances."""
+    g = load_golden(case + "_steps")
+    sim, _ = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    sim.upload(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt", "tlast", "dt_next", "div_v",
+              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot",
+              "level", "levelneib", "nstep", "nlast"]:
+        sim.upload_field(k, np.asarray(s(k), dtype=np.float64))
+    sim.upload_field("flags", np.zeros(len(s("m"))))
+    n, _, nresync = [int(x) for x in s("n_Nsteps_nresync")]
+    lmax, lstep = [int(x) for x in s("levelmax_levelstep_Nlevels_diffmax")[:2]]
+    sim.set_block_clock(n, nresync, lmax, lstep, float(s("dt_max")[0]))
+    t0, dt0 = s("t_timestep")
+    sim.set_time(float(t0), float(dt0))
+    t, dt = sim.step(int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert abs(t - tf) <= 1e-12*abs(tf) and abs(dt - dtf) <= 1e-12*abs(dtf)
+    clock, dt_max = sim.get_block_clock()
+    nf, _, nresf = [int(x) for x in g["final_n_Nsteps_nresync"]]
+    assert clock == [nf, nresf] + [int(x) for x in g["final_levelmax_levelstep_Nlevels_diffmax"][:2]]
+    assert abs(dt_max - float(g["final_dt_max"][0])) <= 1e-12*dt_max
+    for k in ["level", "levelneib", "nstep", "nlast"]:
+        assert np.array_equal(sim.download(k).astype(np.int64), g["final_" + k]), k
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-11*np.abs(g["final_r"]).max()
+    assert np.max(np.abs(sim.download("v") - g["final_v"])) < 1e-10*max(np.abs(g["final_v"]).max(), 1e-3)
+    assert relerr(sim.download("h"), g["final_h"]) < 1e-10
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
+    assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
+    assert relerr(sim.download("u"), g["final_u"]) < 1e-10
+    assert relerr(sim.download("tlast"), g["final_tlast"], floor=1e-300) < 1e-12
