@@ -112,3 +112,26 @@ def test_config1_full_run_vs_reference():
     assert np.max(np.abs(dev.download("v") - g["final_v"])) < 1e-7
     rho = dev.download("rho")
     assert 0.2 < rho.min() and rho.max() < 1.1          # between the two initial states (rhofluid2 = 0.25, rhofluid1 = 1)
+
+
+@pytest.mark.parametrize("case", ["adsod_1d_levels", "plummer_4k_levels"])
+def test_block_timesteps_from_ic(case):
+    """whole run with hierarchical block timesteps through the host shell: our IC generator, gh_setup (which builds the
+    level structure by a resynchronisation) and 40 MainLoop calls, against the reference's state after the same run"""
+    from gandalf_amd.host import Simulation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", case + "_steps.npz"))
+    sim = Simulation(os.path.join(PARAMS, case + ".dat"))
+    sim.generate_ic()
+    sim.post_ic_setup()
+    dev = sim.device()
+    for k in ["level", "nstep", "nlast"]:          # the level ladder right after setup
+        assert np.array_equal(dev.download(k).astype(np.int64), g["setup_" + k]), k
+    clock, dt_max = dev.get_block_clock()
+    assert clock[1:] == [int(g["setup_n_Nsteps_nresync"][2])] + [int(x) for x in g["setup_levelmax_levelstep_Nlevels_diffmax"][:2]]
+    assert abs(dt_max - float(g["setup_dt_max"][0])) < 1e-10*dt_max
+    sim.main_loop(int(g["nsteps"][0]))
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-10*abs(g["final_t_timestep"][0])
+    for k in ["level", "nstep", "nlast"]:
+        assert np.array_equal(dev.download(k).astype(np.int64), g["final_" + k]), k
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-9*np.abs(g["final_r"]).max()
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-8
