@@ -77,6 +77,7 @@ SYMBOLS = {
     "gh_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
     "gh_set_block_clock": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "gh_get_block_clock": (C.c_int, [_CTX, _PI, _PD]),
+    "gh_get_active_count": (C.c_int, [_CTX, _PL, C.c_int]),
     "gh_gather_neighbours": (C.c_int, [_CTX, C.c_int64, _PL, _PI]),
     "gh_get_timers": (C.c_int, [_CTX, _PD, C.POINTER(Stats), C.POINTER(Stats)]),
     "gh_reset_timers": (C.c_int, [_CTX]),
@@ -324,6 +325,12 @@ class GandalfHip:
     def set_block_clock(self, n, nresync, level_max, level_step, dt_max):
         """integer clock of a block-timestep run (Simulation: n, nresync, level_max, level_step) and dt_max"""
         self._chk(self.lib.gh_set_block_clock(self.ctx, n, nresync, level_max, level_step, dt_max))
+
+    def active_count(self, reset=False):
+        """particle force evaluations since the last reset (block-timestep runs)"""
+        v = np.zeros(1, dtype=np.int64)
+        self._chk(self.lib.gh_get_active_count(self.ctx, v.ctypes.data_as(_PL), 1 if reset else 0))
+        return int(v[0])
 
     def get_block_clock(self):
         v = np.zeros(4, dtype=np.int32)

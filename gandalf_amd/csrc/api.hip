@@ -227,8 +227,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
-  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_blk, sizeof(int)*8));
-  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*8));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_blk, sizeof(int)*16));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
   if (cfg->kernel == GH_KERNEL_M4_TAB || cfg->kernel == GH_KERNEL_QUINTIC_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
   return GH_OK;
 }
@@ -347,7 +347,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
-  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*8));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
   return GH_OK;
 }
 
@@ -558,6 +558,17 @@ extern "C" int gh_set_block_clock(gh_ctx *ctx, int n, int nresync, int level_max
   if (!ctx) return GH_ERR_INVALID;
   ctx->n = n; ctx->nresync = nresync; ctx->level_max = level_max; ctx->level_step = level_step; ctx->dt_max = dt_max;
   return push_block(ctx);
+}
+
+extern "C" int gh_get_active_count(gh_ctx *ctx, int64_t *nactive, int reset)
+{
+  if (!ctx || !nactive) return GH_ERR_INVALID;
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long v = 0;
+  GH_CHECK(ctx, hipMemcpy(&v, ctx->d_blk + 8, sizeof(v), hipMemcpyDeviceToHost));
+  *nactive = (int64_t) v;
+  if (reset) GH_CHECK(ctx, hipMemset(ctx->d_blk + 8, 0, sizeof(v)));
+  return GH_OK;
 }
 
 extern "C" int gh_get_block_clock(gh_ctx *ctx, int32_t *clock4, double *dt_max)

@@ -38,9 +38,9 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
-  // block timesteps (Nlevels > 1) always run the COUNT instantiation: targets are the active particles only and the
-  // pair loop also maintains levelneib
-  const bool lv = COUNT && d.levels;
+  // block timesteps (Nlevels > 1, wave-uniform flag): targets are the active particles only and the pair loop also
+  // maintains levelneib
+  const bool lv = d.levels != 0;
   const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   if (lv && !__any(act)) return;
   const int i = gfirst + (act ? lane : 0);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
-  const bool lv = COUNT && d.levels;                  // block timesteps: see k_hydro_forces
+  const bool lv = d.levels != 0;                  // block timesteps: see k_hydro_forces
   const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   const int i = gfirst + (act ? lane : 0);
   const int mylevel = lv ? (int) d.f[D_LEVEL][i] : 0;
@@ -525,7 +525,6 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
 
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
 {
-  if (ctx->cfg.Nlevels > 1) count = true;                // the instrumented instantiation carries the block-timestep code
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_hydro_forces: no tree");
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
@@ -551,7 +550,6 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
 // launch of the fused gravity kernel; with only_if != NULL the kernel returns at once unless *only_if is set
 int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
 {
-  if (ctx->cfg.Nlevels > 1) count = true;
   DevicePtrs d = gh_dev(ctx);
   ForceParams P;
   fill_force_params(ctx, P);

@@ -89,6 +89,19 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
     Amin = wave_min(amn); Amax = wave_max(amx);
   }
   for (int l = 0; l < nl; l++) if (d.cN[leafnode0 + l] > 0) allmask |= 1u << l;
+  if (d.levels) {
+    // block timesteps: only leaves with an active particle get lists (Tree::ComputeActiveCellList, Tree.cpp:91-115);
+    // the evaluation kernel never looks at the others
+    unsigned int am = 0;
+    for (int l = 0; l < nl; l++) {
+      const int f0 = d.cfirst[leafnode0 + l], cn = d.cN[leafnode0 + l];
+      bool a = false;
+      for (int t = 0; t < cn; t++) a = a || ((int) d.f[D_FLAGS][f0 + t] & 1);
+      if (a) am |= 1u << l;
+    }
+    allmask &= am;
+    if (!allmask) return;
+  }
   // list lengths: wave-uniform, in scalar registers (loops over leaves are fully unrolled)
   int len_c[GH_MAXLEAF], len_d[GH_MAXLEAF], len_h[GH_MAXLEAF];
 #pragma unroll
@@ -366,9 +379,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   if (Nt == 0) return;
   if (Nt > MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
   const int occ = d.leafocc;
-  // block timesteps (Nlevels > 1, always the COUNT instantiation): a leaf without active particles has no work
+  // block timesteps (Nlevels > 1, wave-uniform flag): a leaf without active particles has no work
   // (Tree::ComputeActiveCellList, Tree.cpp:91-115); otherwise all of its particles are evaluated, the active ones stored
-  const bool lv = COUNT && d.levels;
+  const bool lv = d.levels != 0;
   unsigned int actmask = ~0u;
   if (lv) {
     actmask = 0;
@@ -808,7 +821,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // ================================================================================================
 int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
-  if (ctx->cfg.Nlevels > 1) count = true;                // the instrumented instantiation carries the block-timestep code
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
   int cap_c = 4096, cap_d = 256, cap_h = 1024;
   // small trees: a strict relative MAC (gadget2, small macerror) degenerates towards a direct sum, so let a leaf

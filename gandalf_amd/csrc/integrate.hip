@@ -28,10 +28,11 @@ __global__ void k_zero_acc(DevicePtrs d)
 // time[0] = t, time[1] = timestep.  advance: t <- t + timestep first (SphSimulation.cpp:587)
 __global__ void k_advance_time(double *time) { time[0] = time[0] + time[1]; }
 
-__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration, int tdavisc, const int *blk)
+__global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int energy_integration, int tdavisc, int *blk)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= d.N) return;
+  int nact = 0;
+  if (i < d.N) {
   const double t = time[0];
   const double dt = t - d.f[D_TLAST][i];
   for (int k = 0; k < d.ndim; k++) {
@@ -62,6 +63,12 @@ __global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int 
     const int fl = (int) d.f[D_FLAGS][i];
     const bool active = blk[0] - (int) d.f[D_NLAST][i] == (int) d.f[D_NSTEP][i];
     d.f[D_FLAGS][i] = (double) (active ? (fl | 1) : (fl & ~1));
+    nact = active ? 1 : 0;
+  }
+  }
+  if (d.levels) {                                                         // running count of force evaluations (blk[8..9])
+    const unsigned long long m = __ballot(nact);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd((unsigned long long*) (blk + 8), (unsigned long long) __popcll(m));
   }
 }
 
@@ -335,7 +342,7 @@ __global__ void k_check_timesteps(DevicePtrs d, int *blk, int level_diff_max)
     d.f[D_FLAGS][i] = (double) fl;
   }
   const unsigned long long m = __ballot(woke);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&blk[B_ACTIVE], __popcll(m));
+  if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&blk[B_ACTIVE], __popcll(m)); atomicAdd((unsigned long long*) (blk + 8), (unsigned long long) __popcll(m)); }
 }
 
 static TimestepParams fill_tp(gh_ctx *ctx)

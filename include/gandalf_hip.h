@@ -144,6 +144,9 @@ int gh_build_tree(gh_ctx *ctx);
  * restarts: clock4 = {n, nresync, level_max, level_step}. */
 int gh_set_block_clock(gh_ctx *ctx, int n, int nresync, int level_max, int level_step, double dt_max);
 int gh_get_block_clock(gh_ctx *ctx, int32_t *clock4, double *dt_max);
+/* number of particle force evaluations (active particles summed over the steps, the N_active of SURVEY.md 8d's metric)
+ * since the last reset; block-timestep runs only */
+int gh_get_active_count(gh_ctx *ctx, int64_t *nactive, int reset);
 
 int gh_tree_size(gh_ctx *ctx, int32_t *Ncell, int32_t *ltot, int32_t *gtot);
 int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_first, int32_t *cell_N,
