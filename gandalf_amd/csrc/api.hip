@@ -664,7 +664,8 @@ extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
     if ((rc = forces_impl(ctx))) return rc;
   }
   // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
-  ctx->t = 0.0; ctx->timestep = 0.0; ctx->n = 0;
+  // the simulation time is 0 after gh_upload_particles, or what gh_set_time put there (runs started from a snapshot)
+  ctx->timestep = 0.0; ctx->n = 0;
   if ((rc = push_time(ctx))) return rc;
   if (ctx->cfg.Nlevels > 1) {
     if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");

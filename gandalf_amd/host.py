@@ -30,6 +30,14 @@ HOST_SYMBOLS = {
     "gah_time": (C.c_double, [_H]),
     "gah_timestep": (C.c_double, [_H]),
     "gah_ctx": (C.c_void_p, [_H]),
+    "gah_write_snapshot": (C.c_int, [_H, C.c_char_p, C.c_char_p]),
+    "gah_snapshot_error": (C.c_char_p, []),
+    "gah_snapshot_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, _PD, _PD, _PD, _PD, _PD, _PD,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_long), _PD]),
+    "gah_snapshot_open": (C.c_void_p, [C.c_char_p, C.c_char_p]),
+    "gah_snapshot_info": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _PD, C.POINTER(C.c_long), _PD]),
+    "gah_snapshot_data": (None, [C.c_void_p, _PD, _PD, _PD, _PD, _PD, _PD, C.POINTER(C.c_int32)]),
+    "gah_snapshot_close": (None, [C.c_void_p]),
 }
 
 
@@ -51,6 +59,54 @@ def load_host_library(path=HOST_LIB_PATH):
 
 class HostError(RuntimeError):
     pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(_PD)
+
+
+def write_snapshot(filename, fileform, snap):
+    """GANDALF snapshot file (fileform = column | su) from a dict with r, v [N][ndim], m, h, rho, u [N], t and, for su,
+    optionally iorig and the header words Noutsnap, Nsteps, Noutlitesnap, tsnaplast, mmean, tlitesnaplast, h_fac
+    (gandalf_amd/host/SnapshotIO.cpp; reference SimulationIO.hpp:444-540, 2009-2254)"""
+    lib = load_host_library()
+    c = lambda k: np.ascontiguousarray(snap[k], dtype=np.float64)  # noqa: E731
+    r = c("r")
+    N = len(c("m"))
+    r = r.reshape(N, -1)
+    v = c("v").reshape(N, -1)
+    io = np.ascontiguousarray(snap.get("iorig", np.arange(N)), dtype=np.int32)
+    hl = np.array([snap.get("Noutsnap", 0), snap.get("Nsteps", 0), snap.get("Noutlitesnap", 0)], dtype=np.int64)
+    hd = np.array([snap.get("tsnaplast", 0.0), snap.get("mmean", 0.0), snap.get("tlitesnaplast", 0.0), snap.get("h_fac", 1.2)])
+    rc = lib.gah_snapshot_write(filename.encode(), fileform.encode(), r.shape[1], N, float(snap["t"]), _dp(r), _dp(v), _dp(c("m")),
+                                _dp(c("h")), _dp(c("rho")), _dp(c("u")), io.ctypes.data_as(C.POINTER(C.c_int32)),
+                                hl.ctypes.data_as(C.POINTER(C.c_long)), _dp(hd))
+    if rc:
+        raise HostError(lib.gah_snapshot_error().decode())
+
+
+def read_snapshot(filename, fileform):
+    """inverse of write_snapshot: dict with ndim, N, t, r, v, m, h, rho, u, iorig and the su header words"""
+    lib = load_host_library()
+    h = lib.gah_snapshot_open(filename.encode(), fileform.encode())
+    if not h:
+        raise HostError(lib.gah_snapshot_error().decode())
+    try:
+        nd, N, t = C.c_int(), C.c_int(), C.c_double()
+        hl = np.zeros(3, dtype=np.int64)
+        hd = np.zeros(4)
+        lib.gah_snapshot_info(h, C.byref(nd), C.byref(N), C.byref(t), hl.ctypes.data_as(C.POINTER(C.c_long)), _dp(hd))
+        out = {"ndim": nd.value, "N": N.value, "t": t.value, "r": np.zeros((N.value, nd.value)), "v": np.zeros((N.value, nd.value)),
+               "iorig": np.zeros(N.value, dtype=np.int32)}
+        for k in ("m", "h", "rho", "u"):
+            out[k] = np.zeros(N.value)
+        lib.gah_snapshot_data(h, _dp(out["r"]), _dp(out["v"]), _dp(out["m"]), _dp(out["h"]), _dp(out["rho"]), _dp(out["u"]),
+                              out["iorig"].ctypes.data_as(C.POINTER(C.c_int32)))
+        out.update(Noutsnap=int(hl[0]), Nsteps=int(hl[1]), Noutlitesnap=int(hl[2]), tsnaplast=float(hd[0]), mmean=float(hd[1]),
+                   tlitesnaplast=float(hd[2]), h_fac=float(hd[3]))
+        return out
+    finally:
+        lib.gah_snapshot_close(h)
 
 
 class Simulation:
@@ -109,6 +165,10 @@ class Simulation:
 
     def setup(self):
         self._chk(self.lib.gah_setup(self.h))
+
+    def write_snapshot(self, filename, fileform="su"):
+        """SimulationBase::WriteSnapshotFile: the current device state as a column / su snapshot"""
+        self._chk(self.lib.gah_write_snapshot(self.h, filename.encode(), fileform.encode()))
 
     def main_loop(self, nsteps=1):
         self._chk(self.lib.gah_main_loop(self.h, nsteps))

@@ -27,6 +27,9 @@ void Parameters::SetDefaultValues()
   floatparams["courant_mult"] = 0.15;
   intparams["Nlevels"] = 1;
   intparams["level_diff_max"] = 1;
+  stringparams["in_file"] = "";
+  stringparams["in_file_form"] = "su";
+  stringparams["out_file_form"] = "su";
   intparams["sph_single_timestep"] = 0;
   stringparams["sph_integration"] = "lfkdk";
   stringparams["kernel"] = "m4";

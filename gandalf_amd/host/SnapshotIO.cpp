@@ -1,0 +1,159 @@
+// SnapshotIO.cpp -- see SnapshotIO.h
+#include "SnapshotIO.h"
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include "SphSimulation.h"
+
+static const char *kSerenTag = "SERENBINARYDUMPV3";
+static const int kStr = 20;                 // string_length, SimulationIO.hpp:44
+
+// ---- column -------------------------------------------------------------------------------------
+void WriteColumnSnapshotFile(const std::string &filename, const Snapshot &s)
+{
+  std::ofstream out(filename.c_str());
+  if (!out) throw GandalfError("Cannot open snapshot file for writing : " + filename);
+  const int nd = s.ndim;
+  out << s.N << std::endl << 0 << std::endl << nd << std::endl << s.t << std::endl;      // Nhydro, Nstar, ndim, t
+  const char *sep = "   ";
+  for (int i = 0; i < s.N; i++) {
+    for (int k = 0; k < nd; k++) out << s.r[(size_t) i*nd + k] << sep;
+    for (int k = 0; k < nd; k++) out << s.v[(size_t) i*nd + k] << sep;
+    out << s.m[i] << sep << s.h[i] << sep << s.rho[i] << sep << s.u[i];
+    if (nd == 1) out << sep;                 // the 1-D branch of the reference ends its line with a separator (:466)
+    out << std::endl;
+  }
+}
+
+void ReadColumnSnapshotFile(const std::string &filename, Snapshot &s)
+{
+  std::ifstream in(filename.c_str());
+  if (!in) throw GandalfError("Cannot open snapshot file : " + filename);
+  int Nstar = 0, nd = 0;
+  in >> s.N >> Nstar >> nd >> s.t;
+  if (nd < 1 || nd > 3) throw GandalfError("Incorrect no. of dimensions in file : " + filename);
+  s.ndim = nd;
+  s.r.assign((size_t) s.N*nd, 0.0); s.v.assign((size_t) s.N*nd, 0.0);
+  s.m.assign(s.N, 0.0); s.h.assign(s.N, 0.0); s.rho.assign(s.N, 0.0); s.u.assign(s.N, 0.0);
+  s.iorig.resize(s.N);
+  for (int i = 0; i < s.N && in.good(); i++) {
+    for (int k = 0; k < nd; k++) in >> s.r[(size_t) i*nd + k];
+    for (int k = 0; k < nd; k++) in >> s.v[(size_t) i*nd + k];
+    in >> s.m[i] >> s.h[i] >> s.rho[i] >> s.u[i];
+    s.iorig[i] = i;
+  }
+  if (!in) throw GandalfError("Truncated column snapshot : " + filename);
+}
+
+// ---- SEREN unformatted ------------------------------------------------------------------------------
+template <class T> static void put(std::ofstream &o, T v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+template <class T> static T get(std::ifstream &f) { T v; f.read(reinterpret_cast<char*>(&v), sizeof(T)); return v; }
+static void put_str(std::ofstream &o, const std::string &x)
+{
+  char buf[kStr];
+  std::memset(buf, ' ', kStr);
+  std::memcpy(buf, x.data(), x.size() < (size_t) kStr ? x.size() : (size_t) kStr);
+  o.write(buf, kStr);
+}
+static std::string get_str(std::ifstream &f)
+{
+  char buf[kStr];
+  f.read(buf, kStr);
+  std::string x(buf, kStr);
+  const size_t e = x.find_last_not_of(' ');
+  return e == std::string::npos ? std::string() : x.substr(0, e + 1);
+}
+
+void WriteSerenUnformSnapshotFile(const std::string &filename, const Snapshot &s)
+{
+  std::ofstream out(filename.c_str(), std::ios::binary);
+  if (!out) throw GandalfError("Cannot open snapshot file for writing : " + filename);
+  const int nd = s.ndim, N = s.N;
+  // data arrays: id, {width, 1, count, type code, unit id}   (SimulationIO.hpp:2078-2122)
+  struct Arr { const char *id; int t[5]; };
+  const Arr arrs[7] = {{"porig", {1, 1, N, 2, 0}}, {"r", {nd, 1, N, 4, 1}}, {"m", {1, 1, N, 4, 2}}, {"h", {1, 1, N, 4, 1}},
+                       {"v", {nd, 1, N, 4, 4}}, {"rho", {1, 1, N, 4, 6}}, {"u", {1, 1, N, 4, 20}}};
+  const int ndata = N > 0 ? 7 : 0;
+  int32_t idata[50] = {0}; int64_t ilpdata[50] = {0}; double rdata[50] = {0.0}, ddata[50] = {0.0};
+  idata[0] = N; idata[1] = 0;               // Nhydro (live), Nstar
+  idata[4] = N;                             // particles per type: icm, GAS, cdm, dust (:2151-2156)
+  idata[19] = 0; idata[20] = ndata;         // no unit strings when dimensionless
+  ilpdata[0] = s.Noutsnap; ilpdata[1] = s.Nsteps; ilpdata[10] = s.Noutlitesnap;
+  rdata[0] = s.h_fac;
+  ddata[0] = s.t; ddata[1] = s.tsnaplast; ddata[2] = s.mmean; ddata[10] = s.tlitesnaplast;
+  put_str(out, kSerenTag);
+  put<int32_t>(out, 8);                     // double precision build
+  for (int k = 0; k < 3; k++) put<int32_t>(out, nd);
+  for (int i = 0; i < 50; i++) put<int32_t>(out, idata[i]);
+  for (int i = 0; i < 50; i++) put<int64_t>(out, ilpdata[i]);
+  for (int i = 0; i < 50; i++) put<double>(out, rdata[i]);
+  for (int i = 0; i < 50; i++) put<double>(out, ddata[i]);
+  for (int a = 0; a < ndata; a++) put_str(out, arrs[a].id);
+  for (int a = 0; a < ndata; a++) for (int j = 0; j < 5; j++) put<int32_t>(out, arrs[a].t[j]);
+  if (N > 0) {
+    for (int i = 0; i < N; i++) put<int32_t>(out, s.iorig.empty() ? i : s.iorig[i]);
+    out.write(reinterpret_cast<const char*>(s.r.data()), sizeof(double)*(size_t) N*nd);
+    out.write(reinterpret_cast<const char*>(s.m.data()), sizeof(double)*(size_t) N);
+    out.write(reinterpret_cast<const char*>(s.h.data()), sizeof(double)*(size_t) N);
+    out.write(reinterpret_cast<const char*>(s.v.data()), sizeof(double)*(size_t) N*nd);
+    out.write(reinterpret_cast<const char*>(s.rho.data()), sizeof(double)*(size_t) N);
+    out.write(reinterpret_cast<const char*>(s.u.data()), sizeof(double)*(size_t) N);
+  }
+}
+
+void ReadSerenUnformSnapshotFile(const std::string &filename, Snapshot &s)
+{
+  std::ifstream in(filename.c_str(), std::ios::binary);
+  if (!in) throw GandalfError("Cannot open snapshot file : " + filename);
+  if (get_str(in) != kSerenTag) throw GandalfError("Incorrect format of IC file : " + filename);
+  const int prec = get<int32_t>(in);
+  if (prec != 8) throw GandalfError("Incorrect precision in snapshot (single-precision files are not read) : " + filename);
+  const int nd = get<int32_t>(in);
+  get<int32_t>(in); get<int32_t>(in);
+  if (nd < 1 || nd > 3) throw GandalfError("Incorrect no. of dimensions in file : " + filename);
+  int32_t idata[50]; int64_t ilpdata[50]; double rdata[50], ddata[50];
+  for (int i = 0; i < 50; i++) idata[i] = get<int32_t>(in);
+  for (int i = 0; i < 50; i++) ilpdata[i] = get<int64_t>(in);
+  for (int i = 0; i < 50; i++) rdata[i] = get<double>(in);
+  for (int i = 0; i < 50; i++) ddata[i] = get<double>(in);
+  const int N = idata[0], Nstar = idata[1], nunit = idata[19], ndata = idata[20];
+  if (Nstar != 0) throw GandalfError("snapshots with stars / sinks are not read on this path : " + filename);
+  for (int i = 0; i < nunit; i++) get_str(in);
+  std::vector<std::string> ids(ndata);
+  for (int a = 0; a < ndata; a++) ids[a] = get_str(in);
+  std::vector<int> typ((size_t) ndata*5);
+  for (int a = 0; a < ndata; a++) for (int j = 0; j < 5; j++) typ[(size_t) a*5 + j] = get<int32_t>(in);
+  s.ndim = nd; s.N = N; s.t = ddata[0]; s.tsnaplast = ddata[1]; s.mmean = ddata[2]; s.tlitesnaplast = ddata[10];
+  s.h_fac = rdata[0]; s.Noutsnap = ilpdata[0]; s.Nsteps = ilpdata[1]; s.Noutlitesnap = ilpdata[10];
+  s.r.assign((size_t) N*nd, 0.0); s.v.assign((size_t) N*nd, 0.0);
+  s.m.assign(N, 0.0); s.h.assign(N, 0.0); s.rho.assign(N, 0.0); s.u.assign(N, 0.0); s.iorig.assign(N, 0);
+  for (int a = 0; a < ndata; a++) {
+    const int width = typ[(size_t) a*5], count = typ[(size_t) a*5 + 2], code = typ[(size_t) a*5 + 3];
+    std::vector<double> *dst = nullptr;
+    if (ids[a] == "r") dst = &s.r; else if (ids[a] == "v") dst = &s.v; else if (ids[a] == "m") dst = &s.m;
+    else if (ids[a] == "h") dst = &s.h; else if (ids[a] == "rho") dst = &s.rho; else if (ids[a] == "u") dst = &s.u;
+    if (ids[a] == "porig" && count == N) in.read(reinterpret_cast<char*>(s.iorig.data()), sizeof(int32_t)*(size_t) N);
+    else if (dst && code == 4 && count == N) in.read(reinterpret_cast<char*>(dst->data()), sizeof(double)*(size_t) N*width);
+    else {                                   // an array this path does not use: skip it by its declared size
+      const size_t el = code == 2 ? 4 : (code == 4 ? 8 : (code == 3 ? 8 : 0));
+      if (!el) throw GandalfError("unknown array type in snapshot : " + ids[a]);
+      in.seekg((std::streamoff) (el*(size_t) width*count), std::ios::cur);
+    }
+  }
+  if (!in) throw GandalfError("Truncated snapshot : " + filename);
+}
+
+void WriteSnapshotFile(const std::string &filename, const std::string &fileform, const Snapshot &s)
+{
+  if (fileform == "column") WriteColumnSnapshotFile(filename, s);
+  else if (fileform == "su" || fileform == "seren_unform") WriteSerenUnformSnapshotFile(filename, s);
+  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su)");
+}
+
+void ReadSnapshotFile(const std::string &filename, const std::string &fileform, Snapshot &s)
+{
+  if (fileform == "column") ReadColumnSnapshotFile(filename, s);
+  else if (fileform == "su" || fileform == "seren_unform") ReadSerenUnformSnapshotFile(filename, s);
+  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su)");
+}

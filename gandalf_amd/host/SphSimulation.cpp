@@ -144,6 +144,19 @@ void SphSimulation::GenerateIC()
 {
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
+  if (ic == "file") {
+    // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su); the smoothing lengths are
+    // recomputed from scratch by the setup (initial_h_provided = false)
+    Snapshot snap;
+    ReadSnapshotFile(sp["in_file"], sp["in_file_form"], snap);
+    if (snap.ndim != ndim) throw GandalfError("Incorrect no. of dimensions in file");
+    sph->AllocateMemory(std::max(snap.N, 1));
+    HydroParticles &q = sph->part;
+    q.r = snap.r; q.v = snap.v; q.m = snap.m; q.h = snap.h; q.u = snap.u;
+    t = snap.t;
+    initial_h_provided = false;
+    return;
+  }
   const int N = ip["Nhydro"];
   if (N <= 0 && ic != "shocktube") throw GandalfError("Nhydro must be positive");
   sph->AllocateMemory(std::max(N, 1));
@@ -257,8 +270,11 @@ void SphSimulation::PostInitialConditionsSetup()
   if (!initial_h_provided) sph->InitialSmoothingLengthGuess();
   EnsureContext();
   check(ctx, gh_upload_particles(ctx, p.N, p.r.data(), p.v.data(), p.m.data(), p.h.data(), p.u.data()), "upload");
+  // a run that starts from a snapshot keeps the snapshot's time (ReadColumnSnapshotFile / ReadSerenUnformSnapshotFile set
+  // Simulation::t and nothing in the setup resets it); generated ICs start at t = 0
+  if (t != 0.0) check(ctx, gh_set_time(ctx, t, 0.0), "set_time");
   check(ctx, gh_setup(ctx, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
-  t = 0.0; Nsteps = 0;
+  Nsteps = 0;
   setup = true;
 }
 
@@ -281,6 +297,20 @@ void SphSimulation::Run(int Nadvance)
 {
   const int Ntarget = Nadvance < 0 ? Nstepsmax : Nsteps + Nadvance;
   while (t < tend && Nsteps < Ntarget) MainLoop(1);
+}
+
+// SimulationBase::WriteSnapshotFile (SimulationIO.hpp:96-125): current device state in the caller's particle order
+void SphSimulation::WriteSnapshotFile(const std::string &filename, const std::string &fileform)
+{
+  Snapshot s;
+  s.ndim = ndim; s.N = sph->part.N; s.t = t; s.Nsteps = Nsteps; s.h_fac = cfg.h_fac;
+  Download(GH_F_R, s.r); Download(GH_F_V, s.v); Download(GH_F_M, s.m); Download(GH_F_H, s.h);
+  Download(GH_F_RHO, s.rho); Download(GH_F_U, s.u);
+  s.iorig.resize(s.N);
+  for (int i = 0; i < s.N; i++) s.iorig[i] = i;
+  for (int i = 0; i < s.N; i++) s.mmean += s.m[i];                        // sph->mmean, SphSimulation.cpp:260-262
+  if (s.N > 0) s.mmean /= (double) s.N;
+  ::WriteSnapshotFile(filename, fileform, s);
 }
 
 void SphSimulation::Download(int field, std::vector<double> &out)

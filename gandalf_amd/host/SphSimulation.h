@@ -8,13 +8,14 @@
 //                                                                          (SphNeighbourSearch.h:76-94)
 //   SphLeapfrogKDK::AdvanceParticles / EndTimestep                          (SphLeapfrogKDK.cpp:76, 219)
 //   Nbody::CalculateDirectGravForces                                        (Nbody.cpp:233-287)
-// Only what the SPH + tree-gravity path needs is here; everything else GANDALF does (units, snapshots,
-// radiation, dust, MFV, sinks, MPI) is out of scope.
+// Only what the SPH + tree-gravity path needs is here (+ the column / su snapshot formats, SnapshotIO.h); everything
+// else GANDALF does (units, radiation, dust, MFV, sinks, MPI) is out of scope.
 #pragma once
 #include <string>
 #include <vector>
 #include "Parameters.h"
 #include "RandomNumber.h"
+#include "SnapshotIO.h"
 #include "../../include/gandalf_hip.h"
 
 class GandalfError : public std::exception {
@@ -67,6 +68,7 @@ class SphSimulation {
   void MainLoop(int nsteps = 1);           // SphSimulation.cpp:574
   void Run(int Nadvance = -1);             // Simulation.cpp:382
   void Download(int field, std::vector<double> &out);
+  void WriteSnapshotFile(const std::string &filename, const std::string &fileform);   // SimulationIO.hpp:96
 
   int ndim;
   Parameters *simparams;

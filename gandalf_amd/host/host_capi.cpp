@@ -70,5 +70,47 @@ int gah_main_loop(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->MainLoop(nsteps))
 double gah_time(gah_sim *s) { return s->sim->t; }
 double gah_timestep(gah_sim *s) { return s->sim->timestep; }
 gh_ctx *gah_ctx(gah_sim *s) { return s->sim ? s->sim->ctx : nullptr; }
+int gah_write_snapshot(gah_sim *s, const char *filename, const char *fileform) { GAH_TRY(s, s->sim->WriteSnapshotFile(filename, fileform)) }
+
+// ---- snapshot files without a simulation object (SnapshotIO.h); header = {Noutsnap, Nsteps, Noutlitesnap},
+//      hd = {tsnaplast, mmean, tlitesnaplast, h_fac}
+static std::string g_snap_err;
+const char *gah_snapshot_error(void) { return g_snap_err.c_str(); }
+int gah_snapshot_write(const char *filename, const char *fileform, int ndim, int N, double t, const double *r, const double *v,
+                       const double *m, const double *h, const double *rho, const double *u, const int *iorig,
+                       const long *hl, const double *hd)
+{
+  try {
+    Snapshot s;
+    s.ndim = ndim; s.N = N; s.t = t;
+    s.r.assign(r, r + (size_t) N*ndim); s.v.assign(v, v + (size_t) N*ndim);
+    s.m.assign(m, m + N); s.h.assign(h, h + N); s.rho.assign(rho, rho + N); s.u.assign(u, u + N);
+    if (iorig) s.iorig.assign(iorig, iorig + N);
+    if (hl) { s.Noutsnap = hl[0]; s.Nsteps = hl[1]; s.Noutlitesnap = hl[2]; }
+    if (hd) { s.tsnaplast = hd[0]; s.mmean = hd[1]; s.tlitesnaplast = hd[2]; s.h_fac = hd[3]; }
+    WriteSnapshotFile(filename, fileform, s);
+    return 0;
+  } catch (const std::exception &e) { g_snap_err = e.what(); return -1; }
+}
+Snapshot *gah_snapshot_open(const char *filename, const char *fileform)
+{
+  Snapshot *s = new Snapshot();
+  try { ReadSnapshotFile(filename, fileform, *s); return s; }
+  catch (const std::exception &e) { g_snap_err = e.what(); delete s; return nullptr; }
+}
+void gah_snapshot_info(Snapshot *s, int *ndim, int *N, double *t, long *hl, double *hd)
+{
+  *ndim = s->ndim; *N = s->N; *t = s->t;
+  if (hl) { hl[0] = s->Noutsnap; hl[1] = s->Nsteps; hl[2] = s->Noutlitesnap; }
+  if (hd) { hd[0] = s->tsnaplast; hd[1] = s->mmean; hd[2] = s->tlitesnaplast; hd[3] = s->h_fac; }
+}
+void gah_snapshot_data(Snapshot *s, double *r, double *v, double *m, double *h, double *rho, double *u, int *iorig)
+{
+  memcpy(r, s->r.data(), sizeof(double)*s->r.size()); memcpy(v, s->v.data(), sizeof(double)*s->v.size());
+  memcpy(m, s->m.data(), sizeof(double)*s->m.size()); memcpy(h, s->h.data(), sizeof(double)*s->h.size());
+  memcpy(rho, s->rho.data(), sizeof(double)*s->rho.size()); memcpy(u, s->u.data(), sizeof(double)*s->u.size());
+  memcpy(iorig, s->iorig.data(), sizeof(int)*s->iorig.size());
+}
+void gah_snapshot_close(Snapshot *s) { delete s; }
 
 }

@@ -14,6 +14,8 @@
 //       pass has an (input state, output state) pair.
 //   ref_dump steps  <params.dat> <out_prefix> <nsteps>
 //       SetupSimulation(), dump "setup"; nsteps x MainLoop(); dump "final".
+//   ref_dump snap   <params.dat> <out_prefix> [nsteps]
+//       SetupSimulation(), nsteps x MainLoop(), then the reference's column and SEREN-unformatted snapshot writers.
 //   ref_dump time   <params.dat> <nsteps> [warmup]
 //       SetupSimulation(); warmup x MainLoop(); time nsteps x MainLoop(); prints one JSON line
 //       (the CPU baseline of bench.py, kind "reference").
@@ -193,6 +195,17 @@ static int run(const string &mode, Parameters *params, SimulationBase *simbase, 
   const string prefix = argv[3];
   { Dump out(prefix + "_setup.gdmp"); dump_particles<ndim>(out, sim); dump_tree<ndim>(out, sim); dump_gather_lists<ndim>(out, sim); }
 
+  if (mode == "snap") {
+    // the reference's own snapshot writers on the post-setup state (SimulationIO.hpp:274-540, 2009-2254)
+    const int nsteps = argc > 4 ? atoi(argv[4]) : 0;
+    for (int s = 0; s < nsteps; s++) sim->MainLoop();
+    sim->WriteSnapshotFile(prefix + ".column", "column");
+    sim->WriteSnapshotFile(prefix + ".su", "su");
+    { Dump out(prefix + "_snap.gdmp"); dump_particles<ndim>(out, sim);
+      vector<double> v; v.push_back(sim->t); v.push_back(sim->tsnaplast); v.push_back(sph->mmean); v.push_back(sim->tlitesnaplast); v.push_back(sph->h_fac); out.d("snap_t_tsnaplast_mmean_tlitesnaplast_hfac", v);
+      vector<int> w; w.push_back(sim->Noutsnap); w.push_back(sim->Nsteps); w.push_back(sim->Noutlitesnap); out.i("snap_Noutsnap_Nsteps_Noutlitesnap", w); }
+    return 0;
+  }
   if (mode == "passes") {
     // MainLoop order (SphSimulation.cpp:634-709) at fixed positions, all particles active
     set_all_active<ndim>(sim);

@@ -101,6 +101,24 @@ def levels(name, nsteps=40):
         print(name, "levels ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def fromfile(name, nsteps=20):
+    """a run that starts from a snapshot file (ic = file): setup + nsteps, in_file resolved against the repo root"""
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        txt = open(par).read().replace("in_file = ", "in_file = " + ROOT + "/")
+        tpar = os.path.join(tmp, "p.dat")
+        open(tpar, "w").write(txt)
+        run(["steps", tpar, os.path.join(tmp, "s"), str(nsteps)], tmp)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in ["r", "v", "h", "rho", "u", "a", "t_timestep"]:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
+        print(name, "fromfile ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 NBODY_FIELDS = ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt", "t_dt"]
 
 
@@ -142,6 +160,8 @@ if __name__ == "__main__":
     for cfg in cases:
         if cfg == "adsod_mirror_full":
             long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
+        elif cfg.endswith("_fromfile"):
+            fromfile(cfg)
         elif cfg.endswith("_levels"):
             levels(cfg)
         elif cfg == "nbody":

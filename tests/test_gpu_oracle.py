@@ -135,3 +135,28 @@ def test_block_timesteps_from_ic(case):
         assert np.array_equal(dev.download(k).astype(np.int64), g["final_" + k]), k
     assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-9*np.abs(g["final_r"]).max()
     assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-8
+
+
+def test_run_from_reference_snapshot(tmp_path):
+    """ic = file: start from a SEREN-unformatted snapshot the REFERENCE wrote (tests/golden/snapshots/sod.su, t = 0.0015),
+    run the setup and 20 steps, compare with the reference's own run from the same file; then write the state back as a
+    snapshot and read it again"""
+    from gandalf_amd.host import Simulation, read_snapshot
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "adsod_1d_fromfile_steps.npz"))
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d_fromfile.dat"), in_file=os.path.join(here, "golden", "snapshots", "sod.su"))
+    sim.setup()
+    dev = sim.device()
+    assert abs(sim.t - g["setup_t_timestep"][0]) < 1e-15
+    assert np.max(np.abs(dev.download("h")/g["setup_h"] - 1)) < 1e-12
+    assert abs(sim.timestep - g["setup_t_timestep"][1]) < 1e-12*sim.timestep
+    sim.main_loop(int(g["nsteps"][0]))
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-12
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-11
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-10
+    assert np.max(np.abs(dev.download("u")/g["final_u"] - 1)) < 1e-10
+    out = str(tmp_path / "final.su")
+    sim.write_snapshot(out, "su")
+    f = read_snapshot(out, "su")
+    assert f["t"] == sim.t and f["Nsteps"] == int(g["nsteps"][0])
+    assert np.array_equal(f["rho"], dev.download("rho")) and np.array_equal(f["r"].ravel(), dev.download("r").ravel())
