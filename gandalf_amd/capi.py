@@ -133,7 +133,7 @@ _ENUMS = {
     "gas_eos": {"energy_eqn": 0, "isothermal": 1, "barotropic": 2},
     "avisc": {"none": 0, "mon97": 1},
     "acond": {"none": 0, "wadsley2008": 1, "price2008": 2},
-    "multipole": {"monopole": 0, "quadrupole": 1, "fast_monopole": 2},
+    "multipole": {"monopole": 0, "quadrupole": 1, "fast_monopole": 2, "fast_quadrupole": 3},
     "gravity_mac": {"geometric": 0, "gadget2": 1, "eigenmac": 2},
 }
 

@@ -14,6 +14,7 @@ struct ForceParams {
   const double *ktab;   // kernel tables (tabulated_kernel = 1) or nullptr
   double macerror;      // gravity_mac = gadget2
   int mac;              // GH_MAC_*
+  int fastquad;         // multipole = fast_quadrupole: the fast_monopole kernel also adds the cells' quadrupole terms
   int group0;
 };
 

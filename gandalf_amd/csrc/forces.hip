@@ -518,6 +518,7 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
     P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min;
   }
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
+  P.fastquad = ctx->cfg.multipole == GH_MULTIPOLE_FAST_QUADRUPOLE ? 1 : 0;
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
@@ -573,9 +574,9 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN || ctx->cfg.boundary_rhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
-  if ((ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE && ctx->cfg.multipole != GH_MULTIPOLE_QUADRUPOLE && ctx->cfg.multipole != GH_MULTIPOLE_FAST_MONOPOLE) ||
+  if ((ctx->cfg.multipole < GH_MULTIPOLE_MONOPOLE || ctx->cfg.multipole > GH_MULTIPOLE_FAST_QUADRUPOLE) ||
       (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.gravity_mac != GH_MAC_GADGET2 && ctx->cfg.gravity_mac != GH_MAC_EIGENMAC))
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "built: multipole=monopole|quadrupole|fast_monopole, gravity_mac=geometric|gadget2|eigenmac");
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "built: multipole=monopole|quadrupole|fast_monopole|fast_quadrupole, gravity_mac=geometric|gadget2|eigenmac");
   const bool quad = ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // list kernels only
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {

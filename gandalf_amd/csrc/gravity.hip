@@ -457,8 +457,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       const CellCom lc = d.ccom[node];
       double f_pot = 0.0, f_a[3] = {0.0, 0.0, 0.0}, f_q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       // same software pipeline as the monopole loop: ids two chunks ahead, records one chunk ahead
+      const bool fq = P.fastquad != 0;
       auto fm_term = [&](int id, const double4 &v) {
         #pragma clang fp contract(fast)
+        if (fq) {
+          // fast_quadrupole: FastMultipoleForces::AddQuadrupoleContribution (NeighbourSearch.h:601-720) on top of the
+          // monopole part below; note its dr = rc - cell.r and the softened r^2 (+1e-20), unlike the monopole part
+          const CellQuad cq = d.cquad[id < 0 ? 0 : id];
+          double e[3] = {0.0, 0.0, 0.0};
+          for (int k = 0; k < ND; k++) e[k] = lc.com[k] - (k == 0 ? v.x : (k == 1 ? v.y : v.z));
+          double e2 = e[0]*e[0];
+          if (ND > 1) e2 += e[1]*e[1];
+          if (ND > 2) e2 += e[2]*e[2];
+          e2 += GH_SMALL;
+          const double im = id < 0 ? 0.0 : fast_rsqrt(e2);
+          const double i2 = im*im, i5 = i2*i2*im;
+          const double Q0 = cq.q[0], Q1 = cq.q[1], Q2 = cq.q[2], Q3 = cq.q[3], Q4 = cq.q[4], Q5 = -(cq.q[0] + cq.q[2]);
+          double qs, qx[3] = {0.0, 0.0, 0.0};
+          if (ND == 3) {
+            qs = Q0*e[0]*e[0] + Q2*e[1]*e[1] + Q5*e[2]*e[2] + 2.0*(Q1*e[0]*e[1] + Q3*e[0]*e[2] + Q4*e[1]*e[2]);
+            qx[0] = (Q0*e[0] + Q1*e[1] + Q3*e[2])*i5; qx[1] = (Q1*e[0] + Q2*e[1] + Q4*e[2])*i5; qx[2] = (Q3*e[0] + Q4*e[1] + Q5*e[2])*i5;
+          }
+          else if (ND == 2) {
+            qs = Q0*e[0]*e[0] + Q2*e[1]*e[1] + 2.0*Q1*e[0]*e[1];
+            qx[0] = (Q0*e[0] + Q1*e[1])*i5; qx[1] = (Q1*e[0] + Q2*e[1])*i5;
+          }
+          else { qs = Q0*e[0]*e[0]; qx[0] = Q0*e[0]*i5; }
+          const double qf = 2.5*qs*i5*i2;
+          f_pot += 0.5*qs*i5;
+          for (int k = 0; k < ND; k++) f_a[k] += qx[k] - qf*e[k];
+          for (int k = 0; k < ND; k++) qx[k] *= 5.0*i2;
+          f_q[0] += qf*(7.0*e[0]*e[0]*i2 - 1) - (qx[0]*e[0] + qx[0]*e[0] - Q0*i5);
+          if (ND > 1) {
+            f_q[1] += qf*(7.0*e[0]*e[1]*i2) - (qx[0]*e[1] + qx[1]*e[0] - Q1*i5);
+            f_q[2] += qf*(7.0*e[1]*e[1]*i2 - 1) - (qx[1]*e[1] + qx[1]*e[1] - Q2*i5);
+          }
+          if (ND > 2) {
+            f_q[3] += qf*(7.0*e[0]*e[2]*i2) - (qx[0]*e[2] + qx[2]*e[0] - Q3*i5);
+            f_q[4] += qf*(7.0*e[1]*e[2]*i2) - (qx[1]*e[2] + qx[2]*e[1] - Q4*i5);
+            f_q[5] += qf*(7.0*e[2]*e[2]*i2 - 1) - (qx[2]*e[2] + qx[2]*e[2] - Q5*i5);
+          }
+        }
         double dr[3] = {0.0, 0.0, 0.0};
         for (int k = 0; k < ND; k++) dr[k] = (k == 0 ? v.x : (k == 1 ? v.y : v.z)) - lc.com[k];
         double drsqd = dr[0]*dr[0];
@@ -867,6 +906,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   P.avisc = ctx->cfg.avisc; P.acond = ctx->cfg.acond; P.ktab = ctx->ktab;
   if (ctx->cfg.avisc == GH_AVISC_MON97MM97) { P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min; }   // see sph_pair
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
+  P.fastquad = ctx->cfg.multipole == GH_MULTIPOLE_FAST_QUADRUPOLE ? 1 : 0;
   const int mpole = ctx->cfg.multipole;
   const bool lists_only = mpole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither
   int g0, g1;
@@ -896,7 +936,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
       if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
       else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
-#define LAUNCH(ND_, KT_) if (mpole == GH_MULTIPOLE_QUADRUPOLE) { LAUNCHM(ND_, KT_, 1) } else if (mpole == GH_MULTIPOLE_FAST_MONOPOLE) { LAUNCHM(ND_, KT_, 2) } else { LAUNCHM(ND_, KT_, 0) }
+#define LAUNCH(ND_, KT_) if (mpole == GH_MULTIPOLE_QUADRUPOLE) { LAUNCHM(ND_, KT_, 1) } else if (mpole == GH_MULTIPOLE_FAST_MONOPOLE || mpole == GH_MULTIPOLE_FAST_QUADRUPOLE) { LAUNCHM(ND_, KT_, 2) } else { LAUNCHM(ND_, KT_, 0) }
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCHM
 #undef LAUNCH

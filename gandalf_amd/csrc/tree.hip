@@ -663,7 +663,7 @@ int gh_alloc_tree(gh_ctx *ctx)
     GH_CHECK(ctx, re((void**) &ctx->leaf_amin, sizeof(double)*gtot));
     GH_CHECK(ctx, hipMemsetAsync(ctx->leaf_amin, 0, sizeof(double)*gtot, ctx->stream));
   }
-  if ((ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.gravity_mac == GH_MAC_EIGENMAC) && ctx->cfg.self_gravity) {
+  if ((ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.multipole == GH_MULTIPOLE_FAST_QUADRUPOLE || ctx->cfg.gravity_mac == GH_MAC_EIGENMAC) && ctx->cfg.self_gravity) {   // KDTree.cpp:823-824
     GH_CHECK(ctx, re((void**) &ctx->cquad, sizeof(CellQuad)*Ncell));
     GH_CHECK(ctx, hipMemsetAsync(ctx->cquad, 0, sizeof(CellQuad)*Ncell, ctx->stream));
   }

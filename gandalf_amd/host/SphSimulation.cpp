@@ -89,7 +89,7 @@ void SphSimulation::ProcessParameters()
   if (ip["Nlevels"] > 1 && ip["sph_single_timestep"] != 0) throw GandalfError("sph_single_timestep = 1 is not built");
   static const char *kern[] = {"m4", "quintic"}, *eos[] = {"energy_eqn", "isothermal", "barotropic"};
   static const char *av[] = {"none", "mon97"}, *ac[] = {"none", "wadsley2008", "price2008"};
-  static const char *mp[] = {"monopole", "quadrupole", "fast_monopole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic", "mirror"};
+  static const char *mp[] = {"monopole", "quadrupole", "fast_monopole", "fast_quadrupole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic", "mirror"};
   cfg.ndim = ndim;
   cfg.kernel = enum_of(sp["kernel"], kern, 2, "kernel");
   if (ip["tabulated_kernel"] != 0)                                       // TabulatedKernel<ndim>(kernel), Sph constructor
@@ -103,7 +103,7 @@ void SphSimulation::ProcessParameters()
   cfg.acond = enum_of(sp["acond"], ac, 3, "acond");
   cfg.self_gravity = ip["self_gravity"];
   cfg.hydro_forces = ip["hydro_forces"];
-  cfg.multipole = enum_of(sp["multipole"], mp, 3, "multipole");
+  cfg.multipole = enum_of(sp["multipole"], mp, 4, "multipole");
   cfg.gravity_mac = enum_of(sp["gravity_mac"], mac, 3, "gravity_mac");
   cfg.macerror = fp["macerror"];
   cfg.Nleafmax = ip["Nleafmax"];

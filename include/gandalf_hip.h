@@ -45,7 +45,8 @@ enum { GH_EOS_ENERGY_EQN = 0, GH_EOS_ISOTHERMAL = 1, GH_EOS_BAROTROPIC = 2 };
 enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1, GH_AVISC_MON97MM97 = 2 /* avisc = mon97 + time_dependent_avisc = mm97 */ };
 enum { GH_ACOND_NONE = 0, GH_ACOND_WADSLEY2008 = 1, GH_ACOND_PRICE2008 = 2 };
 /* multipole / gravity_mac (reference Tree.h MAC_Type; NeighbourSearch.h:350-475) */
-enum { GH_MULTIPOLE_MONOPOLE = 0, GH_MULTIPOLE_QUADRUPOLE = 1, GH_MULTIPOLE_FAST_MONOPOLE = 2 /* NeighbourSearch.h:481-794 */ };
+enum { GH_MULTIPOLE_MONOPOLE = 0, GH_MULTIPOLE_QUADRUPOLE = 1, GH_MULTIPOLE_FAST_MONOPOLE = 2 /* NeighbourSearch.h:481-794 */,
+       GH_MULTIPOLE_FAST_QUADRUPOLE = 3 /* NeighbourSearch.h:601-720, 796-827 */ };
 enum { GH_MAC_GEOMETRIC = 0, GH_MAC_GADGET2 = 1, GH_MAC_EIGENMAC = 2 };   /* Tree.h:413-432 open_cell_for_gravity */
 
 /* Parameter block: the hot-path subset of the reference's parameter file

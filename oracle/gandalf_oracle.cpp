@@ -287,7 +287,7 @@ struct KDTree {
   }
   void StockCellProperties(Cell &c, const std::vector<Part> &p) {   // KDTree.cpp:808-1083 (geometric MAC)
     const int nd = P->ndim;
-    const bool need_quad = P->multipole == 1 || P->gravity_mac == 2;
+    const bool need_quad = P->multipole == 1 || P->multipole == 3 || P->gravity_mac == 2;      // KDTree.cpp:823-824
     FLOAT dr[3];
     for (int k = 0; k < 5; k++) c.q[k] = 0.0;
     c.amin = big_number; c.macfactor = 0; c.mac = 0.0;
@@ -996,7 +996,7 @@ struct Oracle {
           }
         }
       }
-      if (GRAV && P.multipole == 2) {
+      if (GRAV && (P.multipole == 2 || P.multipole == 3)) {
         // ComputeFastMonopoleForces, NeighbourSearch.h:768-794: field, gradient and potential of all cells at the leaf's
         // COM (AddMonopoleContribution :561-583), first-order Taylor expansion to the particles (:737-745)
         FLOAT rc[3] = {0, 0, 0}, ac[3] = {0, 0, 0}, dphi[3] = {0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0}, pot = 0;
@@ -1015,6 +1015,44 @@ struct Oracle {
           q[0] += mc*(3.0*dr[0]*dr[0]*invdrsqd - 1);
           if (nd > 1) { q[1] += mc*(3.0*dr[0]*dr[1]*invdrsqd); q[2] += mc*(3.0*dr[1]*dr[1]*invdrsqd - 1); }
           if (nd > 2) { q[3] += mc*(3.0*dr[2]*dr[0]*invdrsqd); q[4] += mc*(3.0*dr[2]*dr[1]*invdrsqd); q[5] += mc*(3.0*dr[2]*dr[2]*invdrsqd - 1); }
+          if (P.multipole == 3) {
+            // fast_quadrupole: FastMultipoleForces::AddQuadrupoleContribution, NeighbourSearch.h:601-720 (dr = rc - cell.r)
+            const FLOAT *cq = gravcell[cc2].q;
+            FLOAT e[3] = {0, 0, 0};
+            for (int k = 0; k < nd; k++) e[k] = rc[k] - gravcell[cc2].r[k];
+            const FLOAT drsqd = Dot(e, e, nd) + small_number;
+            const FLOAT i2 = (FLOAT) 1.0/drsqd;
+            const FLOAT im = sqrt(i2);
+            const FLOAT i5 = i2*i2*im;
+            FLOAT qscalar, qx[3] = {0, 0, 0};
+            if (nd == 3) {
+              qscalar = cq[0]*e[0]*e[0] + cq[2]*e[1]*e[1] - (cq[0] + cq[2])*e[2]*e[2] + 2.0*(cq[1]*e[0]*e[1] + cq[3]*e[0]*e[2] + cq[4]*e[1]*e[2]);
+              qx[0] = (cq[0]*e[0] + cq[1]*e[1] + cq[3]*e[2])*i5;
+              qx[1] = (cq[1]*e[0] + cq[2]*e[1] + cq[4]*e[2])*i5;
+              qx[2] = (cq[3]*e[0] + cq[4]*e[1] - (cq[0] + cq[2])*e[2])*i5;
+            }
+            else if (nd == 2) {
+              qscalar = cq[0]*e[0]*e[0] + cq[2]*e[1]*e[1] + 2.0*cq[1]*e[0]*e[1];
+              qx[0] = (cq[0]*e[0] + cq[1]*e[1])*i5;
+              qx[1] = (cq[1]*e[0] + cq[2]*e[1])*i5;
+            }
+            else { qscalar = cq[0]*e[0]*e[0]; qx[0] = (cq[0]*e[0])*i5; }
+            const FLOAT qfactor = 2.5*qscalar*i5*i2;
+            pot += 0.5*qscalar*i5;
+            for (int k = 0; k < nd; k++) ac[k] += qx[k] - qfactor*e[k];
+            for (int k = 0; k < nd; k++) dphi[k] += qx[k] - qfactor*e[k];
+            for (int k = 0; k < nd; k++) qx[k] *= 5*i2;
+            q[0] += qfactor*(7*e[0]*e[0]*i2 - 1);
+            if (nd > 1) { q[1] += qfactor*(7*e[0]*e[1]*i2); q[2] += qfactor*(7*e[1]*e[1]*i2 - 1); }
+            if (nd > 2) { q[3] += qfactor*(7*e[0]*e[2]*i2); q[4] += qfactor*(7*e[1]*e[2]*i2); q[5] += qfactor*(7*e[2]*e[2]*i2 - 1); }
+            q[0] -= qx[0]*e[0] + qx[0]*e[0] - cq[0]*i5;
+            if (nd > 1) { q[1] -= qx[0]*e[1] + qx[1]*e[0] - cq[1]*i5; q[2] -= qx[1]*e[1] + qx[1]*e[1] - cq[2]*i5; }
+            if (nd > 2) {
+              q[3] -= qx[0]*e[2] + qx[2]*e[0] - cq[3]*i5;
+              q[4] -= qx[1]*e[2] + qx[2]*e[1] - cq[4]*i5;
+              q[5] -= qx[2]*e[2] + qx[2]*e[2] + (cq[0] + cq[2])*i5;
+            }
+          }
         }
         for (int j = 0; j < Nactive; j++) {
           Part &pi = activepart[j];

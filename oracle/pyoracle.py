@@ -75,8 +75,8 @@ class Oracle:
         assert p.get("kernel", "m4") in ("m4", "quintic")
         # bit 0: quintic, bit 1: tabulated_kernel
         q.kernel = (1 if p.get("kernel", "m4") == "quintic" else 0) | (2 if int(p.get("tabulated_kernel", 0)) else 0)
-        assert p.get("multipole", "quadrupole") in ("monopole", "quadrupole", "fast_monopole") or not q.self_gravity
-        q.multipole = {"monopole": 0, "quadrupole": 1, "fast_monopole": 2}.get(p.get("multipole", "quadrupole"), 0)
+        assert p.get("multipole", "quadrupole") in ("monopole", "quadrupole", "fast_monopole", "fast_quadrupole") or not q.self_gravity
+        q.multipole = {"monopole": 0, "quadrupole": 1, "fast_monopole": 2, "fast_quadrupole": 3}.get(p.get("multipole", "quadrupole"), 0)
         assert p.get("avisc", "mon97") == "mon97"
         q.acond = {"none": 0, "wadsley2008": 1, "price2008": 2}[p.get("acond", "none")]
         q.gravity_mac = {"geometric": 0, "gadget2": 1, "eigenmac": 2}[p.get("gravity_mac", "geometric")]
