@@ -510,7 +510,12 @@ struct KDTree {
 };
 
 // ---------------------------------------------------------------------------------------------
+// star particle as the gas force routines see it (hybrid gas + N-body runs; NbodyParticle.h)
+struct GasStar { FLOAT r[3], a[3], m, h, gpot; };
+
 struct Oracle {
+  std::vector<GasStar> stars;
+  int star_softening = 1;                         // nbody_softening
   Params P; M4 kern; FLOAT invndim;
   int mac_now;                          // MAC in force (geometric during the setup bootstrap, SphSimulation.cpp:381-388)
   std::vector<Part> p;          // [0,Nhydro) real, then periodic ghosts
@@ -616,6 +621,17 @@ struct Oracle {
     pi.div_v = 0.0;
     pi.invomega = 1.0 - h_rho_deriv(pi.h, pi.rho)*pi.invomega;
     pi.invomega = 1.0/pi.invomega;
+    // Hubber et al. (2013) SPH-star conservative-gravity term in zeta (conservative_sph_star_gravity = 1, the default),
+    // GradhSph.cpp:288-307: mean-h softening for kernel-softened stars, h/2 otherwise
+    if (!stars.empty()) {
+      FLOAT invhsqd_s = (FLOAT) 4.0*invh*invh;
+      for (size_t j = 0; j < stars.size(); j++) {
+        if (star_softening == 1) invhsqd_s = pow((FLOAT) 2.0/(pi.h + stars[j].h), 2);
+        for (int k = 0; k < nd; k++) dr[k] = stars[j].r[k] - pi.r[k];
+        ssqd = Dot(dr, dr, nd)*invhsqd_s;
+        pi.zeta += stars[j].m*invhsqd_s*kern.wzeta_s2(ssqd);
+      }
+    }
     pi.zeta = h_rho_deriv(pi.h, pi.rho)*pi.zeta*pi.invomega;
     // energy_eqn EOS: AdiabaticEOS.cpp:69-82, EOS.h:156
     pi.sound = sqrt(P.gamma*(P.gamma - 1.0)*pi.u);
@@ -1073,6 +1089,21 @@ struct Oracle {
         }
       }
       if (GRAV) for (int j = 0; j < Nactive; j++) activepart[j].gpot_hydro = activepart[j].gpot;   // GradhSphTree.cpp:595-598
+      // gas <- stars: GradhSph::ComputeStarGravForces, GradhSph.cpp:699-743 (mean-h kernel softening), GradhSphTree.cpp:600-607
+      if (GRAV && !stars.empty()) for (int j = 0; j < Nactive; j++) {
+        Part &pi = activepart[j];
+        for (size_t s = 0; s < stars.size(); s++) {
+          FLOAT dr[3];
+          for (int k = 0; k < nd; k++) dr[k] = stars[s].r[k] - pi.r[k];
+          const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+          const FLOAT drmag = sqrt(drsqd);
+          const FLOAT invdrmag = (FLOAT) 1.0/drmag;
+          const FLOAT invhmean = (FLOAT) 2.0/(pi.h + stars[s].h);
+          const FLOAT paux = stars[s].m*invhmean*invhmean*kern.wgrav(drmag*invhmean)*invdrmag;
+          for (int k = 0; k < nd; k++) pi.atree[k] += paux*dr[k];
+          pi.gpot += stars[s].m*invhmean*kern.wpot(drmag*invhmean);
+        }
+      }
       for (int j = 0; j < Nactive; j++) {                             // GradhSphTree.cpp:396-404 / 610-619
         const int i = activelist[j];
         for (int k = 0; k < nd; k++) p[i].a[k] += activepart[j].a[k];
@@ -1099,6 +1130,100 @@ struct Oracle {
     }
   }
   void Forces() { if (P.self_gravity) UpdateForces<true>(); else UpdateForces<false>(); }
+
+  // ---- stars <- gas: HydroTree::UpdateAllStarGasForces (HydroTree.cpp:552-657), Tree::ComputeStarGravityInteractionList
+  //      (Tree.cpp:748-885; always the geometric opening criterion), NbodyLeapfrogKDK::CalculateDirectHydroForces
+  //      (NbodyLeapfrogKDK.cpp:151-239), ComputeCellMonopoleForces / ComputeCellQuadrupoleForces (NeighbourSearch.h:350-475)
+  void UpdateAllStarGasForces() {
+    const int nd = P.ndim;
+    for (size_t si = 0; si < stars.size(); si++) {
+      GasStar &st = stars[si];
+      std::vector<int> neiblist, directlist, cells;
+      const FLOAT hrangemax = kern.kernrange*st.h;
+      int cc = 0;
+      while (cc < tree.Ncell) {
+        const Cell &o = tree.cell[cc];
+        FLOAT dr[3];
+        for (int k = 0; k < nd; k++) dr[k] = o.rcell[k] - st.r[k];
+        const FLOAT drsqd = Dot(dr, dr, nd);
+        if (drsqd < pow((FLOAT) 0.5*hrangemax + o.rmax + (FLOAT) 0.5*kern.kernrange*o.hmax, 2)) {
+          if (o.copen != -1) cc = o.copen;
+          else {
+            int i = o.ifirst;
+            while (i != -1) { neiblist.push_back(i); if (i == o.ilast) break; i = tree.inext[i]; }
+            cc = o.cnext;
+          }
+        }
+        else if (drsqd > o.cdistsqd && o.N > 0) {
+          if (o.copen == -1 && o.N == 1) directlist.push_back(o.ifirst);
+          else cells.push_back(cc);
+          cc = o.cnext;
+        }
+        else if (drsqd <= o.cdistsqd && o.N > 0) {
+          if (o.copen != -1) cc = o.copen;
+          else {
+            int i = o.ifirst;
+            while (i != -1) { directlist.push_back(i); if (i == o.ilast) break; i = tree.inext[i]; }
+            cc = o.cnext;
+          }
+        }
+        else cc = o.cnext;
+      }
+      for (size_t jj = 0; jj < neiblist.size(); jj++) {
+        const Part &g = p[neiblist[jj]];
+        FLOAT dr[3];
+        for (int k = 0; k < nd; k++) dr[k] = g.r[k] - st.r[k];
+        const FLOAT drsqd = Dot(dr, dr, nd);
+        const FLOAT drmag = sqrt(drsqd);
+        const FLOAT invdrmag = 1.0/drmag;
+        const FLOAT invhmean = 2.0/(st.h + g.h);
+        const FLOAT paux = g.m*invhmean*invhmean*kern.wgrav(drmag*invhmean)*invdrmag;
+        for (int k = 0; k < nd; k++) st.a[k] += paux*dr[k];
+        st.gpot += g.m*invhmean*kern.wpot(drmag*invhmean);
+      }
+      for (size_t jj = 0; jj < directlist.size(); jj++) {
+        const Part &g = p[directlist[jj]];
+        FLOAT dr[3];
+        for (int k = 0; k < nd; k++) dr[k] = g.r[k] - st.r[k];
+        const FLOAT drsqd = Dot(dr, dr, nd);
+        const FLOAT drmag = sqrt(drsqd);
+        const FLOAT invdrmag = 1.0/drmag;
+        const FLOAT paux = g.m*pow(invdrmag, 3);
+        for (int k = 0; k < nd; k++) st.a[k] += paux*dr[k];
+        st.gpot += g.m*invdrmag;
+      }
+      const bool quad = P.multipole == 1 || P.multipole == 3;
+      for (size_t jj = 0; jj < cells.size(); jj++) {
+        const Cell &cl = tree.cell[cells[jj]];
+        if (!quad) {                                                   // NeighbourSearch.h:350-377
+          FLOAT dr[3];
+          for (int k = 0; k < nd; k++) dr[k] = cl.r[k] - st.r[k];
+          const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+          const FLOAT invdrsqd = 1.0/drsqd;
+          const FLOAT invdrmag = sqrt(invdrsqd);
+          const FLOAT invdr3 = invdrsqd*invdrmag;
+          st.gpot += cl.m*invdrmag;
+          for (int k = 0; k < nd; k++) st.a[k] += cl.m*dr[k]*invdr3;
+        }
+        else {                                                         // NeighbourSearch.h:384-475 (3-D)
+          FLOAT dr[3] = {0.0, 0.0, 0.0};
+          for (int k = 0; k < nd; k++) dr[k] = st.r[k] - cl.r[k];
+          const FLOAT drsqd = Dot(dr, dr, nd) + small_number;
+          const FLOAT invdrsqd = (FLOAT) 1.0/drsqd;
+          const FLOAT invdrmag = sqrt(invdrsqd);
+          const FLOAT invdr5 = invdrsqd*invdrsqd*invdrmag;
+          for (int k = 0; k < nd; k++) st.a[k] -= cl.m*dr[k]*invdrsqd*invdrmag;
+          const FLOAT qscalar = cl.q[0]*dr[0]*dr[0] + cl.q[2]*dr[1]*dr[1] - (cl.q[0] + cl.q[2])*dr[2]*dr[2] +
+                                2.0*(cl.q[1]*dr[0]*dr[1] + cl.q[3]*dr[0]*dr[2] + cl.q[4]*dr[1]*dr[2]);
+          const FLOAT qfactor = 2.5*qscalar*invdr5*invdrsqd;
+          st.a[0] += (cl.q[0]*dr[0] + cl.q[1]*dr[1] + cl.q[3]*dr[2])*invdr5 - qfactor*dr[0];
+          st.a[1] += (cl.q[1]*dr[0] + cl.q[2]*dr[1] + cl.q[4]*dr[2])*invdr5 - qfactor*dr[1];
+          st.a[2] += (cl.q[3]*dr[0] + cl.q[4]*dr[1] - (cl.q[0] + cl.q[2])*dr[2])*invdr5 - qfactor*dr[2];
+          st.gpot += cl.m*invdrmag + 0.5*qscalar*invdr5;
+        }
+      }
+    }
+  }
 
   // ---- time integration: SphLeapfrogKDK.cpp:76-127, Integration.cpp (CheckBoundaries), SphIntegration.cpp:81-134,
   //      Simulation.cpp:1669-1754, SphLeapfrogKDK.cpp:219-272
@@ -1525,6 +1650,27 @@ int orc_set(Oracle *o, const char *name, const double *in)
   return 0;
 }
 void orc_set_time(Oracle *o, double t, double timestep) { o->t = t; o->timestep = timestep; }
+// hybrid runs: the stars the gas sees (positions, masses, smoothing lengths); accelerations / potential start at zero
+void orc_set_stars(Oracle *o, int N, const double *r, const double *m, const double *h, int nbody_softening)
+{
+  o->star_softening = nbody_softening;
+  o->stars.assign(N, GasStar());
+  for (int i = 0; i < N; i++) {
+    GasStar &s = o->stars[i];
+    for (int k = 0; k < 3; k++) { s.r[k] = k < o->P.ndim ? r[i*o->P.ndim + k] : 0.0; s.a[k] = 0.0; }
+    s.m = m[i]; s.h = h[i]; s.gpot = 0.0;
+  }
+}
+// stars <- gas (the tree must have been built); out_a [N][ndim], out_gpot [N]
+void orc_star_gas_forces(Oracle *o, double *out_a, double *out_gpot)
+{
+  for (size_t i = 0; i < o->stars.size(); i++) { for (int k = 0; k < 3; k++) o->stars[i].a[k] = 0.0; o->stars[i].gpot = 0.0; }
+  o->UpdateAllStarGasForces();
+  for (size_t i = 0; i < o->stars.size(); i++) {
+    for (int k = 0; k < o->P.ndim; k++) out_a[i*o->P.ndim + k] = o->stars[i].a[k];
+    out_gpot[i] = o->stars[i].gpot;
+  }
+}
 static int *ifield_ptr(Part &q, const char *name)
 {
 #define I(nm) if (!strcmp(name, #nm)) return &q.nm;

@@ -139,6 +139,19 @@ class Oracle:
         dt_max = self.L.orc_get_block(self.h, v.ctypes.data_as(C.c_void_p))
         return [int(x) for x in v], float(dt_max)
 
+    def set_stars(self, r, m, h, nbody_softening=1):
+        """stars of a hybrid gas + N-body run (their gravity acts on the gas in forces())"""
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1, self.ndim)
+        self.Nstar = r.shape[0]
+        m = np.ascontiguousarray(m, dtype=np.float64); h = np.ascontiguousarray(h, dtype=np.float64)
+        self.L.orc_set_stars(self.h, self.Nstar, self._dp(r), self._dp(m), self._dp(h), int(nbody_softening))
+
+    def star_gas_forces(self):
+        """stars <- gas through the gas tree (UpdateAllStarGasForces): (a [Nstar][ndim], gpot [Nstar])"""
+        a = np.zeros((self.Nstar, self.ndim)); g = np.zeros(self.Nstar)
+        self.L.orc_star_gas_forces(self.h, self._dp(a), self._dp(g))
+        return a, g
+
     def set_time(self, t, dt):
         self.L.orc_set_time(self.h, C.c_double(t), C.c_double(dt))
 

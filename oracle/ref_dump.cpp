@@ -106,6 +106,16 @@ static void dump_particles(Dump &out, Simulation<ndim> *sim)
   PSCAL(dt) PSCAL(dt_next) PSCAL(tlast) PSCAL(div_v) PSCAL(alpha) PSCAL(dalphadt)
   PSCAL(invomega) PSCAL(zeta)
   { vector<double> v; v.push_back(sim->t); v.push_back(sim->timestep); out.d("t_timestep", v); }
+  // star particles of a hybrid gas + N-body run (NbodyParticle.h)
+  if (sim->nbody && sim->nbody->Nstar > 0) {
+    const int Ns = sim->nbody->Nstar;
+    StarParticle<ndim> *st = sim->nbody->stardata;
+    { vector<int> v(1, Ns); out.i("Nstar", v); }
+#define SVEC(field) { vector<double> v((size_t)Ns*ndim); for (int i=0;i<Ns;i++) for (int k=0;k<ndim;k++) v[(size_t)i*ndim+k]=st[i].field[k]; out.d("star_" #field, v, ndim); }
+#define SSCAL(field) { vector<double> v(Ns); for (int i=0;i<Ns;i++) v[i]=st[i].field; out.d("star_" #field, v); }
+    SVEC(r) SVEC(v) SVEC(a) SVEC(adot) SVEC(r0) SVEC(v0) SVEC(a0) SVEC(adot0)
+    SSCAL(m) SSCAL(h) SSCAL(gpot) SSCAL(dt) SSCAL(tlast)
+  }
   { vector<int> v; v.push_back(sim->n); v.push_back(sim->Nsteps); v.push_back(sim->nresync); out.i("n_Nsteps_nresync", v); }
   { vector<int> v; v.push_back(sim->level_max); v.push_back(sim->level_step); v.push_back(sim->Nlevels); v.push_back(sim->level_diff_max); out.i("levelmax_levelstep_Nlevels_diffmax", v); }
   { vector<double> v; v.push_back(sim->dt_max); out.d("dt_max", v); }
@@ -219,6 +229,20 @@ static int run(const string &mode, Parameters *params, SimulationBase *simbase, 
     if (sph->self_gravity == 1) sim->sphneib->UpdateAllSphForces(sph, sim->nbody, sim->simbox, sim->ewald);
     else sim->sphneib->UpdateAllSphHydroForces(sph, sim->nbody, sim->simbox);
     { Dump out(prefix + "_forces.gdmp"); dump_particles<ndim>(out, sim); }
+    if (sim->nbody->Nstar > 0) {
+      // the star part of MainLoop (SphSimulation.cpp:771-812) at fixed positions: gas -> star tree forces, then star-star
+      Nbody<ndim> *nb = sim->nbody;
+      for (int i = 0; i < nb->Nnbody; i++) {
+        nb->nbodydata[i]->flags.set(active);
+        for (int k = 0; k < ndim; k++) { nb->nbodydata[i]->a[k] = 0.0; nb->nbodydata[i]->adot[k] = 0.0; nb->nbodydata[i]->a2dot[k] = 0.0; nb->nbodydata[i]->a3dot[k] = 0.0; }
+        nb->nbodydata[i]->gpot = 0.0; nb->nbodydata[i]->gpe = 0.0;
+      }
+      sim->sphneib->UpdateAllStarGasForces(sph, nb, sim->simbox, sim->ewald);
+      { Dump out(prefix + "_stargas.gdmp"); dump_particles<ndim>(out, sim); }
+      if (nb->nbody_softening == 1) nb->CalculateDirectSmoothedGravForces(nb->Nnbody, nb->nbodydata, sim->simbox, sim->ewald);
+      else nb->CalculateDirectGravForces(nb->Nnbody, nb->nbodydata, sim->simbox, sim->ewald);
+      { Dump out(prefix + "_starall.gdmp"); dump_particles<ndim>(out, sim); }
+    }
   }
   else if (mode == "steps") {
     const int nsteps = atoi(argv[4]);

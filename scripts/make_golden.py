@@ -66,6 +66,15 @@ def passes(name, nsteps=None):
         out["dens_gather_ids"] = dens["gather_ids"]
         for k in FORCE_OUT:
             out["force_" + k] = forc[k]
+        if "Nstar" in setup:                 # hybrid gas + stars: star state, stars <- gas tree forces, + star-star direct sum
+            sg = read_gdmp(os.path.join(tmp, "p_stargas.gdmp"))
+            sa = read_gdmp(os.path.join(tmp, "p_starall.gdmp"))
+            for k in ["r", "v", "m", "h"]:
+                out["star_" + k] = setup["star_" + k]
+            for k in ["a", "gpot"]:
+                out["stargas_" + k] = sg["star_" + k]
+                out["starall_" + k] = sa["star_" + k]
+            out["starall_adot"] = sa["star_adot"]
         np.savez_compressed(os.path.join(GOLD, name + "_passes.npz"), **out)
         print(name, "passes ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
     with tempfile.TemporaryDirectory() as tmp:
@@ -77,6 +86,10 @@ def passes(name, nsteps=None):
             out["setup_" + k] = setup[k]
             out["final_" + k] = final[k]
         out["setup_m"] = setup["m"]
+        if "Nstar" in setup:
+            for k in ["r", "v", "a", "adot", "r0", "v0", "a0", "adot0", "m", "h", "gpot", "dt", "tlast"]:
+                out["setup_star_" + k] = setup["star_" + k]
+                out["final_star_" + k] = final["star_" + k]
         np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
         print(name, "steps ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 

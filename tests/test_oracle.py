@@ -148,3 +148,20 @@ def test_block_timesteps_bitwise(case):
         assert np.array_equal(o.get_int(k), g["final_" + k]), k
     for k in ["r", "v", "a", "h", "rho", "u", "dudt", "dt", "tlast", "r0", "v0", "a0", "pressure", "sound"]:
         assert np.array_equal(o.get(k), g["final_" + k]), k
+
+
+def test_star_gas_forces_bitwise():
+    """hybrid gas + stars (64 stars in the 4k Plummer sphere): gas <- stars inside the force pass
+    (GradhSph::ComputeStarGravForces) and stars <- gas through the gas tree (HydroTree::UpdateAllStarGasForces)"""
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_passes")
+    o = make(case, g)
+    o.set_stars(g["star_r"], g["star_m"], g["star_h"])
+    o.build_tree()
+    o.density()
+    o.zero_accelerations()
+    o.forces()
+    for k in ["a", "atree", "gpot", "gpot_hydro", "dudt"]:
+        assert np.array_equal(o.get(k), g["force_" + k]), k
+    a, gp = o.star_gas_forces()
+    assert np.array_equal(a, g["stargas_a"]) and np.array_equal(gp, g["stargas_gpot"])
