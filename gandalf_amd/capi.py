@@ -75,6 +75,8 @@ SYMBOLS = {
     "gh_setup": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_set_time": (C.c_int, [_CTX, C.c_double, C.c_double]),
     "gh_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
+    "gh_set_stars": (C.c_int, [_CTX, C.c_int64, _PD, _PD, _PD, C.c_int]),
+    "gh_star_gas_forces": (C.c_int, [_CTX, _PD, _PD]),
     "gh_set_block_clock": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "gh_get_block_clock": (C.c_int, [_CTX, _PI, _PD]),
     "gh_get_active_count": (C.c_int, [_CTX, _PL, C.c_int]),
@@ -325,6 +327,19 @@ class GandalfHip:
     def set_block_clock(self, n, nresync, level_max, level_step, dt_max):
         """integer clock of a block-timestep run (Simulation: n, nresync, level_max, level_step) and dt_max"""
         self._chk(self.lib.gh_set_block_clock(self.ctx, n, nresync, level_max, level_step, dt_max))
+
+    def set_stars(self, r, m, h, nbody_softening=1):
+        """stars of a hybrid gas + N-body run (their gravity acts on the gas; see gh_set_stars)"""
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1, self.ndim)
+        m = np.ascontiguousarray(m, dtype=np.float64); h = np.ascontiguousarray(h, dtype=np.float64)
+        self.nstars = r.shape[0]
+        self._chk(self.lib.gh_set_stars(self.ctx, self.nstars, _dp(r), _dp(m), _dp(h), int(nbody_softening)))
+
+    def star_gas_forces(self):
+        """gravity of the gas on every star through the gas tree: (a [nstars][ndim], gpot [nstars])"""
+        a = np.zeros((self.nstars, self.ndim)); g = np.zeros(self.nstars)
+        self._chk(self.lib.gh_star_gas_forces(self.ctx, _dp(a), _dp(g)))
+        return a, g
 
     def active_count(self, reset=False):
         """particle force evaluations since the last reset (block-timestep runs)"""

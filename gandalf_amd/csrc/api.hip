@@ -256,7 +256,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -469,6 +469,7 @@ static int density_and_hmax(gh_ctx *ctx, bool count)
 {
   int rc = gh_density_impl(ctx, count);
   if (rc) return rc;
+  gh_zeta_stars_impl(ctx);                              // hybrid runs: star term of zeta (GradhSph.cpp:288-307)
   if (ctx->nranks > 1) return GH_OK;                    // h of the other slices arrives with the exchange
   return gh_update_hmax_impl(ctx);                      // tree->UpdateAllHmaxValues, GradhSphTree.cpp:268
 }
@@ -510,6 +511,7 @@ extern "C" int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats)
   ctx->dom_ms[GH_T_SPH_FORCES] = 0; ctx->dom_calls[GH_T_SPH_FORCES] = 0;
   int rc = gh_all_forces_impl(ctx, stats != nullptr);
   if (rc) return rc;
+  gh_gas_star_forces_impl(ctx);                         // hybrid runs: gas <- stars (GradhSphTree.cpp:600-607)
   rc = gh_sync_collect(ctx, "gh_update_all_forces");
   if (rc) return rc;
   if (stats) return read_stats(ctx, stats, GH_T_SPH_FORCES);
@@ -518,7 +520,7 @@ extern "C" int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats)
 
 static int forces_impl(gh_ctx *ctx)
 {
-  if (ctx->cfg.self_gravity) return gh_all_forces_impl(ctx, false);
+  if (ctx->cfg.self_gravity) { const int rc = gh_all_forces_impl(ctx, false); if (rc) return rc; return gh_gas_star_forces_impl(ctx); }
   if (ctx->cfg.hydro_forces) return gh_hydro_forces_impl(ctx, false);
   return gh_fail(ctx, GH_ERR_INVALID, "Error: No forces included in simulation");   // SphSimulation.cpp:474
 }

@@ -145,6 +145,10 @@ struct gh_ctx {
   double dt_max = 0.0;
   int *d_blk = nullptr;            // device {n, nresync, level_max, level_step, level_max_new, activecount, nfactor_mul, nfactor_div}
 
+  // stars of a hybrid gas + N-body run as the gas sees them (stars.hip)
+  double4 *star_posm = nullptr; double *star_h = nullptr, *star_out = nullptr;
+  int nstars = 0, star_softening = 1; int64_t star_cap = 0;
+
   // multi-GPU work shard
   int rank = 0, nranks = 1;
 };
@@ -206,6 +210,9 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int n, double t, double timestep);
 int gh_kdk_end_impl(gh_ctx *ctx, int n, double t, double timestep);
 int gh_timestep_impl(gh_ctx *ctx);          // leaves min dt in ctx->redbuf[0] and writes dt_next
 int gh_pack_posm(gh_ctx *ctx);
+// hybrid runs (stars.hip): star term of zeta after a density pass, gas <- stars after a gravity pass
+int gh_zeta_stars_impl(gh_ctx *ctx);
+int gh_gas_star_forces_impl(gh_ctx *ctx);
 // block timesteps (integrate.hip)
 int gh_thermal_all_impl(gh_ctx *ctx);
 int gh_block_timesteps_impl(gh_ctx *ctx);

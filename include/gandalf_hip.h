@@ -138,6 +138,18 @@ int gh_build_tree(gh_ctx *ctx);
 /* tree export for parity tests, in the reference's pre-order cell numbering (KDTree.cpp:362-433).
  * Any pointer may be NULL.  Ncell = 2*gtot-1.  cell_first/cell_N index the `order` array:
  * order[cell_first[c] .. +cell_N[c]) are the caller-order ids of the particles of cell c. */
+/* Hybrid gas + star runs: the stars as the gas sees them (positions [nstars][ndim], masses, smoothing lengths;
+ * nbody_softening as in the parameter file).  While nstars > 0
+ *   - gh_update_density adds the star term of zeta (GradhSph::ComputeH, GradhSph.cpp:288-307, conservative_sph_star_gravity = 1),
+ *   - gh_update_all_forces adds the stars' kernel-softened gravity to the gas (GradhSph::ComputeStarGravForces,
+ *     GradhSph.cpp:699-743),
+ *   - gh_star_gas_forces returns the gas' gravity on every star through the gas tree (HydroTree::UpdateAllStarGasForces,
+ *     HydroTree.cpp:552-657; Tree::ComputeStarGravityInteractionList, Tree.cpp:748-885;
+ *     NbodyLeapfrogKDK::CalculateDirectHydroForces, NbodyLeapfrogKDK.cpp:151-239): a [nstars][ndim], gpot [nstars],
+ *     to be added to the star-star sums of gh_nbody_forces. */
+int gh_set_stars(gh_ctx *ctx, int64_t nstars, const double *r, const double *m, const double *h, int nbody_softening);
+int gh_star_gas_forces(gh_ctx *ctx, double *a, double *gpot);
+
 /* Hierarchical block timesteps (Nlevels > 1).  Replaces Simulation::ComputeBlockTimesteps (Simulation.cpp:1764-2200),
  * SphLeapfrogKDK::CheckTimesteps (SphLeapfrogKDK.cpp:284-330) and the active-particle bookkeeping of
  * SphSimulation::MainLoop (SphSimulation.cpp:574-880); gh_setup / gh_step run them when cfg.Nlevels > 1.  The integer

@@ -220,3 +220,27 @@ def test_block_timesteps_match_reference(case):
     assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
     assert relerr(sim.download("u"), g["final_u"]) < 1e-10
     assert relerr(sim.download("tlast"), g["final_tlast"], floor=1e-300) < 1e-12
+
+
+def test_star_gas_forces_match_reference():
+    """hybrid gas + stars (64 stars in the 4k Plummer sphere, nbody_softening = 1): star term of zeta in the density pass,
+    gas <- stars in the force pass, stars <- gas through the gas tree - against the compiled reference"""
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_passes")
+    sim, p = make(case)
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.set_stars(g["star_r"], g["star_m"], g["star_h"], nbody_softening=int(p.get("nbody_softening", 0)))
+    sim.build_tree()
+    sim.update_density()
+    for name in ["h", "rho", "invomega"]:
+        assert relerr(sim.download(name), g["dens_" + name]) < 1e-12, name
+    assert relerr(sim.download("zeta"), g["dens_zeta"], floor=np.abs(g["dens_zeta"]).mean()) < 1e-12
+    sim.zero_accelerations()
+    sim.update_all_forces()
+    assert vec_err(sim.download("a"), g["force_a"]) < 1e-11
+    assert vec_err(sim.download("atree"), g["force_atree"]) < 1e-11
+    assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
+    assert relerr(sim.download("gpot_hydro"), g["force_gpot_hydro"]) < 1e-11
+    a, gp = sim.star_gas_forces()
+    assert vec_err(a, g["stargas_a"]) < 1e-11
+    assert relerr(gp, g["stargas_gpot"]) < 1e-11
