@@ -103,6 +103,8 @@ SYMBOLS = {
     "gh_nbody_forces": (C.c_int, [_CTX]),
     "gh_nbody_setup": (C.c_int, [_CTX, _PD]),
     "gh_nbody_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
+    "gh_nbody_upload_field": (C.c_int, [_CTX, C.c_int, _PD]),
+    "gh_hybrid_step": (C.c_int, [_CTX, _CTX, C.c_int, _PD, _PD]),
 }
 
 _lib = None
@@ -429,7 +431,7 @@ class GandalfHip:
 
 class NbodyHip:
     """Stars: direct-sum forces + leapfrog KDK on the GPU (gh_nbody_* of include/gandalf_hip.h)."""
-    FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4}
+    FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4, "r0": 5, "v0": 6, "a0": 7, "tlast": 8}
 
     def __init__(self, ndim=3, softening=0, nbody_mult=0.1, device=0):
         self.lib = load_library()
@@ -466,6 +468,19 @@ class NbodyHip:
         out = np.empty(self.N if name == "gpot" else (self.N, self.ndim))
         self._chk(self.lib.gh_nbody_download(self.ctx, self.FIELDS[name], _dp(out)))
         return out
+
+    def upload_field(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._chk(self.lib.gh_nbody_upload_field(self.ctx, self.FIELDS[name], _dp(arr)))
+
+    def hybrid_step(self, gas, nsteps=1):
+        """nsteps MainLoop calls of a hybrid gas + stars run; `gas` is the GandalfHip context holding the gas"""
+        t, dt = C.c_double(), C.c_double()
+        rc = self.lib.gh_hybrid_step(gas.ctx, self.ctx, int(nsteps), C.byref(t), C.byref(dt))
+        if rc:
+            msg = gas.lib.gh_last_error(gas.ctx).decode() or self.lib.gh_nbody_last_error(self.ctx).decode()
+            raise GhError(rc, msg)
+        return t.value, dt.value
 
     def forces(self):
         self._chk(self.lib.gh_nbody_forces(self.ctx))

@@ -641,6 +641,16 @@ static int build_tree_timed(gh_ctx *ctx)
   return rc;
 }
 
+// the gas passes of one MainLoop call, enqueued only (used by gh_hybrid_step, nbody.hip)
+int gh_hybrid_gas_passes(gh_ctx *ctx)
+{
+  int rc;
+  if ((rc = build_tree_timed(ctx))) return rc;
+  if ((rc = density_and_hmax(ctx, false))) return rc;
+  gh_zero_acc_impl(ctx);
+  return forces_impl(ctx);
+}
+
 extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
 {
   if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;

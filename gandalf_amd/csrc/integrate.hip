@@ -182,14 +182,18 @@ int gh_advance_time_impl(gh_ctx *ctx)
   return GH_OK;
 }
 
-int gh_timestep_impl(gh_ctx *ctx)
+int gh_timestep_impl_extra(gh_ctx *ctx, int nextra);
+int gh_timestep_impl(gh_ctx *ctx) { return gh_timestep_impl_extra(ctx, 0); }
+
+// nextra further candidates for the minimum sit behind the block minima in ctx->redbuf (the stars of a hybrid run)
+int gh_timestep_impl_extra(gh_ctx *ctx, int nextra)
 {
   TimestepParams tp;
   tp.courant_mult = ctx->cfg.courant_mult; tp.accel_mult = ctx->cfg.accel_mult; tp.energy_mult = ctx->cfg.energy_mult;
   tp.energy_integration = ctx->cfg.energy_integration; tp.hydro_forces = ctx->cfg.hydro_forces;
   const int nblk = 256;
   hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev(ctx), tp, ctx->redbuf);
-  hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, ctx->stream, ctx->redbuf, nblk, gh_time_dev(ctx));
+  hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, ctx->stream, ctx->redbuf, nblk + nextra, gh_time_dev(ctx));
   hipLaunchKernelGGL(k_set_dt_next, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), gh_time_dev(ctx));
   return GH_OK;
 }

@@ -236,8 +236,9 @@ extern "C" int gh_nbody_upload(gh_nbody *nb, int64_t N, const double *r, const d
   const int nd = nb->ndim;
   if (N > nb->Ncap) {
     nb_free(nb);
-    double **vec[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->stage};
+    double **vec[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0};
     for (double **q : vec) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*3*N));
+    NB_CHECK(nb, hipMalloc((void**) &nb->stage, sizeof(double)*4*N));          // 3N transposition buffer / hybrid: gas a + gpot
     double **sca[] = {&nb->m, &nb->h, &nb->gpot, &nb->tlast};
     for (double **q : sca) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*N));
     NB_CHECK(nb, hipMalloc((void**) &nb->red, sizeof(double)*((N + 255)/256 + 1)));
@@ -266,12 +267,14 @@ extern "C" int gh_nbody_upload(gh_nbody *nb, int64_t N, const double *r, const d
 
 extern "C" int gh_nbody_download(gh_nbody *nb, int field, double *out)
 {
-  if (!nb || !out || nb->N <= 0 || field < 0 || field >= GH_NB_FIELDS) return GH_ERR_INVALID;
+  if (!nb || !out || nb->N <= 0 || field < 0 || field >= GH_NB_ALLFIELDS) return GH_ERR_INVALID;
   const int64_t N = nb->N;
   const int nd = nb->ndim;
   NB_CHECK(nb, hipStreamSynchronize(nb->stream));
   if (field == GH_NB_GPOT) { NB_CHECK(nb, hipMemcpy(out, nb->gpot, sizeof(double)*N, hipMemcpyDeviceToHost)); return GH_OK; }
-  const double *src = field == GH_NB_R ? nb->r : field == GH_NB_V ? nb->v : field == GH_NB_A ? nb->a : nb->adot;
+  if (field == GH_NB_TLAST) { NB_CHECK(nb, hipMemcpy(out, nb->tlast, sizeof(double)*N, hipMemcpyDeviceToHost)); return GH_OK; }
+  const double *src = field == GH_NB_R ? nb->r : field == GH_NB_V ? nb->v : field == GH_NB_A ? nb->a : field == GH_NB_R0 ? nb->r0 :
+                      field == GH_NB_V0 ? nb->v0 : field == GH_NB_A0 ? nb->a0 : nb->adot;
   std::vector<double> t((size_t) 3*N);
   NB_CHECK(nb, hipMemcpy(t.data(), src, sizeof(double)*3*N, hipMemcpyDeviceToHost));
   for (int64_t i = 0; i < N; i++) for (int k = 0; k < nd; k++) out[(size_t) i*nd + k] = t[(size_t) k*N + i];
@@ -343,5 +346,92 @@ extern "C" int gh_nbody_step(gh_nbody *nb, int nsteps, double *t, double *timest
   NB_CHECK(nb, hipStreamSynchronize(nb->stream));
   if (t) *t = td[0];
   if (timestep) *timestep = td[1];
+  return GH_OK;
+}
+
+extern "C" int gh_nbody_upload_field(gh_nbody *nb, int field, const double *src)
+{
+  if (!nb || !src || nb->N <= 0 || field < 0 || field >= GH_NB_ALLFIELDS) return GH_ERR_INVALID;
+  const int64_t N = nb->N;
+  const int nd = nb->ndim;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  if (field == GH_NB_GPOT) { NB_CHECK(nb, hipMemcpy(nb->gpot, src, sizeof(double)*N, hipMemcpyHostToDevice)); return GH_OK; }
+  if (field == GH_NB_TLAST) { NB_CHECK(nb, hipMemcpy(nb->tlast, src, sizeof(double)*N, hipMemcpyHostToDevice)); return GH_OK; }
+  double *dst = field == GH_NB_R ? nb->r : field == GH_NB_V ? nb->v : field == GH_NB_A ? nb->a : field == GH_NB_R0 ? nb->r0 :
+                field == GH_NB_V0 ? nb->v0 : field == GH_NB_A0 ? nb->a0 : nb->adot;
+  std::vector<double> t((size_t) 3*N, 0.0);
+  for (int64_t i = 0; i < N; i++) for (int k = 0; k < nd; k++) t[(size_t) k*N + i] = src[(size_t) i*nd + k];
+  NB_CHECK(nb, hipMemcpy(dst, t.data(), sizeof(double)*3*N, hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hybrid gas + stars stepping (SphSimulation::MainLoop with Nstar > 0, global timestep, Npec = 1)
+// ------------------------------------------------------------------------------------------------
+#include "gh_internal.hpp"
+int gh_advance_time_impl(gh_ctx *ctx);
+double *gh_time_dev(gh_ctx *ctx);
+int gh_hybrid_gas_passes(gh_ctx *ctx);                       // api.hip: tree, density, zero, forces (enqueue only)
+int gh_timestep_impl_extra(gh_ctx *ctx, int nextra);         // integrate.hip: global min incl. nextra values behind the block minima
+
+// a += gas part, gpot += gas part (component-major star arrays; ga is [N][ndim] as gh_star_gas_forces returns it)
+__global__ void k_nbody_add_gas(NbPtrs p, const double *ga, const double *gg)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= p.N) return;
+  for (int k = 0; k < p.ndim; k++) p.a[(size_t) k*p.N + i] += ga[(size_t) i*p.ndim + k];
+  p.gpot[i] += gg[i];
+}
+
+extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_out, double *timestep_out)
+{
+  if (!gas || !nb || nb->N <= 0 || gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
+  if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
+  if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
+  const int64_t Ns = nb->N;
+  const int nd = nb->ndim;
+  NbPtrs p = nb_ptrs(nb);
+  const int nblk = (int) ((Ns + 255)/256);
+  std::vector<double> sr((size_t) Ns*nd), sm((size_t) Ns), shh((size_t) Ns), ga((size_t) Ns*nd), gg((size_t) Ns);
+  NB_CHECK(nb, hipMemcpy(sm.data(), nb->m, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  NB_CHECK(nb, hipMemcpy(shh.data(), nb->h, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  int rc;
+  for (int s = 0; s < nsteps; s++) {
+    // the stars follow the gas clock
+    double td[2] = {gas->t, gas->timestep};
+    NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+    gas->n++; gas->Nsteps++;
+    gh_advance_time_impl(gas);                                               // t = t + timestep
+    gh_kdk_advance_impl(gas, gas->n, 0.0, 0.0);                              // hydroint->AdvanceParticles
+    hipLaunchKernelGGL(k_nbody_advance, dim3(nblk), dim3(256), 0, nb->stream, p, 0);   // nbody->AdvanceParticles
+    hipLaunchKernelGGL(k_nbody_clock, dim3(1), dim3(1), 0, nb->stream, p);
+    if ((rc = gh_nbody_download(nb, GH_NB_R, sr.data()))) return rc;
+    if ((rc = gh_set_stars(gas, Ns, sr.data(), sm.data(), shh.data(), nb->softening))) return rc;
+    if ((rc = gh_hybrid_gas_passes(gas))) return rc;                         // tree, density (+ zeta), forces (+ gas <- stars)
+    if ((rc = gh_star_gas_forces(gas, ga.data(), gg.data()))) return rc;    // UpdateAllStarGasForces
+    if ((rc = nb_launch_forces(nb))) return rc;                              // star-star direct sum
+    NB_CHECK(nb, hipMemcpyAsync(nb->stage, ga.data(), sizeof(double)*Ns*nd, hipMemcpyHostToDevice, nb->stream));
+    NB_CHECK(nb, hipMemcpyAsync(nb->stage + (size_t) Ns*nd, gg.data(), sizeof(double)*Ns, hipMemcpyHostToDevice, nb->stream));
+    hipLaunchKernelGGL(k_nbody_add_gas, dim3(nblk), dim3(256), 0, nb->stream, p, nb->stage, nb->stage + (size_t) Ns*nd);
+    // CorrectionTerms, the stars' timestep minimum and EndTimestep
+    hipLaunchKernelGGL(k_nbody_correct_dt, dim3(nblk), dim3(256), 0, nb->stream, p, nb->nbody_mult, nb->red, 1);
+    hipLaunchKernelGGL(k_nbody_end, dim3(std::min(nblk, 256)), dim3(256), 0, nb->stream, p, nb->red, nblk);
+    double star_min = 0.0;
+    NB_CHECK(nb, hipMemcpyAsync(&star_min, nb->tdt + 2, sizeof(double), hipMemcpyDeviceToHost, nb->stream));
+    NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+    // ComputeGlobalTimestep over both species, then the gas' EndTimestep
+    GH_CHECK(gas, hipMemcpyAsync(gas->redbuf + 256, &star_min, sizeof(double), hipMemcpyHostToDevice, gas->stream));
+    gh_timestep_impl_extra(gas, 1);
+    gh_kdk_end_impl(gas, 0, 0.0, 0.0);
+    gas->n = 0;
+    if ((rc = gh_sync_collect(gas, "gh_hybrid_step"))) return rc;
+    double tt[2];
+    GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+    gas->t = tt[0]; gas->timestep = tt[1];
+  }
+  double td[2] = {gas->t, gas->timestep};
+  NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  if (t_out) *t_out = gas->t;
+  if (timestep_out) *timestep_out = gas->timestep;
   return GH_OK;
 }

@@ -264,7 +264,9 @@ void *gh_field_dev(gh_ctx *ctx, int field, int k);
  * NbodySimulation::MainLoop (src/Nbody/NbodySimulation.cpp:311-404).  Global timestep (Nlevels = 1),
  * open boundaries, no sub-systems / perturbers.  Stars stay in caller order (no tree). */
 typedef struct gh_nbody gh_nbody;
-enum { GH_NB_R = 0, GH_NB_V, GH_NB_A, GH_NB_ADOT, GH_NB_GPOT, GH_NB_FIELDS };
+enum { GH_NB_R = 0, GH_NB_V, GH_NB_A, GH_NB_ADOT, GH_NB_GPOT, GH_NB_FIELDS,
+       /* start-of-step copies and the time of the last step end (upload_field / download only) */
+       GH_NB_R0 = GH_NB_FIELDS, GH_NB_V0, GH_NB_A0, GH_NB_TLAST, GH_NB_ALLFIELDS };
 /* softening: 0 = Newtonian point masses, 1 = M4-kernel softened with mean h (nbody_softening) */
 int gh_nbody_create(int ndim, int softening, double nbody_mult, int device, gh_nbody **out);
 void gh_nbody_destroy(gh_nbody *nb);
@@ -279,6 +281,14 @@ int gh_nbody_forces(gh_nbody *nb);
 int gh_nbody_setup(gh_nbody *nb, double *timestep);
 /* nsteps x MainLoop.  Returns t and the next timestep. */
 int gh_nbody_step(gh_nbody *nb, int nsteps, double *t, double *timestep);
+/* state of a restart / of a hybrid run: overwrite one field ([N][ndim], or [N] for GH_NB_GPOT / GH_NB_TLAST) */
+int gh_nbody_upload_field(gh_nbody *nb, int field, const double *src);
+/* Hybrid gas + stars: nsteps of SphSimulation::MainLoop with a global timestep (SphSimulation.cpp:574-880, Npec = 1) -
+ * both species advance, the gas passes see the stars (gh_set_stars is refreshed from the star context every step), the stars
+ * get the gas' tree forces (gh_star_gas_forces) on top of their direct sum, the timestep is the minimum over both
+ * (Simulation::ComputeGlobalTimestep, Simulation.cpp:1669-1754).  gas must hold the post-setup state (gh_set_time). */
+int gh_hybrid_step(gh_ctx *gas, gh_nbody *stars, int nsteps, double *t, double *timestep);
+
 
 #ifdef __cplusplus
 }

@@ -1758,6 +1758,51 @@ void orc_nbody_step(NbodyOracle *o, int n) { for (int i = 0; i < n; i++) o->Step
 double orc_nbody_time(NbodyOracle *o) { return o->t; }
 double orc_nbody_timestep(NbodyOracle *o) { return o->timestep; }
 // field: 0 r, 1 v, 2 a, 3 adot, 4 gpot, 5 r0, 6 v0, 7 a0
+// post-setup state of the stars of a hybrid run: fields 0 r, 1 v, 2 a, 3 adot, 5 r0, 6 v0, 7 a0, 8 adot0 ([N][3]);
+// 4 gpot, 9 dt, 10 tlast ([N]).  nstep = 1, nlast = 0 (global timestep)
+void orc_nbody_set(NbodyOracle *o, int field, const double *in)
+{
+  for (int i = 0; i < o->N; i++) {
+    Star &q = o->s[i];
+    FLOAT *dst = field == 0 ? q.r : field == 1 ? q.v : field == 2 ? q.a : field == 3 ? q.adot : field == 5 ? q.r0 :
+                 field == 6 ? q.v0 : field == 7 ? q.a0 : field == 8 ? q.adot0 : NULL;
+    if (field == 4) q.gpot = in[i]; else if (field == 9) q.dt = in[i]; else if (field == 10) q.tlast = in[i];
+    else for (int k = 0; k < 3; k++) dst[k] = in[3*i + k];
+    q.nstep = 1; q.nlast = 0;
+  }
+}
+
+// One SphSimulation::MainLoop call of a hybrid gas + stars run with a global timestep (SphSimulation.cpp:574-880, Npec = 1):
+// both species advance, the gas passes see the stars (zeta term, ComputeStarGravForces), the stars get the gas' tree
+// forces and their own direct sum, the timestep is the minimum over both (Simulation.cpp:1669-1754)
+static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
+{
+  g.n++; g.Nsteps++; g.t = g.t + g.timestep;
+  nb.t = g.t; nb.timestep = g.timestep;
+  g.AdvanceParticles();
+  nb.Advance(g.n);
+  g.stars.resize(nb.N);
+  g.star_softening = nb.softening;
+  for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].r[k] = nb.s[i].r[k]; g.stars[i].m = nb.s[i].m; g.stars[i].h = nb.s[i].h; }
+  g.BuildTree(); g.DensityPass();
+  g.ZeroAccelerations(); g.Forces();
+  nb.Zero();                                                         // :773-784
+  for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].a[k] = 0.0; g.stars[i].gpot = 0.0; }
+  g.UpdateAllStarGasForces();                                        // :787
+  for (int i = 0; i < nb.N; i++) if (nb.s[i].active) { for (int k = 0; k < 3; k++) nb.s[i].a[k] = g.stars[i].a[k]; nb.s[i].gpot = g.stars[i].gpot; }
+  nb.Forces();                                                       // :794-799 (adds the star-star sums)
+  nb.Correct(g.n);                                                   // :811
+  g.ComputeGlobalTimestep();                                         // minimum over gas and stars
+  nb.GlobalTimestep();
+  const double ts = std::min(g.timestep, (double) nb.timestep);
+  g.timestep = ts; nb.timestep = ts;
+  for (int i = 0; i < g.Nhydro; i++) g.p[i].dt_next = ts;
+  for (int i = 0; i < nb.N; i++) nb.s[i].dt_next = ts;
+  g.EndTimestep();
+  nb.EndTimestep(0);
+}
+void orc_hybrid_step(Oracle *g, NbodyOracle *nb, int nsteps) { for (int s = 0; s < nsteps; s++) HybridMainLoop(*g, *nb); }
+
 void orc_nbody_get(NbodyOracle *o, int field, double *out)
 {
   for (int i = 0; i < o->N; i++) {

@@ -44,6 +44,10 @@ def lib():
         L.orc_nbody_time.argtypes = [C.c_void_p]
         L.orc_nbody_timestep.argtypes = [C.c_void_p]
         L.orc_nbody_get.argtypes = [C.c_void_p, C.c_int, _PD]
+        L.orc_nbody_set.argtypes = [C.c_void_p, C.c_int, _PD]
+        L.orc_hybrid_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_set_stars.argtypes = [C.c_void_p, C.c_int, _PD, _PD, _PD, C.c_int]
+        L.orc_star_gas_forces.argtypes = [C.c_void_p, _PD, _PD]
         _lib = L
     return _lib
 
@@ -256,6 +260,16 @@ class NbodyOracle:
 
     def timestep(self):
         return self.L.orc_nbody_timestep(self.o)
+
+    SET_FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4, "r0": 5, "v0": 6, "a0": 7, "adot0": 8, "dt": 9, "tlast": 10}
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self.L.orc_nbody_set(self.o, self.SET_FIELDS[name], arr.ctypes.data_as(_PD))
+
+    def hybrid_step(self, gas, n=1):
+        """n MainLoop calls of a hybrid run: `gas` is the Oracle holding the gas, self the stars"""
+        self.L.orc_hybrid_step(gas.h, self.o, int(n))
 
     def get(self, name):
         out = np.empty(self.N if name == "gpot" else (self.N, 3))

@@ -244,3 +244,32 @@ def test_star_gas_forces_match_reference():
     a, gp = sim.star_gas_forces()
     assert vec_err(a, g["stargas_a"]) < 1e-11
     assert relerr(gp, g["stargas_gpot"]) < 1e-11
+
+
+def test_hybrid_steps_match_reference():
+    """three MainLoop calls of the hybrid gas + stars run (gas context + star context, gh_hybrid_step) from the
+    reference's post-setup state"""
+    from gandalf_amd.capi import NbodyHip
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_steps")
+    sim, p = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    sim.upload(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
+        sim.upload_field(k, s(k))
+    t0, dt0 = s("t_timestep")
+    sim.set_time(float(t0), float(dt0))
+    nb = NbodyHip(ndim=3, softening=int(p["nbody_softening"]), nbody_mult=float(p["nbody_mult"]))
+    nb.upload(s("star_r"), s("star_v"), s("star_m"), s("star_h"))
+    for k in ["a", "r0", "v0", "a0", "tlast"]:
+        nb.upload_field(k, s("star_" + k))
+    t, dt = nb.hybrid_step(sim, int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert abs(t - tf) <= 1e-12*abs(tf) and abs(dt - dtf) <= 1e-9*abs(dtf)
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-11*np.abs(g["final_r"]).max()
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
+    assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
+    assert np.max(np.abs(nb.download("r") - g["final_star_r"])) < 1e-11*np.abs(g["final_star_r"]).max()
+    assert np.max(np.abs(nb.download("v") - g["final_star_v"])) < 1e-10*np.abs(g["final_star_v"]).max()
+    assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-10
+    assert relerr(nb.download("gpot"), g["final_star_gpot"]) < 1e-10

@@ -165,3 +165,27 @@ def test_star_gas_forces_bitwise():
         assert np.array_equal(o.get(k), g["force_" + k]), k
     a, gp = o.star_gas_forces()
     assert np.array_equal(a, g["stargas_a"]) and np.array_equal(gp, g["stargas_gpot"])
+
+
+def test_hybrid_steps_bitwise():
+    """three MainLoop calls of the hybrid gas + stars run from the reference's post-setup state: gas and stars bit for bit"""
+    from oracle.pyoracle import NbodyOracle
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_steps")
+    p = read_params_file("%s/%s.dat" % (PARAMS, case))
+    o = Oracle(p, nthreads=4)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    o.set_particles(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
+    for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt"]:
+        o.set(k, s(k))
+    nb = NbodyOracle(s("star_r"), s("star_v"), s("star_m"), s("star_h"), int(p["nbody_softening"]), float(p["nbody_mult"]))
+    for k in ["a", "adot", "r0", "v0", "a0", "adot0", "gpot", "dt", "tlast"]:
+        nb.set(k, s("star_" + k))
+    t0, dt0 = s("t_timestep")
+    o.set_time(float(t0), float(dt0))
+    nb.hybrid_step(o, int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ["r", "v", "a", "h", "rho", "u"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
+    for k in ["r", "v", "a", "adot", "gpot", "r0", "v0", "a0"]:
+        assert np.array_equal(nb.get(k), g["final_star_" + k]), "star " + k
