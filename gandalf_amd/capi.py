@@ -155,8 +155,10 @@ def config_from_params(p, device=0):
     tdav = p.get("time_dependent_avisc", "none")
     if tdav == "mm97" and c.avisc == 1:
         c.avisc = 2                       # GH_AVISC_MON97MM97
+    elif tdav == "cd2010" and c.avisc == 1:
+        c.avisc = 3                       # GH_AVISC_MON97CD2010
     elif tdav != "none":
-        raise ValueError("time_dependent_avisc = %s is not built (none | mm97 with avisc = mon97)" % tdav)
+        raise ValueError("time_dependent_avisc = %s is not built (none | mm97 | cd2010 with avisc = mon97)" % tdav)
     c.alpha_visc_min = float(p.get("alpha_visc_min", 0.1))
     c.acond = _ENUMS["acond"][p.get("acond", "none")]
     c.self_gravity = int(p.get("self_gravity", 0))

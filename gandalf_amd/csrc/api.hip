@@ -337,7 +337,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   if ((rc = put(D_U, u, 1, 0, 0.0))) return rc;
   if ((rc = put(D_U0, u, 1, 0, 0.0))) return rc;
   // SphSimulation.cpp:252-257: alpha = alpha_visc, or alpha_visc_min with time-dependent viscosity
-  if ((rc = put(D_ALPHA, nullptr, 1, 0, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? ctx->cfg.alpha_visc_min : ctx->cfg.alpha_visc))) return rc;
+  if ((rc = put(D_ALPHA, nullptr, 1, 0, (ctx->cfg.avisc == GH_AVISC_MON97MM97 || ctx->cfg.avisc == GH_AVISC_MON97CD2010) ? ctx->cfg.alpha_visc_min : ctx->cfg.alpha_visc))) return rc;
   if ((rc = put(D_FLAGS, nullptr, 1, 0, 1.0))) return rc;              // every particle active until the first EndTimestep
   std::vector<int> ids(n);
   for (size_t i = 0; i < n; i++) ids[i] = (int) i;
@@ -470,6 +470,10 @@ static int density_and_hmax(gh_ctx *ctx, bool count)
   int rc = gh_density_impl(ctx, count);
   if (rc) return rc;
   gh_zeta_stars_impl(ctx);                              // hybrid runs: star term of zeta (GradhSph.cpp:288-307)
+  if (ctx->cfg.avisc == GH_AVISC_MON97CD2010) {         // Cullen & Dehnen switch at the end of ComputeH (GradhSph.cpp:319-321)
+    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "time_dependent_avisc = cd2010 runs on one rank");
+    if ((rc = gh_cullen_dehnen_impl(ctx))) return rc;
+  }
   if (ctx->nranks > 1) return GH_OK;                    // h of the other slices arrives with the exchange
   return gh_update_hmax_impl(ctx);                      // tree->UpdateAllHmaxValues, GradhSphTree.cpp:268
 }

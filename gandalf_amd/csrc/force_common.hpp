@@ -83,7 +83,7 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
     // mon97mm97 (GradhSph.cpp:419-424): the pair's mean alpha.  Only the hydro-only driver ever updates alpha
     // (GradhSphTree.cpp:403; UpdateAllSphForces never writes dalphadt back), so with self-gravity every alpha
     // stays alpha_visc_min and the host passes that as alpha_visc with avisc = mon97.
-    if (!GRAV && P.avisc == GH_AVISC_MON97MM97) {
+    if (!GRAV && (P.avisc == GH_AVISC_MON97MM97 || P.avisc == GH_AVISC_MON97CD2010)) {
       const double alpha_mean = 0.5*(ti.alpha + nb.alpha);
       const double vsignal = ti.sound + nb.sound - P.beta_visc*alpha_mean*dvdr;
       paux -= alpha_mean*vsignal*dvdr*winvrho;

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   TargetI ti;
   load_target(d, i, ND, ti);
   const bool mm97 = P.avisc == GH_AVISC_MON97MM97;
-  ti.alpha = mm97 ? d.f[D_ALPHA][i] : 0.0;
+  const bool tdav = mm97 || P.avisc == GH_AVISC_MON97CD2010;      // per-particle alpha (the pair term uses the mean)
+  ti.alpha = tdav ? d.f[D_ALPHA][i] : 0.0;
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
       double sg[3], sh[3];
       code_xform(P.dom, code, sg, sh);
       stage_neib(d, ND, s_t, lane, j, sg, sh, valid);
-      if (mm97) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
+      if (tdav) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
       if (lv) { s_tj[lane] = valid ? j : 0; s_tlv[lane] = valid ? (int) d.f[D_LEVEL][j] : 0; }
     }
     __syncthreads();
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         if (ND > 2) r2 += dr[2]*dr[2];
         Neib nbr;
         neib_from_tile(nbr, s_t, c);
-        nbr.alpha = mm97 ? s_t[T_ALPHA][c] : 0.0;
+        nbr.alpha = tdav ? s_t[T_ALPHA][c] : 0.0;
         sph_pair<ND, false, KT>(P, ti, A, nbr, dr, r2);
         if (COUNT) n_pairs++;
         if (lv) { lnmax = max(lnmax, s_tlv[c]); raise_levelneib(d, s_tj[c], mylevel); }
@@ -571,6 +572,7 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
 int gh_all_forces_impl(gh_ctx *ctx, bool count)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_all_forces: no tree");
+  if (ctx->cfg.avisc == GH_AVISC_MON97CD2010) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "time_dependent_avisc = cd2010 is built for hydro-only runs (self_gravity = 0)");
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN || ctx->cfg.boundary_rhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");

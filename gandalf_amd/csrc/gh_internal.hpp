@@ -213,6 +213,7 @@ int gh_pack_posm(gh_ctx *ctx);
 // hybrid runs (stars.hip): star term of zeta after a density pass, gas <- stars after a gravity pass
 int gh_zeta_stars_impl(gh_ctx *ctx);
 int gh_gas_star_forces_impl(gh_ctx *ctx);
+int gh_cullen_dehnen_impl(gh_ctx *ctx);               // cd2010.hip: alpha, dalphadt after a density pass
 // block timesteps (integrate.hip)
 int gh_thermal_all_impl(gh_ctx *ctx);
 int gh_block_timesteps_impl(gh_ctx *ctx);

@@ -172,7 +172,8 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int, double, double)
   Domain dom;
   gh_fill_domain(ctx, dom);
   hipLaunchKernelGGL(k_kdk_advance, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), dom,
-                     gh_time_dev(ctx), ctx->cfg.energy_integration, ctx->cfg.avisc == GH_AVISC_MON97MM97 ? 1 : 0, ctx->d_blk);
+                     gh_time_dev(ctx), ctx->cfg.energy_integration,
+                     (ctx->cfg.avisc == GH_AVISC_MON97MM97 || ctx->cfg.avisc == GH_AVISC_MON97CD2010) ? 1 : 0, ctx->d_blk);
   return GH_OK;
 }
 

@@ -97,8 +97,9 @@ void SphSimulation::ProcessParameters()
   cfg.gas_eos = enum_of(sp["gas_eos"], eos, 3, "gas_eos");
   cfg.avisc = enum_of(sp["avisc"], av, 2, "avisc");
   if (sp["time_dependent_avisc"] == "mm97" && cfg.avisc == GH_AVISC_MON97) cfg.avisc = GH_AVISC_MON97MM97;   // GradhSphSimulation.cpp:76-79
+  else if (sp["time_dependent_avisc"] == "cd2010" && cfg.avisc == GH_AVISC_MON97) cfg.avisc = GH_AVISC_MON97CD2010;       // GradhSphSimulation.cpp:80-83
   else if (sp["time_dependent_avisc"] != "none")
-    throw GandalfError("Unrecognised parameter : time_dependent_avisc = " + sp["time_dependent_avisc"] + " (built: none, mm97)");
+    throw GandalfError("Unrecognised parameter : time_dependent_avisc = " + sp["time_dependent_avisc"] + " (built: none, mm97, cd2010)");
   cfg.alpha_visc_min = fp["alpha_visc_min"];
   cfg.acond = enum_of(sp["acond"], ac, 3, "acond");
   cfg.self_gravity = ip["self_gravity"];

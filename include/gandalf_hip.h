@@ -42,7 +42,8 @@ enum { GH_KERNEL_M4 = 0, GH_KERNEL_QUINTIC = 1, GH_KERNEL_M4_TAB = 2, GH_KERNEL_
  * barotropic = BarotropicEOS.cpp) */
 enum { GH_EOS_ENERGY_EQN = 0, GH_EOS_ISOTHERMAL = 1, GH_EOS_BAROTROPIC = 2 };
 /* avisc / acond (reference Sph.h aviscenum, acondenum) */
-enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1, GH_AVISC_MON97MM97 = 2 /* avisc = mon97 + time_dependent_avisc = mm97 */ };
+enum { GH_AVISC_NONE = 0, GH_AVISC_MON97 = 1, GH_AVISC_MON97MM97 = 2 /* avisc = mon97 + time_dependent_avisc = mm97 */,
+       GH_AVISC_MON97CD2010 = 3 /* + time_dependent_avisc = cd2010 (Sph.h:364-456); hydro only */ };
 enum { GH_ACOND_NONE = 0, GH_ACOND_WADSLEY2008 = 1, GH_ACOND_PRICE2008 = 2 };
 /* multipole / gravity_mac (reference Tree.h MAC_Type; NeighbourSearch.h:350-475) */
 enum { GH_MULTIPOLE_MONOPOLE = 0, GH_MULTIPOLE_QUADRUPOLE = 1, GH_MULTIPOLE_FAST_MONOPOLE = 2 /* NeighbourSearch.h:481-794 */,

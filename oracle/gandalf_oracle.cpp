@@ -636,7 +636,81 @@ struct Oracle {
     // energy_eqn EOS: AdiabaticEOS.cpp:69-82, EOS.h:156
     pi.sound = sqrt(P.gamma*(P.gamma - 1.0)*pi.u);
     pi.pressure = (P.gamma - 1.0)*pi.rho*pi.u;
+    if (P.tdavisc == 2) CullenDehnen(pi, ngb2);                        // GradhSph.cpp:319-321
     return pi.h <= hmax ? 1 : -1;
+  }
+
+  // Sph::ComputeCullenAndDehnenViscosity, Sph.h:364-456 (time_dependent_avisc = cd2010): integral-gradient estimates of
+  // grad v and grad a over the gather list, d(div v)/dt, Balsara-type limiter, alpha_loc; InvertMatrix InlineFuncs.h:577-606
+  void CullenDehnen(Part &pi, const std::vector<int> &ngb2) const {
+    const int nd = P.ndim;
+    FLOAT dv[3][3], da[3][3], rr[3][3], dvdx[3][3], dadx[3][3], T[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rr[i][j] = da[i][j] = dv[i][j] = dadx[i][j] = dvdx[i][j] = T[i][j] = 0;
+    const FLOAT invh = 1/pi.h;
+    const FLOAT hfac = invh*pi.hfactor/pi.rho;
+    for (size_t n = 0; n < ngb2.size(); n++) {
+      const Part &g = p[ngb2[n]];
+      FLOAT dr[3];
+      for (int j = 0; j < nd; j++) dr[j] = g.r[j] - pi.r[j];
+      const FLOAT w = g.m*hfac*kern.w1(invh*sqrt(Dot(dr, dr, nd)));
+      for (int j = 0; j < nd; j++)
+        for (int k = 0; k < nd; k++) {
+          rr[j][k] += w*dr[j]*dr[k];
+          dv[j][k] += w*dr[j]*(g.v[k] - pi.v[k]);
+          da[j][k] += w*dr[j]*(g.a[k] - pi.a[k]);
+        }
+    }
+    const FLOAT (*A)[3] = rr;
+    if (nd == 1) T[0][0] = 1/A[0][0];
+    else if (nd == 2) {
+      const FLOAT invdet = (FLOAT) 1.0/(A[0][0]*A[1][1] - A[0][1]*A[1][0]);
+      T[0][0] = invdet*A[1][1]; T[0][1] = -invdet*A[0][1]; T[1][0] = -invdet*A[1][0]; T[1][1] = invdet*A[0][0];
+    }
+    else {
+      const FLOAT invdet = (FLOAT) 1.0/(A[0][0]*(A[1][1]*A[2][2] - A[2][1]*A[1][2]) - A[0][1]*(A[1][0]*A[2][2] - A[1][2]*A[2][0]) +
+                                        A[0][2]*(A[1][0]*A[2][1] - A[1][1]*A[2][0]));
+      T[0][0] = (A[1][1]*A[2][2] - A[2][1]*A[1][2])*invdet;
+      T[0][1] = (A[0][2]*A[2][1] - A[0][1]*A[2][2])*invdet;
+      T[0][2] = (A[0][1]*A[1][2] - A[0][2]*A[1][1])*invdet;
+      T[1][0] = (A[1][2]*A[2][0] - A[1][0]*A[2][2])*invdet;
+      T[1][1] = (A[0][0]*A[2][2] - A[0][2]*A[2][0])*invdet;
+      T[1][2] = (A[1][0]*A[0][2] - A[0][0]*A[1][2])*invdet;
+      T[2][0] = (A[1][0]*A[2][1] - A[2][0]*A[1][1])*invdet;
+      T[2][1] = (A[2][0]*A[0][1] - A[0][0]*A[2][1])*invdet;
+      T[2][2] = (A[0][0]*A[1][1] - A[1][0]*A[0][1])*invdet;
+    }
+    double modR = 0, modT = 0;
+    for (int i = 0; i < nd; i++) for (int j = 0; j < nd; j++) { modR += rr[i][j]*rr[i][j]; modT += T[i][j]*T[i][j]; }
+    const double sqd_condition_number = modR*modT/(nd*nd);
+    FLOAT alpha_loc = 0;
+    if (sqd_condition_number > 1e4) alpha_loc = P.alpha_visc;
+    else {
+      for (int i = 0; i < nd; i++) for (int j = 0; j < nd; j++) for (int k = 0; k < nd; k++) {
+        dvdx[i][j] += T[j][k]*dv[k][i];
+        dadx[i][j] += T[j][k]*da[k][i];
+      }
+      FLOAT ddivdt = 0, divv2 = 0;
+      for (int i = 0; i < nd; ++i) {
+        ddivdt += dadx[i][i];
+        for (int j = 0; j < nd; ++j) ddivdt -= dvdx[i][j]*dvdx[j][i];
+        divv2 += dvdx[i][i];
+      }
+      divv2 *= divv2;
+      FLOAT curlv2 = 0;                                              // CurlVelSqd, Sph.h:344-358
+      if (nd == 2) { const FLOAT c = dvdx[1][0] - dvdx[0][1]; curlv2 = c*c; }
+      else if (nd == 3) {
+        const FLOAT c[3] = {dvdx[1][2] - dvdx[2][1], dvdx[2][0] - dvdx[0][2], dvdx[0][1] - dvdx[1][0]};
+        curlv2 = Dot(c, c, 3);
+      }
+      FLOAT f_balsara = 1;
+      if (curlv2 > 0) f_balsara = divv2/(divv2 + curlv2);
+      if (ddivdt < 0) {
+        alpha_loc = (10*pi.h*pi.h/(pi.sound*pi.sound))*f_balsara*(-ddivdt);
+        alpha_loc = std::min(alpha_loc, P.alpha_visc);
+      }
+    }
+    if (alpha_loc > pi.alpha) pi.alpha = alpha_loc;
+    pi.dalphadt = (FLOAT) 0.1*pi.sound*(std::max(P.alpha_visc_min, alpha_loc) - pi.alpha)*invh;
   }
 
   std::vector<int> ActiveLeafCells() const {                         // Tree::ComputeActiveCellList, Tree.cpp:91-115
@@ -949,7 +1023,7 @@ struct Oracle {
         const FLOAT invrho_i = 1/pi.rho;
         pi.div_v *= invrho_i;                                         // GradhSph.cpp:452-453 / 577-578
         pi.dudt -= pi.pressure*pi.div_v*invrho_i*pi.invomega;
-        if (P.tdavisc) {                                               // GradhSph.cpp:454-457 / 579-582 (note the sign quirk)
+        if (P.tdavisc == 1) {                                          // GradhSph.cpp:454-457 / 579-582 (note the sign quirk)
           const FLOAT invh_i = 1/pi.h;
           if (!GRAV) pi.dalphadt = (FLOAT) 0.1*pi.sound*(P.alpha_visc_min - pi.alpha)*invh_i + std::max(-pi.div_v, (FLOAT) 0.0)*(P.alpha_visc - pi.alpha);
           else pi.dalphadt = (FLOAT) 0.1*pi.sound*(P.alpha_visc_min - pi.alpha)*invh_i + std::max(pi.div_v, (FLOAT) 0.0)*(P.alpha_visc - pi.alpha);

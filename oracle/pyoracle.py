@@ -85,8 +85,8 @@ class Oracle:
         q.acond = {"none": 0, "wadsley2008": 1, "price2008": 2}[p.get("acond", "none")]
         q.gravity_mac = {"geometric": 0, "gadget2": 1, "eigenmac": 2}[p.get("gravity_mac", "geometric")]
         q.macerror = float(p.get("macerror", 0.0001))
-        assert p.get("time_dependent_avisc", "none") in ("none", "mm97")
-        q.tdavisc = 1 if p.get("time_dependent_avisc", "none") == "mm97" else 0
+        assert p.get("time_dependent_avisc", "none") in ("none", "mm97", "cd2010")
+        q.tdavisc = {"none": 0, "mm97": 1, "cd2010": 2}[p.get("time_dependent_avisc", "none")]
         q.alpha_visc_min = float(p.get("alpha_visc_min", 0.1))
         q.Nlevels = int(p.get("Nlevels", 1)); q.level_diff_max = int(p.get("level_diff_max", 1))
         q.sph_single_timestep = int(p.get("sph_single_timestep", 0))

@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror", "plummer_4k_fastmono", "plummer_4k_fastquad"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror", "plummer_4k_fastmono", "plummer_4k_fastquad", "adsod_1d_cd2010", "box3d_4k_cd2010"]
 
 
 def make(case):
@@ -165,6 +165,8 @@ def test_steps_match_reference(case):
     assert relerr(sim.download("rho"), g["final_rho"]) < 1e-10
     assert vec_err(sim.download("a"), g["final_a"]) < 1e-9
     assert relerr(sim.download("u"), g["final_u"]) < 1e-10
+    if "final_alpha" in g and "setup_alpha" in g:        # time-dependent viscosity: the switch itself
+        assert relerr(sim.download("alpha"), g["final_alpha"]) < 1e-8
 
 
 def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):

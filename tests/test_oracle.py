@@ -10,7 +10,7 @@ from conftest import PARAMS, load_golden
 from gandalf_amd.params import read_params_file
 from oracle.pyoracle import Oracle
 
-CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror", "plummer_4k_fastmono", "plummer_4k_fastquad"]
+CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror", "plummer_4k_fastmono", "plummer_4k_fastquad", "adsod_1d_cd2010", "box3d_4k_cd2010"]
 
 
 def make(case, g):
@@ -76,6 +76,8 @@ def test_steps_bitwise(case):
     assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
     for k in ["r", "v", "a", "h", "rho", "u", "dudt"]:
         assert np.array_equal(o.get(k), g["final_" + k]), k
+    if "final_alpha" in g:
+        assert np.array_equal(o.get("alpha"), g["final_alpha"]) and np.array_equal(o.get("dalphadt"), g["final_dalphadt"])
 
 
 def test_setup_from_ic_matches_reference_setup():
