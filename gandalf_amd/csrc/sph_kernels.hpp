@@ -288,8 +288,11 @@ __device__ __forceinline__ void eos_eval(const EosParams &e, double rho, double 
     sound = sqrt(e.gamma*e.gammam1*u);
     press = e.gammam1*rho*u;
   }
-  else {  // isothermal in dimensionless units: u = temp0/gammam1/mu_bar (IsothermalEOS.cpp:72-87)
-    u = e.temp0/e.gammam1/e.mu_bar;
+  else {
+    // dimensionless units.  isothermal: u = temp0/gammam1/mu_bar (IsothermalEOS.cpp:72-87); barotropic:
+    // u = temp0 (1 + (rho/rho_bary)^(gamma-1))/gammam1/mu_bar (BarotropicEOS.cpp:78-91); c = sqrt(gammam1 u), P = gammam1 rho u
+    if (e.kind == GH_EOS_BAROTROPIC) u = e.temp0*(1.0 + pow(rho*(1.0/e.rho_bary), e.gammam1))/e.gammam1/e.mu_bar;
+    else u = e.temp0/e.gammam1/e.mu_bar;
     sound = sqrt(e.gammam1*u);
     press = e.gammam1*rho*u;
   }

@@ -59,6 +59,7 @@ struct Params {
   int mirror[3][2];               // mirror wall at the lhs / rhs face of dimension k
   FLOAT macerror, alpha_visc_min;
   int Nlevels, level_diff_max, sph_single_timestep;   // block timesteps (Simulation.cpp:1209-1223)
+  int gas_eos; FLOAT temp0, mu_bar, rho_bary;          // 0 energy_eqn, 1 isothermal, 2 barotropic
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -634,10 +635,20 @@ struct Oracle {
     }
     pi.zeta = h_rho_deriv(pi.h, pi.rho)*pi.zeta*pi.invomega;
     // energy_eqn EOS: AdiabaticEOS.cpp:69-82, EOS.h:156
-    pi.sound = sqrt(P.gamma*(P.gamma - 1.0)*pi.u);
-    pi.pressure = (P.gamma - 1.0)*pi.rho*pi.u;
+    Thermal(pi);
     if (P.tdavisc == 2) CullenDehnen(pi, ngb2);                        // GradhSph.cpp:319-321
     return pi.h <= hmax ? 1 : -1;
+  }
+
+  // GradhSph::ComputeThermalProperties (GradhSph.cpp:335-347) with the three closed-form EOS in dimensionless units:
+  // energy_eqn (AdiabaticEOS.cpp:69-82), isothermal (IsothermalEOS.cpp:72-87), barotropic (BarotropicEOS.cpp:78-91)
+  void Thermal(Part &pi) const {
+    const FLOAT gammam1 = P.gamma - 1.0;
+    if (P.gas_eos == 0) { pi.sound = sqrt(P.gamma*gammam1*pi.u); pi.pressure = gammam1*pi.rho*pi.u; return; }
+    if (P.gas_eos == 2) pi.u = P.temp0*(1.0 + pow(pi.rho*((FLOAT) 1.0/P.rho_bary), gammam1))/gammam1/P.mu_bar;
+    else pi.u = P.temp0/gammam1/P.mu_bar;
+    pi.sound = sqrt(gammam1*pi.u);
+    pi.pressure = gammam1*pi.rho*pi.u;
   }
 
   // Sph::ComputeCullenAndDehnenViscosity, Sph.h:364-456 (time_dependent_avisc = cd2010): integral-gradient estimates of
@@ -1512,8 +1523,7 @@ struct Oracle {
         // SphSimulation.cpp:665-679 (nradstep = 1): thermal properties of ALL particles from the predicted u - a no-op with
         // a global timestep, but with block timesteps this is what refreshes pressure / sound of the inactive neighbours
         for (int i = 0; i < Nhydro; i++) {
-          p[i].sound = sqrt(P.gamma*(P.gamma - 1.0)*p[i].u);
-          p[i].pressure = (P.gamma - 1.0)*p[i].rho*p[i].u;
+          Thermal(p[i]);
         }
         Forces();
         for (int i = 0; i < Nhydro; i++) p[i].flags &= ~F_ACTIVE;
@@ -1653,8 +1663,8 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep;
-  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep, gas_eos, pad2_;
+  double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min, temp0, mu_bar, rho_bary;
 };
 
 Oracle *orc_create(const orc_params *q)
@@ -1663,6 +1673,7 @@ Oracle *orc_create(const orc_params *q)
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
   P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
+  P.gas_eos = q->gas_eos; P.temp0 = q->temp0; P.mu_bar = q->mu_bar; P.rho_bary = q->rho_bary;
   P.Nlevels = q->Nlevels > 1 ? q->Nlevels : 1; P.level_diff_max = q->level_diff_max; P.sph_single_timestep = q->sph_single_timestep;
   for (int k = 0; k < 3; k++) {
     P.periodic[k] = q->periodic[k] == 1; P.mirror[k][0] = (q->periodic[k] & 2) != 0; P.mirror[k][1] = (q->periodic[k] & 4) != 0;
