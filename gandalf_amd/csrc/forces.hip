@@ -26,21 +26,21 @@
 // ================================================================================================
 // hydro only                                                     (GradhSphTree.cpp:280-435)
 // ================================================================================================
-template <int ND, bool COUNT, int KT>
+template <int ND, bool COUNT, int KT, bool LV>
 __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   __shared__ WalkLDS<int> L;
   __shared__ double s_t[T_NFA][64];
-  __shared__ int s_tj[64], s_tlv[64];                   // block timesteps: particle index and level of every tile slot
+  __shared__ int s_tj[LV ? 64 : 1], s_tlv[LV ? 64 : 1];   // block timesteps: particle index and level of every tile slot
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
-  // block timesteps (Nlevels > 1, wave-uniform flag): targets are the active particles only and the pair loop also
+  // block timesteps (Nlevels > 1: the LV instantiation): targets are the active particles only and the pair loop also
   // maintains levelneib
-  const bool lv = d.levels != 0;
+  constexpr bool lv = LV;
   const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   if (lv && !__any(act)) return;
   const int i = gfirst + (act ? lane : 0);
@@ -539,8 +539,12 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_, KT_)                                                                                            \
-    if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
+    if (ctx->cfg.Nlevels > 1) { \
+      if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    } \
+    else if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true, KT_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_, false>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   }
