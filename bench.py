@@ -31,6 +31,8 @@ WORKLOADS = {
                                desc="3-D Plummer gas sphere, N=1048576, multipole = fast_monopole (not the metric's config)"),
     "plummer1m_quad": dict(params="plummer_4k.dat", overrides={"Nhydro": 1048576, "run_id": "PLUM1MQ", "multipole": "quadrupole"},
                            desc="3-D Plummer gas sphere, N=1048576, multipole = quadrupole, the reference's default (not the metric's config)"),
+    "plummer1m_tb8": dict(params="plummer_4k.dat", overrides={"Nhydro": 1048576, "run_id": "PLUM1MTB8", "ntreebuildstep": 8},
+                          desc="3-D Plummer gas sphere, N=1048576, ntreebuildstep = 8: tree re-stocked on 7 of 8 steps (not the metric's config)"),
     "plummer64k": dict(params="plummer_4k.dat", overrides={"Nhydro": 65536, "run_id": "PLUM64K"},
                        desc="3-D Plummer gas sphere, N=65536 (reduced; not the metric's config)"),
 }

@@ -210,6 +210,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (cfg->kernel < GH_KERNEL_M4 || cfg->kernel > GH_KERNEL_QUINTIC_TAB)
     return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic, each with tabulated_kernel = 0 or 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
+  if (cfg->ntreebuildstep > 1 && cfg->ntreestockstep > 1)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "ntreebuildstep > 1 needs ntreestockstep = 1 (ExtrapolateCellProperties is not built)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");
@@ -345,6 +347,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->tree_valid = false;
   ctx->n = 0; ctx->Nsteps = 0; ctx->t = 0.0; ctx->timestep = 0.0;
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
+  ctx->rebuild_tree = true;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
   GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
@@ -645,14 +648,28 @@ static int build_tree_timed(gh_ctx *ctx)
   return rc;
 }
 
+// HydroTree::BuildTree as MainLoop calls it (HydroTree.cpp:325-343): rebuild every ntreebuildstep steps and on the first
+// step after the setup (rebuild_tree), re-stock the existing tree otherwise
+static int step_tree_timed(gh_ctx *ctx)
+{
+  const int ntb = ctx->cfg.ntreebuildstep;
+  if (ntb <= 1 || ctx->nranks > 1 || ctx->rebuild_tree || ctx->Nsteps%ntb == 0 || ctx->tree_layout_N != ctx->N) return build_tree_timed(ctx);
+  gh_phase_begin(ctx, GH_T_BUILD_TREE);
+  int rc = gh_tree_restock_impl(ctx);
+  gh_phase_end(ctx, GH_T_BUILD_TREE);
+  return rc;
+}
+
 // the gas passes of one MainLoop call, enqueued only (used by gh_hybrid_step, nbody.hip)
 int gh_hybrid_gas_passes(gh_ctx *ctx)
 {
   int rc;
-  if ((rc = build_tree_timed(ctx))) return rc;
+  if ((rc = step_tree_timed(ctx))) return rc;
   if ((rc = density_and_hmax(ctx, false))) return rc;
   gh_zero_acc_impl(ctx);
-  return forces_impl(ctx);
+  if ((rc = forces_impl(ctx))) return rc;
+  ctx->rebuild_tree = false;
+  return GH_OK;
 }
 
 extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
@@ -717,7 +734,7 @@ static int block_step(gh_ctx *ctx)
   gh_phase_begin(ctx, GH_T_KDK);
   gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // all particles drift; active = end of own step
   gh_phase_end(ctx, GH_T_KDK);
-  if ((rc = build_tree_timed(ctx))) return rc;
+  if ((rc = step_tree_timed(ctx))) return rc;
   for (;;) {
     if ((rc = density_and_hmax(ctx, false))) return rc;
     gh_zero_acc_impl(ctx);
@@ -735,6 +752,7 @@ static int block_step(gh_ctx *ctx)
   gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // EndTimestep of the particles that finished their step
   gh_phase_end(ctx, GH_T_KDK);
   if ((rc = gh_sync_collect(ctx, "gh_step/block"))) return rc;
+  ctx->rebuild_tree = false;
   return pull_block(ctx);
 }
 
@@ -757,7 +775,7 @@ extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
     gh_phase_begin(ctx, GH_T_KDK);
     gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // AdvanceParticles + CheckBoundaries
     gh_phase_end(ctx, GH_T_KDK);
-    if ((rc = build_tree_timed(ctx))) return rc;         // BuildTree (rebuilt every step)
+    if ((rc = step_tree_timed(ctx))) return rc;          // BuildTree: rebuild or re-stock
     if ((rc = density_and_hmax(ctx, false))) return rc;  // UpdateAllSphProperties
     gh_zero_acc_impl(ctx);                               // ZeroAccelerations
     if ((rc = forces_impl(ctx))) return rc;              // UpdateAllSph(Hydro)Forces
@@ -766,6 +784,7 @@ extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
     gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                   // EndTimestep
     gh_phase_end(ctx, GH_T_KDK);
     ctx->n = 0;
+    ctx->rebuild_tree = false;
   }
   if ((rc = gh_sync_collect(ctx, "gh_step"))) return rc;
   if ((rc = pull_time(ctx))) return rc;

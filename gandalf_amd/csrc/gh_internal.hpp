@@ -120,6 +120,7 @@ struct gh_ctx {
   int lsub = 0;                    // first level built by the LDS-resident subtree kernel
   double *redbuf = nullptr;        // reduction scratch
   bool tree_valid = false;
+  bool rebuild_tree = true;        // SimulationBase::rebuild_tree: raised by upload / setup, lowered at the end of a step
 
   // gravity interaction lists in HBM (gravity.hip)
   int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr, *gl_gcells = nullptr, *gl_glen = nullptr;
@@ -199,6 +200,7 @@ DevicePtrs gh_dev(gh_ctx *ctx);
 int gh_alloc_particles(gh_ctx *ctx, int64_t N);
 int gh_alloc_tree(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx);
+int gh_tree_restock_impl(gh_ctx *ctx);   // KDTree::StockTree: same cells and particle order, properties from the current r, h
 int gh_update_hmax_impl(gh_ctx *ctx);
 // the *_impl functions only enqueue work on ctx->stream (no host synchronisation)
 int gh_density_impl(gh_ctx *ctx, bool count);

@@ -788,3 +788,13 @@ int gh_tree_build_impl(gh_ctx *ctx)
   ctx->tree_valid = true;
   return GH_OK;
 }
+
+int gh_tree_restock_impl(gh_ctx *ctx)
+{
+  if (!ctx->tree_valid && ctx->tree_layout_N != ctx->N) return gh_tree_build_impl(ctx);
+  stock_tree(ctx, 0);
+  gh_pack_posm(ctx);
+  GH_CHECK(ctx, hipGetLastError());
+  ctx->tree_valid = true;
+  return GH_OK;
+}

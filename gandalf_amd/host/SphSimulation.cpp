@@ -109,6 +109,7 @@ void SphSimulation::ProcessParameters()
   cfg.macerror = fp["macerror"];
   cfg.Nleafmax = ip["Nleafmax"];
   cfg.Nlevels = ip["Nlevels"]; cfg.level_diff_max = ip["level_diff_max"];   // Simulation.cpp:1209-1211
+  cfg.ntreebuildstep = ip["ntreebuildstep"]; cfg.ntreestockstep = ip["ntreestockstep"];
   cfg.device = ip["device"];
   cfg.energy_integration = sp["gas_eos"] == "energy_eqn" ? 1 : 0;     // GradhSphSimulation.cpp:114-122
   for (int k = 0; k < 3; k++) {

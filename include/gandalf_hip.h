@@ -69,6 +69,9 @@ typedef struct gh_config {
   int32_t boundary_rhs[3]; /* boundary_rhs[k] */
   int32_t Nlevels;         /* Nlevels: 1 = global timestep, > 1 = hierarchical block timesteps (Simulation.cpp:1764-2200) */
   int32_t level_diff_max;  /* level_diff_max: largest level difference tolerated between SPH neighbours (SphLeapfrogKDK.cpp:284-330) */
+  int32_t ntreebuildstep;  /* ntreebuildstep: the tree is rebuilt every ntreebuildstep steps (and on the first step after the setup) and
+                            * re-stocked in between (HydroTree::BuildTree, HydroTree.cpp:325-343); <= 1: rebuilt every step */
+  int32_t ntreestockstep;  /* ntreestockstep: must be 1 when ntreebuildstep > 1 (ExtrapolateCellProperties is not built) */
   double  boxmin[3];       /* boxmin[k] */
   double  boxmax[3];       /* boxmax[k] */
   double  h_fac;           /* h_fac */

@@ -60,6 +60,7 @@ struct Params {
   FLOAT macerror, alpha_visc_min;
   int Nlevels, level_diff_max, sph_single_timestep;   // block timesteps (Simulation.cpp:1209-1223)
   int gas_eos; FLOAT temp0, mu_bar, rho_bary;          // 0 energy_eqn, 1 isothermal, 2 barotropic
+  int ntreebuildstep;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -403,6 +404,11 @@ struct KDTree {
     c.ilast = b.ilast;
     StockCellProperties(c, p);
   }
+  // KDTree::StockTree, KDTree.cpp:760-798: re-stock every cell bottom-up, membership unchanged
+  void StockTree(Cell &c, const std::vector<Part> &p) {
+    if (c.level != ltot) { StockTree(cell[c.c1], p); StockTree(cell[c.c2], p); }
+    StockCellProperties(c, p);
+  }
   void BuildTree(int _ifirst, int Npart, const std::vector<Part> &p) {              // KDTree.cpp:220-313
     const int nd = P->ndim;
     Ntot = Npart;
@@ -523,6 +529,7 @@ struct Oracle {
   int Nhydro = 0, Nghost = 0;
   KDTree tree, ghosttree;
   int n = 0, Nsteps = 0; double t = 0.0, timestep = 0.0;
+  bool rebuild_tree = true;
   int nresync = 0, level_max = 0, level_step = 1, integration_step = 1; double dt_max = 0.0;   // Simulation.cpp:159-198
   std::string err;
   explicit Oracle(const Params &pp) : P(pp), kern(pp.ndim, pp.kernel & 1, (pp.kernel >> 1) & 1), invndim(1.0/pp.ndim) {
@@ -581,6 +588,15 @@ struct Oracle {
     }
   }
   void BuildTree() { p.resize(Nhydro); Nghost = 0; tree.BuildTree(0, Nhydro, p); }
+  // HydroTree::BuildTree inside MainLoop (HydroTree.cpp:310-372): rebuild every ntreebuildstep steps, re-stock otherwise
+  // (ntreestockstep = 1; ExtrapolateCellProperties is not restated)
+  void StepTree() {
+    // rebuild_tree is raised by the setup and only lowered at the end of a MainLoop call (SphSimulation.cpp:866): the
+    // first step after the setup always rebuilds
+    if (P.ntreebuildstep <= 1 || Nsteps%P.ntreebuildstep == 0 || rebuild_tree) { BuildTree(); return; }
+    p.resize(Nhydro); Nghost = 0;
+    tree.StockTree(tree.cell[0], p);
+  }
   void BuildGhostTree() { ghosttree.BuildTree(Nhydro, Nghost, p); }
 
   // ---- GradhSph::ComputeH, GradhSph.cpp:142-326 (no sinks, no stars) + ComputeThermalProperties :335-347
@@ -1514,7 +1530,7 @@ struct Oracle {
     n++; Nsteps++; t = t + timestep;
     AdvanceParticles();
     if (P.Nlevels > 1) {
-      BuildTree(); SearchBoundaryGhostParticles(); BuildGhostTree();
+      StepTree(); SearchBoundaryGhostParticles(); BuildGhostTree();
       int activecount = 0;
       do {                                                             // SphSimulation.cpp:654-755
         if (activecount > 0) UpdateActiveParticleCounters();
@@ -1530,11 +1546,13 @@ struct Oracle {
         activecount = CheckTimesteps();
       } while (activecount > 0);
       ComputeBlockTimesteps(); EndTimestep();
+      rebuild_tree = false;
       return;
     }
-    BuildTree(); DensityPass();
+    StepTree(); DensityPass();
     ZeroAccelerations(); Forces();
     ComputeGlobalTimestep(); EndTimestep();
+    rebuild_tree = false;
   }
 };
 
@@ -1663,7 +1681,7 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep, gas_eos, pad2_;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep, gas_eos, ntreebuildstep;
   double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min, temp0, mu_bar, rho_bary;
 };
 
@@ -1673,6 +1691,7 @@ Oracle *orc_create(const orc_params *q)
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
   P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
+  P.ntreebuildstep = q->ntreebuildstep > 1 ? q->ntreebuildstep : 1;
   P.gas_eos = q->gas_eos; P.temp0 = q->temp0; P.mu_bar = q->mu_bar; P.rho_bary = q->rho_bary;
   P.Nlevels = q->Nlevels > 1 ? q->Nlevels : 1; P.level_diff_max = q->level_diff_max; P.sph_single_timestep = q->sph_single_timestep;
   for (int k = 0; k < 3; k++) {
@@ -1869,7 +1888,7 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   g.stars.resize(nb.N);
   g.star_softening = nb.softening;
   for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].r[k] = nb.s[i].r[k]; g.stars[i].m = nb.s[i].m; g.stars[i].h = nb.s[i].h; }
-  g.BuildTree(); g.DensityPass();
+  g.StepTree(); g.DensityPass();
   g.ZeroAccelerations(); g.Forces();
   nb.Zero();                                                         // :773-784
   for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].a[k] = 0.0; g.stars[i].gpot = 0.0; }
@@ -1885,6 +1904,7 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   for (int i = 0; i < nb.N; i++) nb.s[i].dt_next = ts;
   g.EndTimestep();
   nb.EndTimestep(0);
+  g.rebuild_tree = false;
 }
 void orc_hybrid_step(Oracle *g, NbodyOracle *nb, int nsteps) { for (int s = 0; s < nsteps; s++) HybridMainLoop(*g, *nb); }
 

@@ -160,3 +160,20 @@ def test_run_from_reference_snapshot(tmp_path):
     f = read_snapshot(out, "su")
     assert f["t"] == sim.t and f["Nsteps"] == int(g["nsteps"][0])
     assert np.array_equal(f["rho"], dev.download("rho")) and np.array_equal(f["r"].ravel(), dev.download("r").ravel())
+
+
+@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4"])
+def test_restocked_tree_runs_match_reference(case):
+    """ntreebuildstep = 4: from the IC through the setup and ten steps - the tree is rebuilt on steps 1, 4, 8 and re-stocked
+    (same cells, properties from the moved particles) on the others, as HydroTree::BuildTree does"""
+    from gandalf_amd.host import Simulation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", case + "_steps.npz"))
+    sim = Simulation(os.path.join(PARAMS, case + ".dat"))
+    sim.setup()
+    sim.main_loop(int(g["nsteps"][0]))
+    dev = sim.device()
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-11*abs(g["final_t_timestep"][0])
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-9
+    a, ar = dev.download("a"), g["final_a"]
+    assert np.max(np.linalg.norm(a - ar, axis=1)/np.maximum(np.linalg.norm(ar, axis=1), np.linalg.norm(ar, axis=1).mean())) < 1e-8

@@ -191,3 +191,22 @@ def test_hybrid_steps_bitwise():
         assert np.array_equal(o.get(k), g["final_" + k]), k
     for k in ["r", "v", "a", "adot", "gpot", "r0", "v0", "a0"]:
         assert np.array_equal(nb.get(k), g["final_star_" + k]), "star " + k
+
+
+@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4"])
+def test_restocked_tree_steps_bitwise(case):
+    """ntreebuildstep = 4, ntreestockstep = 1, from the IC: setup, then ten MainLoop calls of which steps 4 and 8 rebuild
+    the tree and the others re-stock the existing one (HydroTree::BuildTree, HydroTree.cpp:325-343; KDTree::StockTree).
+    The first steps re-stock the tree the SETUP built, so the run has to include the setup."""
+    from gandalf_amd.host import Simulation
+    g = load_golden(case + "_steps")
+    pf = "%s/%s.dat" % (PARAMS, case)
+    ic = Simulation(pf).generate_ic()
+    o = Oracle(read_params_file(pf), nthreads=4)
+    o.set_particles(ic["r"], ic["m"], ic["h"], v=ic["v"], u=ic["u"])
+    o.setup(h_provided=ic["initial_h_provided"])
+    assert o.timestep == g["setup_t_timestep"][1]
+    o.step(int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ["r", "v", "a", "h", "rho", "u", "dudt"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
