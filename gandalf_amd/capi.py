@@ -30,6 +30,7 @@ class Config(C.Structure):
         ("energy_integration", C.c_int32), ("device", C.c_int32),
         ("boundary_lhs", C.c_int32 * 3), ("boundary_rhs", C.c_int32 * 3),
         ("Nlevels", C.c_int32), ("level_diff_max", C.c_int32), ("ntreebuildstep", C.c_int32), ("ntreestockstep", C.c_int32),
+        ("sph_single_timestep", C.c_int32), ("reserved_", C.c_int32),
         ("boxmin", C.c_double * 3), ("boxmax", C.c_double * 3),
         ("h_fac", C.c_double), ("h_converge", C.c_double), ("alpha_visc", C.c_double),
         ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("temp0", C.c_double),
@@ -171,8 +172,7 @@ def config_from_params(p, device=0):
     c.level_diff_max = int(p.get("level_diff_max", 1))
     c.ntreebuildstep = int(p.get("ntreebuildstep", 1))
     c.ntreestockstep = int(p.get("ntreestockstep", 1))
-    if c.Nlevels > 1 and int(p.get("sph_single_timestep", 0)):
-        raise ValueError("sph_single_timestep = 1 is not built")
+    c.sph_single_timestep = int(p.get("sph_single_timestep", 0))
     c.energy_integration = 1 if p.get("gas_eos", "energy_eqn") == "energy_eqn" else 0
     c.device = device
     for k in range(3):

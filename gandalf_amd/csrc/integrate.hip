@@ -217,7 +217,7 @@ int gh_kdk_end_impl(gh_ctx *ctx, int, double, double)
 // nstep = 0 and therefore dt_next = 0 until the next pass refreshes nstep, Simulation.cpp:1989-1990 with :2141-2146)
 __device__ __forceinline__ int ipow2(int e) { return e >= 0 ? (1 << e) : 0; }
 
-enum { B_N = 0, B_NRESYNC, B_LMAX, B_LSTEP, B_LMAXNEW, B_ACTIVE, B_MUL, B_DIV };
+enum { B_N = 0, B_NRESYNC, B_LMAX, B_LSTEP, B_LMAXNEW, B_ACTIVE, B_MUL, B_DIV, B_CNT0, B_CNT1, B_LMH };   // B_CNT*: 64-bit active counter
 
 // ComputeTimestepLevel, InlineFuncs.h:550-558
 __device__ __forceinline__ int timestep_level(double dt, double dt_max)
@@ -242,14 +242,17 @@ __global__ void k_block_resync_clock(int *blk, double *time, int Nlevels)
   blk[B_LMAX] = Nlevels - 1;
   blk[B_LSTEP] = Nlevels - 1;                                // level_max + integration_step - 1, integration_step = 1 (lfkdk)
   time[2] = time[1]*(double) (1 << (Nlevels - 1));           // dt_max = timestep*2^level_max
+  const int lmh = timestep_level(time[1], time[2]);          // level_max_hydro (:1857): the minimum timestep is a gas one
+  blk[B_LMH] = lmh < Nlevels - 1 ? lmh : Nlevels - 1;
 }
-__global__ void k_block_resync_assign(DevicePtrs d, const int *blk, const double *time)
+__global__ void k_block_resync_assign(DevicePtrs d, const int *blk, const double *time, int single)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
   const int level_max = blk[B_LMAX], level_step = blk[B_LSTEP];
   int level = timestep_level(d.f[D_DT_NEXT][i], time[2]);
   level = level < level_max ? level : level_max;
+  if (single) level = blk[B_LMH];                            // sph_single_timestep (:1890-1900)
   const int nstep = ipow2(level_step - level);
   d.f[D_LEVEL][i] = (double) level; d.f[D_LEVELNEIB][i] = (double) level;
   d.f[D_NSTEP][i] = (double) nstep; d.f[D_NLAST][i] = 0.0;
@@ -311,18 +314,21 @@ __global__ void k_block_clock(int *blk, double *time)
   else level_max = level_max_old;
   blk[B_N] = n; blk[B_LMAX] = level_max; blk[B_LSTEP] = level_max;
   blk[B_NRESYNC] = 1 << level_max;
-  blk[B_MUL] = mul; blk[B_DIV] = div; blk[B_LMAXNEW] = 0;
+  blk[B_MUL] = mul; blk[B_DIV] = div; blk[B_LMH] = blk[B_LMAXNEW]; blk[B_LMAXNEW] = 0;   // hydro only: level_max_hydro = max level
   time[1] = time[2]/(double) blk[B_NRESYNC];
 }
 // pass 3: rescale the integer times, refresh nstep of the particles that just ended their step (:2101-2146)
-__global__ void k_block_rescale(DevicePtrs d, const int *blk)
+__global__ void k_block_rescale(DevicePtrs d, const int *blk, int single)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
   const int mul = blk[B_MUL], div = blk[B_DIV];
   int nstep = (int) d.f[D_NSTEP][i], nlast = (int) d.f[D_NLAST][i];
   nstep = nstep*mul/div; nlast = nlast*mul/div;
-  if (nlast == blk[B_N]) nstep = ipow2(blk[B_LSTEP] - (int) d.f[D_LEVEL][i]);
+  if (nlast == blk[B_N]) {
+    if (single) d.f[D_LEVEL][i] = (double) blk[B_LMH];      // sph_single_timestep (:2090-2096)
+    nstep = ipow2(blk[B_LSTEP] - (int) d.f[D_LEVEL][i]);
+  }
   d.f[D_NSTEP][i] = (double) nstep; d.f[D_NLAST][i] = (double) nlast;
 }
 
@@ -378,13 +384,13 @@ int gh_block_timesteps_impl(gh_ctx *ctx)
     hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, s, d, fill_tp(ctx), ctx->redbuf);
     hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
     hipLaunchKernelGGL(k_block_resync_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time, ctx->cfg.Nlevels);
-    hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time);
+    hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time, ctx->cfg.sph_single_timestep);
     hipLaunchKernelGGL(k_block_resync_finish, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
   }
   else {
     hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
     hipLaunchKernelGGL(k_block_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
-    hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk);
+    hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, ctx->cfg.sph_single_timestep);
   }
   return GH_OK;
 }

@@ -86,7 +86,6 @@ void SphSimulation::ProcessParameters()
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   if (sp["neib_search"] != "kdtree") throw GandalfError("Unrecognised parameter : neib_search = " + sp["neib_search"]);
   if (sp["sph_integration"] != "lfkdk") throw GandalfError("Unrecognised parameter : sph_integration = " + sp["sph_integration"]);
-  if (ip["Nlevels"] > 1 && ip["sph_single_timestep"] != 0) throw GandalfError("sph_single_timestep = 1 is not built");
   static const char *kern[] = {"m4", "quintic"}, *eos[] = {"energy_eqn", "isothermal", "barotropic"};
   static const char *av[] = {"none", "mon97"}, *ac[] = {"none", "wadsley2008", "price2008"};
   static const char *mp[] = {"monopole", "quadrupole", "fast_monopole", "fast_quadrupole"}, *mac[] = {"geometric", "gadget2", "eigenmac"}, *bd[] = {"open", "periodic", "mirror"};
@@ -110,6 +109,7 @@ void SphSimulation::ProcessParameters()
   cfg.Nleafmax = ip["Nleafmax"];
   cfg.Nlevels = ip["Nlevels"]; cfg.level_diff_max = ip["level_diff_max"];   // Simulation.cpp:1209-1211
   cfg.ntreebuildstep = ip["ntreebuildstep"]; cfg.ntreestockstep = ip["ntreestockstep"];
+  cfg.sph_single_timestep = ip["sph_single_timestep"];
   cfg.device = ip["device"];
   cfg.energy_integration = sp["gas_eos"] == "energy_eqn" ? 1 : 0;     // GradhSphSimulation.cpp:114-122
   for (int k = 0; k < 3; k++) {

@@ -175,7 +175,7 @@ if __name__ == "__main__":
             long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
         elif cfg.endswith("_fromfile"):
             fromfile(cfg)
-        elif cfg.endswith("_levels"):
+        elif cfg.endswith("_levels") or cfg.endswith("_levels_single"):
             levels(cfg)
         elif cfg == "nbody":
             nbody(256, 0)

@@ -185,7 +185,7 @@ def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):
     assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
 
 
-LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels"]
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single"]
 
 
 @pytest.mark.parametrize("case", LEVEL_CASES)

@@ -113,7 +113,7 @@ def test_config1_full_run_bitwise():
         assert np.array_equal(o.get(k), g["final_" + k]), k
 
 
-LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels"]
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single"]
 
 
 def upload_block_state(o, g, pre):
