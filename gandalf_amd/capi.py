@@ -106,6 +106,7 @@ SYMBOLS = {
     "gh_nbody_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
     "gh_nbody_upload_field": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_hybrid_step": (C.c_int, [_CTX, _CTX, C.c_int, _PD, _PD]),
+    "gh_hybrid_setup": (C.c_int, [_CTX, _CTX, C.c_int, _PD]),
 }
 
 _lib = None
@@ -476,6 +477,14 @@ class NbodyHip:
     def upload_field(self, name, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         self._chk(self.lib.gh_nbody_upload_field(self.ctx, self.FIELDS[name], _dp(arr)))
+
+    def hybrid_setup(self, gas, initial_h_provided=False):
+        """PostInitialConditionsSetup of a hybrid run; returns the first timestep"""
+        dt = C.c_double()
+        rc = self.lib.gh_hybrid_setup(gas.ctx, self.ctx, 1 if initial_h_provided else 0, C.byref(dt))
+        if rc:
+            raise GhError(rc, gas.lib.gh_last_error(gas.ctx).decode() or self.lib.gh_nbody_last_error(self.ctx).decode())
+        return dt.value
 
     def hybrid_step(self, gas, nsteps=1):
         """nsteps MainLoop calls of a hybrid gas + stars run; `gas` is the GandalfHip context holding the gas"""

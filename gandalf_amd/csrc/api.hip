@@ -672,9 +672,35 @@ int gh_hybrid_gas_passes(gh_ctx *ctx)
   return GH_OK;
 }
 
+int gh_setup_passes(gh_ctx *ctx, int initial_h_provided);
+
 extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
 {
   if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
+  int rc;
+  if ((rc = gh_setup_passes(ctx, initial_h_provided))) return rc;
+  // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
+  // the simulation time is 0 after gh_upload_particles, or what gh_set_time put there (runs started from a snapshot)
+  ctx->timestep = 0.0; ctx->n = 0;
+  if ((rc = push_time(ctx))) return rc;
+  if (ctx->cfg.Nlevels > 1) {
+    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
+    ctx->nresync = 0;
+    if ((rc = push_block(ctx))) return rc;
+    gh_block_timesteps_impl(ctx);                        // ComputeBlockTimesteps (:539): n == nresync == 0, resynchronise
+  }
+  else gh_timestep_impl(ctx);                            // ComputeGlobalTimestep (:538)
+  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // hydroint->EndTimestep (:551)
+  if ((rc = gh_sync_collect(ctx, "gh_setup"))) return rc;
+  if ((rc = pull_time(ctx))) return rc;
+  if (ctx->cfg.Nlevels > 1 && (rc = pull_block(ctx))) return rc;
+  if (timestep) *timestep = ctx->timestep;
+  return GH_OK;
+}
+
+// the density and force passes of PostInitialConditionsSetup (enqueued; also the first half of gh_hybrid_setup, nbody.hip)
+int gh_setup_passes(gh_ctx *ctx, int initial_h_provided)
+{
   int rc;
   // SphSimulation::PostInitialConditionsSetup (SphSimulation.cpp:266-345): density with the guessed h
   // first if no h was provided, then tree + density, then (iteration loop :381-473) tree + density + forces
@@ -696,22 +722,6 @@ extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
     gh_zero_acc_impl(ctx);
     if ((rc = forces_impl(ctx))) return rc;
   }
-  // r0,v0,a0 = r,v,a (:483-489) happens in kdk_end below because dt = 0 leaves v unchanged
-  // the simulation time is 0 after gh_upload_particles, or what gh_set_time put there (runs started from a snapshot)
-  ctx->timestep = 0.0; ctx->n = 0;
-  if ((rc = push_time(ctx))) return rc;
-  if (ctx->cfg.Nlevels > 1) {
-    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
-    ctx->nresync = 0;
-    if ((rc = push_block(ctx))) return rc;
-    gh_block_timesteps_impl(ctx);                        // ComputeBlockTimesteps (:539): n == nresync == 0, resynchronise
-  }
-  else gh_timestep_impl(ctx);                            // ComputeGlobalTimestep (:538)
-  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // hydroint->EndTimestep (:551)
-  if ((rc = gh_sync_collect(ctx, "gh_setup"))) return rc;
-  if ((rc = pull_time(ctx))) return rc;
-  if (ctx->cfg.Nlevels > 1 && (rc = pull_block(ctx))) return rc;
-  if (timestep) *timestep = ctx->timestep;
   return GH_OK;
 }
 

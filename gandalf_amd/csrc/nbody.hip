@@ -435,3 +435,51 @@ extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_o
   if (timestep_out) *timestep_out = gas->timestep;
   return GH_OK;
 }
+
+int gh_setup_passes(gh_ctx *ctx, int initial_h_provided);    // api.hip
+
+// PostInitialConditionsSetup of a hybrid run (SphSimulation.cpp:204-565): gas passes with the stars present, star forces
+// (gas tree part + direct sum, :500-514), first timestep = minimum over both species (:538), EndTimestep of both (:551-553)
+extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided, double *timestep_out)
+{
+  if (!gas || !nb || nb->N <= 0 || gas->N <= 0) return GH_ERR_INVALID;
+  if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
+  if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
+  const int64_t Ns = nb->N;
+  const int nd = nb->ndim;
+  NbPtrs p = nb_ptrs(nb);
+  const int nblk = (int) ((Ns + 255)/256);
+  std::vector<double> sr((size_t) Ns*nd), sm((size_t) Ns), shh((size_t) Ns), ga((size_t) Ns*nd), gg((size_t) Ns);
+  NB_CHECK(nb, hipMemcpy(sm.data(), nb->m, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  NB_CHECK(nb, hipMemcpy(shh.data(), nb->h, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  int rc;
+  if ((rc = gh_nbody_download(nb, GH_NB_R, sr.data()))) return rc;
+  if ((rc = gh_set_stars(gas, Ns, sr.data(), sm.data(), shh.data(), nb->softening))) return rc;
+  if ((rc = gh_setup_passes(gas, initial_h_provided))) return rc;
+  if ((rc = gh_star_gas_forces(gas, ga.data(), gg.data()))) return rc;
+  double td[2] = {gas->t, 0.0};
+  NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  if ((rc = nb_launch_forces(nb))) return rc;
+  NB_CHECK(nb, hipMemcpyAsync(nb->stage, ga.data(), sizeof(double)*Ns*nd, hipMemcpyHostToDevice, nb->stream));
+  NB_CHECK(nb, hipMemcpyAsync(nb->stage + (size_t) Ns*nd, gg.data(), sizeof(double)*Ns, hipMemcpyHostToDevice, nb->stream));
+  hipLaunchKernelGGL(k_nbody_add_gas, dim3(nblk), dim3(256), 0, nb->stream, p, nb->stage, nb->stage + (size_t) Ns*nd);
+  hipLaunchKernelGGL(k_nbody_correct_dt, dim3(nblk), dim3(256), 0, nb->stream, p, nb->nbody_mult, nb->red, 0);
+  hipLaunchKernelGGL(k_nbody_end, dim3(std::min(nblk, 256)), dim3(256), 0, nb->stream, p, nb->red, nblk);
+  double star_min = 0.0;
+  NB_CHECK(nb, hipMemcpyAsync(&star_min, nb->tdt + 2, sizeof(double), hipMemcpyDeviceToHost, nb->stream));
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  gas->timestep = 0.0; gas->n = 0;
+  double tt0[2] = {gas->t, 0.0};
+  GH_CHECK(gas, hipMemcpyAsync(gh_time_dev(gas), tt0, sizeof(tt0), hipMemcpyHostToDevice, gas->stream));
+  GH_CHECK(gas, hipMemcpyAsync(gas->redbuf + 256, &star_min, sizeof(double), hipMemcpyHostToDevice, gas->stream));
+  gh_timestep_impl_extra(gas, 1);
+  gh_kdk_end_impl(gas, 0, 0.0, 0.0);
+  if ((rc = gh_sync_collect(gas, "gh_hybrid_setup"))) return rc;
+  double tt[2];
+  GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+  gas->t = tt[0]; gas->timestep = tt[1];
+  td[0] = gas->t; td[1] = gas->timestep;
+  NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  if (timestep_out) *timestep_out = gas->timestep;
+  return GH_OK;
+}

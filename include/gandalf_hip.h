@@ -294,6 +294,9 @@ int gh_nbody_upload_field(gh_nbody *nb, int field, const double *src);
  * get the gas' tree forces (gh_star_gas_forces) on top of their direct sum, the timestep is the minimum over both
  * (Simulation::ComputeGlobalTimestep, Simulation.cpp:1669-1754).  gas must hold the post-setup state (gh_set_time). */
 int gh_hybrid_step(gh_ctx *gas, gh_nbody *stars, int nsteps, double *t, double *timestep);
+/* ... and its PostInitialConditionsSetup (SphSimulation.cpp:204-565): gas after gh_upload_particles, stars after
+ * gh_nbody_upload; leaves both contexts in the post-setup state and returns the first timestep */
+int gh_hybrid_setup(gh_ctx *gas, gh_nbody *stars, int initial_h_provided, double *timestep);
 
 
 #ifdef __cplusplus

@@ -1513,6 +1513,12 @@ struct Oracle {
   }
   void DensityPass() { SearchBoundaryGhostParticles(); BuildGhostTree(); UpdateAllSphProperties(); }
   void Setup(int h_provided) {                                       // SphSimulation.cpp:204-565 (see gh_setup)
+    SetupPasses(h_provided);
+    t = 0.0; n = 0; nresync = 0;
+    if (P.Nlevels > 1) ComputeBlockTimesteps(); else ComputeGlobalTimestep();
+    EndTimestep();
+  }
+  void SetupPasses(int h_provided) {                                 // the density / force passes of the setup (:266-473)
     for (int i = 0; i < Nhydro; i++) p[i].flags |= F_ACTIVE;
     const int npass = h_provided ? 2 : 3;
     for (int q = 0; q < npass; q++) { BuildTree(); DensityPass(); }
@@ -1522,9 +1528,6 @@ struct Oracle {
     ZeroAccelerations(); Forces();
     mac_now = P.gravity_mac;
     if (relmac) { BuildTree(); ZeroAccelerations(); Forces(); }
-    t = 0.0; n = 0; nresync = 0;
-    if (P.Nlevels > 1) ComputeBlockTimesteps(); else ComputeGlobalTimestep();
-    EndTimestep();
   }
   void MainLoop() {                                                  // SphSimulation.cpp:574-880
     n++; Nsteps++; t = t + timestep;
@@ -1906,6 +1909,34 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   nb.EndTimestep(0);
   g.rebuild_tree = false;
 }
+// PostInitialConditionsSetup of a hybrid run (SphSimulation.cpp:204-565): the gas passes see the stars, the stars get the
+// gas' tree forces and their own direct sum (:500-514), the first timestep is the minimum over both (:538), both end it
+static void HybridSetup(Oracle &g, NbodyOracle &nb, int h_provided)
+{
+  g.stars.resize(nb.N);
+  g.star_softening = nb.softening;
+  for (int i = 0; i < nb.N; i++) {
+    Star &s = nb.s[i];
+    for (int k = 0; k < 3; k++) { g.stars[i].r[k] = s.r[k]; g.stars[i].a[k] = 0.0; s.r0[k] = s.r[k]; s.v0[k] = s.v[k]; }
+    g.stars[i].m = s.m; g.stars[i].h = s.h; g.stars[i].gpot = 0.0;
+    s.active = true; s.nlast = 0; s.tlast = 0.0; s.nstep = 1;
+  }
+  g.SetupPasses(h_provided);
+  g.t = 0.0; g.n = 0; g.nresync = 0; nb.t = 0.0;
+  nb.Zero();
+  g.UpdateAllStarGasForces();
+  for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) nb.s[i].a[k] = g.stars[i].a[k]; nb.s[i].gpot = g.stars[i].gpot; }
+  nb.Forces();
+  g.ComputeGlobalTimestep();
+  nb.GlobalTimestep();
+  const double ts = std::min(g.timestep, (double) nb.timestep);
+  g.timestep = ts; nb.timestep = ts;
+  for (int i = 0; i < g.Nhydro; i++) g.p[i].dt_next = ts;
+  for (int i = 0; i < nb.N; i++) nb.s[i].dt_next = ts;
+  g.EndTimestep();
+  nb.EndTimestep(0);
+}
+void orc_hybrid_setup(Oracle *g, NbodyOracle *nb, int h_provided) { HybridSetup(*g, *nb, h_provided); }
 void orc_hybrid_step(Oracle *g, NbodyOracle *nb, int nsteps) { for (int s = 0; s < nsteps; s++) HybridMainLoop(*g, *nb); }
 
 void orc_nbody_get(NbodyOracle *o, int field, double *out)

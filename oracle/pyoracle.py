@@ -48,6 +48,7 @@ def lib():
         L.orc_nbody_get.argtypes = [C.c_void_p, C.c_int, _PD]
         L.orc_nbody_set.argtypes = [C.c_void_p, C.c_int, _PD]
         L.orc_hybrid_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_hybrid_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_set_stars.argtypes = [C.c_void_p, C.c_int, _PD, _PD, _PD, C.c_int]
         L.orc_star_gas_forces.argtypes = [C.c_void_p, _PD, _PD]
         _lib = L
@@ -272,6 +273,10 @@ class NbodyOracle:
     def set(self, name, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         self.L.orc_nbody_set(self.o, self.SET_FIELDS[name], arr.ctypes.data_as(_PD))
+
+    def hybrid_setup(self, gas, h_provided=False):
+        """PostInitialConditionsSetup of a hybrid run: `gas` is the Oracle holding the gas IC, self the star IC"""
+        self.L.orc_hybrid_setup(gas.h, self.o, 1 if h_provided else 0)
 
     def hybrid_step(self, gas, n=1):
         """n MainLoop calls of a hybrid run: `gas` is the Oracle holding the gas, self the stars"""

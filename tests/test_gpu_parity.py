@@ -275,3 +275,29 @@ def test_hybrid_steps_match_reference():
     assert np.max(np.abs(nb.download("v") - g["final_star_v"])) < 1e-10*np.abs(g["final_star_v"]).max()
     assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-10
     assert relerr(nb.download("gpot"), g["final_star_gpot"]) < 1e-10
+
+
+def test_hybrid_run_from_ic_matches_reference():
+    """whole hybrid gas + stars run from the IC: gh_hybrid_setup (PostInitialConditionsSetup with stars) and three steps"""
+    from gandalf_amd.capi import NbodyHip
+    from test_oracle import initial_h_guess
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_steps")
+    sim, p = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    h0 = np.full(len(s("m")), initial_h_guess(s("r"), float(p["h_fac"])))
+    sim.upload(s("r"), s("m"), h0, v=s("v"), u=s("u"))
+    nb = NbodyHip(ndim=3, softening=int(p["nbody_softening"]), nbody_mult=float(p["nbody_mult"]))
+    nb.upload(s("star_r"), s("star_v"), s("star_m"), s("star_h"))
+    dt = nb.hybrid_setup(sim, initial_h_provided=False)
+    assert abs(dt - g["setup_t_timestep"][1]) <= 1e-10*dt
+    assert relerr(sim.download("h"), s("h")) < 1e-11 and relerr(sim.download("rho"), s("rho")) < 1e-11
+    assert vec_err(sim.download("a"), s("a")) < 1e-10
+    assert vec_err(nb.download("a"), s("star_a")) < 1e-10 and relerr(nb.download("gpot"), s("star_gpot")) < 1e-10
+    t, dt = nb.hybrid_step(sim, int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert abs(t - tf) <= 1e-11*abs(tf)
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-9
+    assert np.max(np.abs(nb.download("r") - g["final_star_r"])) < 1e-10*np.abs(g["final_star_r"]).max()
+    assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9

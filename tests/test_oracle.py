@@ -210,3 +210,37 @@ def test_restocked_tree_steps_bitwise(case):
     assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
     for k in ["r", "v", "a", "h", "rho", "u", "dudt"]:
         assert np.array_equal(o.get(k), g["final_" + k]), k
+
+
+def initial_h_guess(r, h_fac=1.2, kernrange=2.0):
+    """Sph::InitialSmoothingLengthGuess (Sph.cpp:76-119) in 3-D: one h for all particles from the bounding box; the
+    reference calls powf (single precision), so call the same libm function"""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    pi = 3.14159265358979
+    ext = r.max(axis=0) - r.min(axis=0)
+    volume = float(ext[0])*float(ext[1])*float(ext[2])
+    ngather = int(4.0*pi*(kernrange*h_fac)**3/3.0)
+    return float(libm.powf((3.0*volume*ngather)/(32.0*pi*len(r)), 0.333333333333333333))
+
+
+def test_hybrid_setup_bitwise():
+    """PostInitialConditionsSetup of the hybrid gas + stars run from the IC (positions, velocities, masses, energies of both
+    species; the smoothing lengths start from the reference's bounding-box guess): the post-setup state of gas and stars"""
+    from oracle.pyoracle import NbodyOracle
+    case = "plummer_4k_stars"
+    g = load_golden(case + "_steps")
+    p = read_params_file("%s/%s.dat" % (PARAMS, case))
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    o = Oracle(p, nthreads=4)
+    h0 = np.full(len(s("m")), initial_h_guess(s("r"), float(p["h_fac"])))
+    o.set_particles(s("r"), s("m"), h0, v=s("v"), u=s("u"))
+    nb = NbodyOracle(s("star_r"), s("star_v"), s("star_m"), s("star_h"), int(p["nbody_softening"]), float(p["nbody_mult"]))
+    nb.hybrid_setup(o, h_provided=False)
+    assert o.timestep == g["setup_t_timestep"][1]
+    for k in ["h", "rho", "a", "dudt", "dt"]:
+        assert np.array_equal(o.get(k), s(k)), k
+    for k in ["a", "adot", "gpot", "a0"]:
+        assert np.array_equal(nb.get(k), s("star_" + k)), "star " + k
