@@ -470,7 +470,7 @@ class NbodyHip:
         self._chk(self.lib.gh_nbody_upload(self.ctx, self.N, *[_dp(x) for x in a]))
 
     def download(self, name):
-        out = np.empty(self.N if name == "gpot" else (self.N, self.ndim))
+        out = np.empty(self.N if name in ("gpot", "tlast") else (self.N, self.ndim))
         self._chk(self.lib.gh_nbody_download(self.ctx, self.FIELDS[name], _dp(out)))
         return out
 
