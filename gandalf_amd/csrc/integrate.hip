@@ -4,7 +4,7 @@
 // SphIntegration::Timestep, Simulation::ComputeGlobalTimestep and Sph::ZeroAccelerations
 // (reference src/Hydrodynamics/SphLeapfrogKDK.cpp:76-127, 219-272, src/Common/Integration.cpp,
 //  src/Hydrodynamics/SphIntegration.cpp:81-134, src/Common/Simulation.cpp:1669-1754,
-//  src/Hydrodynamics/Sph.cpp:126-140) for Nlevels = 1 (every particle active every step).
+//  src/Hydrodynamics/Sph.cpp:126-140); global timestep (Nlevels = 1) here, hierarchical block timesteps further down.
 // The simulation time and timestep live in device memory (ctx->d_time) so that a run of steps can be
 // enqueued without a host round trip.
 #include "gh_internal.hpp"
