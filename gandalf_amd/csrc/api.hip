@@ -210,8 +210,6 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (cfg->kernel < GH_KERNEL_M4 || cfg->kernel > GH_KERNEL_QUINTIC_TAB)
     return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic, each with tabulated_kernel = 0 or 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
-  if (cfg->ntreebuildstep > 1 && cfg->ntreestockstep > 1)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "ntreebuildstep > 1 needs ntreestockstep = 1 (ExtrapolateCellProperties is not built)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");
@@ -258,7 +256,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -655,7 +653,8 @@ static int step_tree_timed(gh_ctx *ctx)
   const int ntb = ctx->cfg.ntreebuildstep;
   if (ntb <= 1 || ctx->nranks > 1 || ctx->rebuild_tree || ctx->Nsteps%ntb == 0 || ctx->tree_layout_N != ctx->N) return build_tree_timed(ctx);
   gh_phase_begin(ctx, GH_T_BUILD_TREE);
-  int rc = gh_tree_restock_impl(ctx);
+  // re-stock every ntreestockstep steps, otherwise let the cells drift with their mean velocity (Tree.cpp:172-198)
+  int rc = (ctx->cfg.ntreestockstep <= 1 || ctx->Nsteps%ctx->cfg.ntreestockstep == 0) ? gh_tree_restock_impl(ctx) : gh_tree_extrapolate_impl(ctx);
   gh_phase_end(ctx, GH_T_BUILD_TREE);
   return rc;
 }

@@ -102,6 +102,7 @@ struct gh_ctx {
   CellGeo *cgeo = nullptr;
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
+  double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
   double *leaf_amin = nullptr;
   bool mac_bootstrap = false;      // gh_setup's first force pass of a relative MAC runs geometric (SphSimulation.cpp:381-388)
   double *ktab = nullptr;          // tabulated kernel tables [GH_TAB_COUNT][GH_TAB_RES] (device), or nullptr
@@ -200,6 +201,7 @@ DevicePtrs gh_dev(gh_ctx *ctx);
 int gh_alloc_particles(gh_ctx *ctx, int64_t N);
 int gh_alloc_tree(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx);
+int gh_tree_extrapolate_impl(gh_ctx *ctx);  // Tree::ExtrapolateCellProperties: cells drift with their stocked mean velocity
 int gh_tree_restock_impl(gh_ctx *ctx);   // KDTree::StockTree: same cells and particle order, properties from the current r, h
 int gh_update_hmax_impl(gh_ctx *ctx);
 // the *_impl functions only enqueue work on ctx->stream (no host synchronisation)

@@ -659,6 +659,7 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
+  if (ctx->cfg.ntreestockstep > 1) GH_CHECK(ctx, re((void**) &ctx->cvel, sizeof(double)*3*Ncell));
   if (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.self_gravity) {
     GH_CHECK(ctx, re((void**) &ctx->leaf_amin, sizeof(double)*gtot));
     GH_CHECK(ctx, hipMemsetAsync(ctx->leaf_amin, 0, sizeof(double)*gtot, ctx->stream));
@@ -707,6 +708,7 @@ static int stock_tree(gh_ctx *ctx, int hmax_only)
 
 int gh_update_hmax_impl(gh_ctx *ctx) { return stock_tree(ctx, 1); }
 
+void stock_cell_velocities_fwd(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx)
 {
   int rc = gh_alloc_tree(ctx);
@@ -783,9 +785,68 @@ int gh_tree_build_impl(gh_ctx *ctx)
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
   ctx->cur ^= 1;
   stock_tree(ctx, 0);
+  stock_cell_velocities_fwd(ctx);
   gh_pack_posm(ctx);
   GH_CHECK(ctx, hipGetLastError());
   ctx->tree_valid = true;
+  return GH_OK;
+}
+
+// ---- cell mean velocities + Tree::ExtrapolateCellProperties (Tree.cpp:172-198), ntreestockstep > 1 only ----------------
+// leaf: v = sum m_i v_i / m (KDTree.cpp stocking of leaf cells); parent: (m1 v1 + m2 v2)/m
+__global__ void k_cellv_leaf(DevicePtrs d, double *cvel)
+{
+  const int l = blockIdx.x*blockDim.x + threadIdx.x;
+  if (l >= d.gtot) return;
+  const int n = d.gtot - 1 + l;
+  const int first = d.cfirst[n], cn = d.cN[n];
+  double m = 0.0, v[3] = {0.0, 0.0, 0.0};
+  for (int t = 0; t < cn; t++) {
+    const double mi = d.f[D_M][first + t];
+    m += mi;
+    for (int k = 0; k < d.ndim; k++) v[k] += mi*d.f[D_VX + k][first + t];
+  }
+  for (int k = 0; k < 3; k++) cvel[(size_t) 3*n + k] = m > 0.0 ? v[k]/m : 0.0;
+}
+__global__ void k_cellv_level(DevicePtrs d, double *cvel, int level)
+{
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= (1 << level)) return;
+  const int n = (1 << level) - 1 + j, c1 = 2*n + 1, c2 = 2*n + 2;
+  const double m1 = d.ccom[c1].m, m2 = d.ccom[c2].m, m = d.ccom[n].m;
+  for (int k = 0; k < 3; k++)
+    cvel[(size_t) 3*n + k] = m > 0.0 ? (m1*cvel[(size_t) 3*c1 + k] + m2*cvel[(size_t) 3*c2 + k])/m : 0.0;
+}
+__global__ void k_extrapolate_cells(DevicePtrs d, const double *cvel, const double *time, int Ncell)
+{
+  const int n = blockIdx.x*blockDim.x + threadIdx.x;
+  if (n >= Ncell) return;
+  const double dt = time[1];
+  for (int k = 0; k < d.ndim; k++) {
+    const double dx = cvel[(size_t) 3*n + k]*dt;
+    d.cbox[n].bbmin[k] += dx; d.cbox[n].bbmax[k] += dx;
+    d.ch[n].hbmin[k] += dx; d.ch[n].hbmax[k] += dx;
+    d.cgeo[n].rcell[k] += dx;
+    d.ccom[n].com[k] += dx;
+  }
+}
+void stock_cell_velocities_fwd(gh_ctx *ctx) ;
+static void stock_cell_velocities(gh_ctx *ctx)
+{
+  if (ctx->cfg.ntreestockstep <= 1 || !ctx->cvel) return;
+  DevicePtrs d = gh_dev(ctx);
+  hipLaunchKernelGGL(k_cellv_leaf, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, d, ctx->cvel);
+  for (int l = ctx->ltot - 1; l >= 0; l--)
+    hipLaunchKernelGGL(k_cellv_level, dim3(cdiv(1 << l, 256)), dim3(256), 0, ctx->stream, d, ctx->cvel, l);
+}
+void stock_cell_velocities_fwd(gh_ctx *ctx) { stock_cell_velocities(ctx); }
+extern double *gh_time_dev(gh_ctx *ctx);
+int gh_tree_extrapolate_impl(gh_ctx *ctx)
+{
+  if (!ctx->tree_valid || !ctx->cvel) return gh_tree_build_impl(ctx);
+  hipLaunchKernelGGL(k_extrapolate_cells, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->cvel, gh_time_dev(ctx), ctx->Ncell);
+  gh_pack_posm(ctx);
+  GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
 
@@ -793,6 +854,7 @@ int gh_tree_restock_impl(gh_ctx *ctx)
 {
   if (!ctx->tree_valid && ctx->tree_layout_N != ctx->N) return gh_tree_build_impl(ctx);
   stock_tree(ctx, 0);
+  stock_cell_velocities(ctx);
   gh_pack_posm(ctx);
   GH_CHECK(ctx, hipGetLastError());
   ctx->tree_valid = true;

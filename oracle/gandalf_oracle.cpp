@@ -60,7 +60,7 @@ struct Params {
   FLOAT macerror, alpha_visc_min;
   int Nlevels, level_diff_max, sph_single_timestep;   // block timesteps (Simulation.cpp:1209-1223)
   int gas_eos; FLOAT temp0, mu_bar, rho_bary;          // 0 energy_eqn, 1 isothermal, 2 barotropic
-  int ntreebuildstep;
+  int ntreebuildstep, ntreestockstep;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
 };
@@ -595,7 +595,15 @@ struct Oracle {
     // first step after the setup always rebuilds
     if (P.ntreebuildstep <= 1 || Nsteps%P.ntreebuildstep == 0 || rebuild_tree) { BuildTree(); return; }
     p.resize(Nhydro); Nghost = 0;
-    tree.StockTree(tree.cell[0], p);
+    if (Nsteps%P.ntreestockstep == 0) { tree.StockTree(tree.cell[0], p); return; }
+    // Tree::ExtrapolateCellProperties, Tree.cpp:172-198: cells drift with their stocked mean velocity
+    for (int c = 0; c < tree.Ncell; c++) {
+      Cell &x = tree.cell[c];
+      for (int k = 0; k < P.ndim; k++) {
+        const FLOAT dx = x.v[k]*timestep;
+        x.r[k] += dx; x.rcell[k] += dx; x.bbmin[k] += dx; x.bbmax[k] += dx; x.hbmin[k] += dx; x.hbmax[k] += dx;
+      }
+    }
   }
   void BuildGhostTree() { ghosttree.BuildTree(Nhydro, Nghost, p); }
 
@@ -1684,7 +1692,7 @@ struct NbodyOracle {
 extern "C" {
 
 struct orc_params {
-  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep, gas_eos, ntreebuildstep;
+  int32_t ndim, Nleafmax, self_gravity, periodic[3], energy_integration, nthreads, kernel, multipole, acond, gravity_mac, tdavisc, Nlevels, level_diff_max, sph_single_timestep, gas_eos, ntreebuildstep, ntreestockstep, pad3_;
   double boxmin[3], boxmax[3], h_fac, h_converge, alpha_visc, beta_visc, gamma_eos, thetamaxsqd, courant_mult, accel_mult, energy_mult, macerror, alpha_visc_min, temp0, mu_bar, rho_bary;
 };
 
@@ -1694,7 +1702,7 @@ Oracle *orc_create(const orc_params *q)
   P.ndim = q->ndim; P.Nleafmax = q->Nleafmax; P.self_gravity = q->self_gravity; P.energy_integration = q->energy_integration;
   P.nthreads = q->nthreads > 0 ? q->nthreads : 1;
   P.kernel = q->kernel; P.multipole = q->multipole; P.acond = q->acond; P.gravity_mac = q->gravity_mac; P.macerror = q->macerror; P.tdavisc = q->tdavisc; P.alpha_visc_min = q->alpha_visc_min;
-  P.ntreebuildstep = q->ntreebuildstep > 1 ? q->ntreebuildstep : 1;
+  P.ntreebuildstep = q->ntreebuildstep > 1 ? q->ntreebuildstep : 1; P.ntreestockstep = q->ntreestockstep > 1 ? q->ntreestockstep : 1;
   P.gas_eos = q->gas_eos; P.temp0 = q->temp0; P.mu_bar = q->mu_bar; P.rho_bary = q->rho_bary;
   P.Nlevels = q->Nlevels > 1 ? q->Nlevels : 1; P.level_diff_max = q->level_diff_max; P.sph_single_timestep = q->sph_single_timestep;
   for (int k = 0; k < 3; k++) {

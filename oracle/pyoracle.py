@@ -15,7 +15,7 @@ class OrcParams(C.Structure):
                 ("energy_integration", C.c_int32), ("nthreads", C.c_int32),
                 ("kernel", C.c_int32), ("multipole", C.c_int32), ("acond", C.c_int32), ("gravity_mac", C.c_int32), ("tdavisc", C.c_int32),
                 ("Nlevels", C.c_int32), ("level_diff_max", C.c_int32), ("sph_single_timestep", C.c_int32),
-                ("gas_eos", C.c_int32), ("ntreebuildstep", C.c_int32),
+                ("gas_eos", C.c_int32), ("ntreebuildstep", C.c_int32), ("ntreestockstep", C.c_int32), ("pad3_", C.c_int32),
                 ("boxmin", C.c_double*3), ("boxmax", C.c_double*3), ("h_fac", C.c_double), ("h_converge", C.c_double),
                 ("alpha_visc", C.c_double), ("beta_visc", C.c_double), ("gamma_eos", C.c_double), ("thetamaxsqd", C.c_double),
                 ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double), ("macerror", C.c_double), ("alpha_visc_min", C.c_double),
@@ -94,7 +94,7 @@ class Oracle:
         q.gas_eos = {"energy_eqn": 0, "isothermal": 1, "barotropic": 2}[p.get("gas_eos", "energy_eqn")]
         q.temp0 = float(p.get("temp0", 1.0)); q.mu_bar = float(p.get("mu_bar", 1.0)); q.rho_bary = float(p.get("rho_bary", 1.0e-14))
         q.ntreebuildstep = int(p.get("ntreebuildstep", 1))
-        assert q.ntreebuildstep == 1 or int(p.get("ntreestockstep", 1)) == 1
+        q.ntreestockstep = int(p.get("ntreestockstep", 1))
         q.Nlevels = int(p.get("Nlevels", 1)); q.level_diff_max = int(p.get("level_diff_max", 1))
         q.sph_single_timestep = int(p.get("sph_single_timestep", 0))
         self.L, self.ndim, self.N = L, q.ndim, 0

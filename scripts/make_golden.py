@@ -37,7 +37,7 @@ def run(args, cwd):
     subprocess.run([REF] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, env=env)
 
 
-NSTEPS = {"plummer_4k_tb4": 10, "box3d_4k_tb4": 10, "adsod_1d": 20, "adsod_1d_wadsley2008": 20, "adsod_1d_price2008": 20, "adsod_1d_mm97": 20, "adsod_mirror": 20}
+NSTEPS = {"plummer_4k_ts3": 10, "plummer_4k_tb4": 10, "box3d_4k_tb4": 10, "adsod_1d": 20, "adsod_1d_wadsley2008": 20, "adsod_1d_price2008": 20, "adsod_1d_mm97": 20, "adsod_mirror": 20}
 
 
 def passes(name, nsteps=None):

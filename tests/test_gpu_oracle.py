@@ -162,7 +162,7 @@ def test_run_from_reference_snapshot(tmp_path):
     assert np.array_equal(f["rho"], dev.download("rho")) and np.array_equal(f["r"].ravel(), dev.download("r").ravel())
 
 
-@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4"])
+@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4", "plummer_4k_ts3"])
 def test_restocked_tree_runs_match_reference(case):
     """ntreebuildstep = 4: from the IC through the setup and ten steps - the tree is rebuilt on steps 1, 4, 8 and re-stocked
     (same cells, properties from the moved particles) on the others, as HydroTree::BuildTree does"""

@@ -193,7 +193,7 @@ def test_hybrid_steps_bitwise():
         assert np.array_equal(nb.get(k), g["final_star_" + k]), "star " + k
 
 
-@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4"])
+@pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4", "plummer_4k_ts3"])
 def test_restocked_tree_steps_bitwise(case):
     """ntreebuildstep = 4, ntreestockstep = 1, from the IC: setup, then ten MainLoop calls of which steps 4 and 8 rebuild
     the tree and the others re-stock the existing one (HydroTree::BuildTree, HydroTree.cpp:325-343; KDTree::StockTree).
