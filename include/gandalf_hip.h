@@ -72,7 +72,8 @@ typedef struct gh_config {
   int32_t ntreebuildstep;  /* ntreebuildstep: the tree is rebuilt every ntreebuildstep steps (and on the first step after the setup) and
                             * re-stocked in between (HydroTree::BuildTree, HydroTree.cpp:325-343); <= 1: rebuilt every step */
   int32_t ntreestockstep;  /* ntreestockstep: between rebuilds the tree is re-stocked every ntreestockstep steps and its cells drift with
-                            * their mean velocity on the others (Tree::ExtrapolateCellProperties, Tree.cpp:172-198) */
+                            * their mean velocity on the others (Tree::ExtrapolateCellProperties, Tree.cpp:172-198; faithful while
+                            * no particle has left its cell's drifted box) */
   int32_t sph_single_timestep; /* sph_single_timestep: with Nlevels > 1 all gas particles share the highest occupied level (Simulation.cpp:1890-1900, 2090-2096) */
   int32_t reserved_;
   double  boxmin[3];       /* boxmin[k] */

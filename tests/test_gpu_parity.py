@@ -185,7 +185,8 @@ def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):
     assert relerr(sim.download("gpot"), g["force_gpot"]) < 1e-11
 
 
-LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single"]
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single",
+               "adsod_1d_combo_levels", "plummer_4k_combo_levels"]   # combinations with cd2010, conductivity, re-stock / extrapolation, fast_quadrupole, gadget2
 
 
 @pytest.mark.parametrize("case", LEVEL_CASES)
@@ -197,7 +198,7 @@ def test_block_timesteps_match_reference(case):
     s = lambda k: g["setup_" + k]  # noqa: E731
     sim.upload(s("r"), s("m"), s("h"), v=s("v"), u=s("u"))
     for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt", "tlast", "dt_next", "div_v",
-              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot",
+              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot", "atree",
               "level", "levelneib", "nstep", "nlast"]:
         sim.upload_field(k, np.asarray(s(k), dtype=np.float64))
     sim.upload_field("flags", np.zeros(len(s("m"))))

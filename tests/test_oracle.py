@@ -113,14 +113,15 @@ def test_config1_full_run_bitwise():
         assert np.array_equal(o.get(k), g["final_" + k]), k
 
 
-LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single"]
+LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single",
+               "adsod_1d_combo_levels", "plummer_4k_combo_levels"]   # combos: + cd2010 / price2008 / re-stock + extrapolate; + fast_quadrupole / gadget2 / re-stock
 
 
 def upload_block_state(o, g, pre):
     """particle + clock state of a block-timestep run (Nlevels > 1) from a fixture"""
     s = lambda k: g[pre + k]  # noqa: E731
     for k in ["a", "r0", "v0", "a0", "u0", "dudt", "dudt0", "rho", "dt", "tlast", "dt_next", "div_v",
-              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot"]:
+              "pressure", "sound", "hfactor", "invomega", "zeta", "hrangesqd", "alpha", "dalphadt", "gpot", "atree"]:
         o.set(k, s(k))         # inactive particles keep these from their last density / force pass
     for k in ["level", "levelneib", "nstep", "nlast"]:
         o.set_int(k, s(k))
