@@ -14,6 +14,12 @@ PARAMS = os.path.join(ROOT, "tests", "params")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built libraries (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
+    libs = [os.path.join(ROOT, "gandalf_amd", "csrc", "libgandalf_hip.so"), os.path.join(ROOT, "gandalf_amd", "host", "libgandalf_host.so"),
+            os.path.join(ROOT, "oracle", "libgandalf_oracle.so")]
+    if not all(os.path.exists(f) for f in libs):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def load_golden(name):
