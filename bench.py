@@ -70,6 +70,19 @@ def cpu_baseline(workload, verbose=False):
                       "whole run incl. setup %.0f s)" % (shape, n, steps, warm, wall)}
 
 
+def spawn_ranks(n, argv):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` as a child process
+    (this process never initialises the GPU; nothing is exec'ed)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,10 +90,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="plummer1m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--simulate-world", type=int, default=0,
-                    help="estimate only (not a measurement of N GPUs): run rank 0 of a W-rank job on one GPU with the "
-                         "collectives skipped, to time the per-rank compute + pack/unpack of the sharded step")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as plain `python bench.py --gpus N`: start N ranks (one per GPU) as FRESH child processes
+        # before this process has touched the GPU, relay rank 0's JSON line and exit with the children's code
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -88,10 +103,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GH_BENCH_BACKEND=gloo: functional rehearsal of the N-rank path on a box with ONE GPU (all ranks share device 0, the
+    # collectives go through host memory) - never a measurement
+    backend = os.environ.get("GH_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
 
     from gandalf_amd.host import Simulation
@@ -102,10 +124,7 @@ def main():
     sim.set_param("device", local_rank)
     ic = sim.generate_ic()
     N = ic["r"].shape[0]
-    if args.simulate_world > 1 and world == 1:
-        runner = multigpu.ShardedRunner(sim, 0, args.simulate_world, simulate=True)
-    else:
-        runner = multigpu.ShardedRunner(sim, rank, world)       # world == 1: plain single-GPU stepping
+    runner = multigpu.DistributedRunner(sim, rank, world)       # world == 1: plain single-GPU stepping
     runner.setup()
 
     def sync():
@@ -123,7 +142,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     timers, dst, fst = dev.timers()
@@ -173,16 +192,15 @@ def main():
             "ms_per_step": 1e3*elapsed/args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["desc"], "N": N, "ic": "reference xorshift RNG seed 1 (bit-exact IC generators)",
-                       "parallelism": "work-sharded x%d, particles+tree replicated" % world if world > 1 else "single GPU"},
+                       "parallelism": ("domain-decomposed x%d: rank r owns top-level KD cell r, halo + multipole exchange over RCCL" % world) if world > 1 else "single GPU"},
             "roofline": dominant,
             "roofline_density": r_d,
             "roofline_forces": r_f,
             "phase_ms_per_step": {k: v/args.steps for k, v in timers.items()},
             "counters": {"density": dens, "forces": forc},
         }
-        if args.simulate_world > 1 and world == 1:
-            out["simulated_world"] = args.simulate_world
-            out["note"] = "ESTIMATE: rank 0 of a %d-rank job on one GPU, collectives skipped - not a measurement" % args.simulate_world
+        if world > 1 and backend != "nccl":
+            out["note"] = "REHEARSAL: %d ranks sharing one GPU over gloo - not a measurement" % world
         cb = None if (args.no_cpu or world > 1) else cpu_baseline(args.workload)
         out["cpu_baseline"] = cb
         print(json.dumps(out))

@@ -84,18 +84,13 @@ SYMBOLS = {
     "gh_gather_neighbours": (C.c_int, [_CTX, C.c_int64, _PL, _PI]),
     "gh_get_timers": (C.c_int, [_CTX, _PD, C.POINTER(Stats), C.POINTER(Stats)]),
     "gh_reset_timers": (C.c_int, [_CTX]),
-    "gh_set_shard": (C.c_int, [_CTX, C.c_int, C.c_int]),
-    "gh_shard_range": (C.c_int, [_CTX, C.c_int, _PL, _PL]),
+    "gh_comm_init": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_void_p]),
+    "gh_exchange_halo": (C.c_int, [_CTX, C.c_int]),
+    "gh_allgather_multipoles": (C.c_int, [_CTX]),
+    "gh_comm_info": (C.c_int, [_CTX, _PL, _PL, _PL]),
     "gh_field_dev": (C.c_void_p, [_CTX, C.c_int, C.c_int]),
-    "gh_exchange_narrays": (C.c_int, [_CTX, C.c_int]),
-    "gh_shard_pack": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_int64]),
-    "gh_shard_unpack": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
-    "gh_shard_unpack_all": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_int64]),
     "gh_stream": (C.c_void_p, [_CTX]),
     "gh_update_hmax": (C.c_int, [_CTX]),
-    "gh_step_begin": (C.c_int, [_CTX]),
-    "gh_step_forces": (C.c_int, [_CTX]),
-    "gh_step_end": (C.c_int, [_CTX, _PD, _PD]),
     "gh_nbody_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(_CTX)]),
     "gh_nbody_destroy": (None, [_CTX]),
     "gh_nbody_last_error": (C.c_char_p, [_CTX]),
@@ -150,7 +145,7 @@ def config_from_params(p, device=0):
     nd = int(p.get("ndim", 3))
     c.ndim = nd
     c.kernel = _ENUMS["kernel"][p.get("kernel", "m4")]
-    if int(p.get("tabulated_kernel", 0)) != 0:
+    if int(p.get("tabulated_kernel", 1)) != 0:          # the reference's default is 1 (Parameters.cpp:254)
         c.kernel = 3 if p.get("kernel", "m4") == "quintic" else 2     # GH_KERNEL_QUINTIC_TAB / GH_KERNEL_M4_TAB
     c.gas_eos = _ENUMS["gas_eos"][p.get("gas_eos", "energy_eqn")]
     c.avisc = _ENUMS["avisc"][p.get("avisc", "mon97")]
@@ -264,7 +259,7 @@ class GandalfHip:
     def download(self, name):
         n = self.N
         shape = (n, self.ndim) if name in VECTOR_FIELDS else (n,)
-        out = np.empty(shape, dtype=np.float64)
+        out = np.full(shape, np.nan, dtype=np.float64)      # multi-GPU: only this rank's own particles are written
         self._chk(self.lib.gh_download(self.ctx, FIELDS[name], _dp(out)))
         return out
 
@@ -390,27 +385,21 @@ class GandalfHip:
     def reset_timers(self):
         self._chk(self.lib.gh_reset_timers(self.ctx))
 
-    def set_shard(self, rank, nranks):
-        self._chk(self.lib.gh_set_shard(self.ctx, rank, nranks))
+    def comm_init(self, rank, nranks, ops_ptr):
+        """gh_comm_init: ops_ptr = address of a gh_comm_ops (multigpu.CommOps), or None for a single rank"""
+        self._chk(self.lib.gh_comm_init(self.ctx, rank, nranks, ops_ptr))
 
-    def shard_range(self, rank):
-        a, b = C.c_int64(), C.c_int64()
-        self._chk(self.lib.gh_shard_range(self.ctx, rank, C.byref(a), C.byref(b)))
-        return a.value, b.value
+    def exchange_halo(self, phase):
+        self._chk(self.lib.gh_exchange_halo(self.ctx, phase))
 
-    X_DENSITY, X_FORCES = 0, 1
+    def allgather_multipoles(self):
+        self._chk(self.lib.gh_allgather_multipoles(self.ctx))
 
-    def exchange_narrays(self, xset):
-        return int(self.lib.gh_exchange_narrays(self.ctx, xset))
-
-    def shard_pack(self, xset, dst_ptr, stride):
-        self._chk(self.lib.gh_shard_pack(self.ctx, xset, C.c_void_p(dst_ptr), stride))
-
-    def shard_unpack(self, xset, rank, src_ptr, stride):
-        self._chk(self.lib.gh_shard_unpack(self.ctx, xset, rank, C.c_void_p(src_ptr), stride))
-
-    def shard_unpack_all(self, xset, src_ptr, stride):
-        self._chk(self.lib.gh_shard_unpack_all(self.ctx, xset, C.c_void_p(src_ptr), int(stride)))
+    def comm_info(self):
+        """(own_first, own_count, held): this rank's range of the global tree order; particles held = own + imported"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.gh_comm_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def stream_handle(self):
         """hipStream_t of the context as an integer (for torch.cuda.ExternalStream)"""
@@ -418,17 +407,6 @@ class GandalfHip:
 
     def update_hmax(self):
         self._chk(self.lib.gh_update_hmax(self.ctx))
-
-    def step_begin(self):
-        self._chk(self.lib.gh_step_begin(self.ctx))
-
-    def step_forces(self):
-        self._chk(self.lib.gh_step_forces(self.ctx))
-
-    def step_end(self):
-        t, dt = C.c_double(), C.c_double()
-        self._chk(self.lib.gh_step_end(self.ctx, C.byref(t), C.byref(dt)))
-        return t.value, dt.value
 
     def field_dev(self, name, k=0):
         return self.lib.gh_field_dev(self.ctx, FIELDS[name], k)

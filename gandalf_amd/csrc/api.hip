@@ -71,6 +71,8 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
     if (flags & FLAG_LEAFLIST_OVERFLOW) m += " candidate list overflow";
     if (flags & FLAG_ILIST_OVERFLOW) m += " interaction list overflow";
     if (flags & FLAG_H_NOT_CONVERGED) m += " h-rho iteration did not converge (GradhSph.cpp:249)";
+    if (flags & FLAG_LET_MISS) m += " multi-GPU: a tree walk left the imported halo (smoothing lengths grew past the exchange margin)";
+    if (flags & FLAG_DD_SPLIT) m += " multi-GPU: top-level median split unresolved (more equal coordinates than the candidate buffer holds)";
     ctx->err = m;
     return (flags & FLAG_H_NOT_CONVERGED) && !(flags & ~FLAG_H_NOT_CONVERGED) ? GH_ERR_NOTCONVERGED : GH_ERR_CAPACITY;
   }
@@ -249,14 +251,16 @@ static void free_particles(gh_ctx *ctx)
   for (void *p : ptrs) if (p) (void) hipFree(p);
   ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
   ctx->iota_N = -1;
+  ctx->Ncap = 0; ctx->N = 0; ctx->tree_layout_N = -1; ctx->tree_valid = false;
 }
 
 extern "C" void gh_destroy(gh_ctx *ctx)
 {
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+  gh_dd_free(ctx);
   free_particles(ctx);
-  void *ptrs[] = {ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -315,14 +319,19 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   if (N >= (1ll << 31)) return gh_fail(ctx, GH_ERR_INVALID, "N too large");
   int rc = gh_alloc_particles(ctx, N);
   if (rc) return rc;
+  if ((rc = gh_alloc_tree(ctx))) return rc;              // fixes this rank's own particle range
   ctx->cur = 0;
   const int nd = ctx->ndim;
   const size_t n = (size_t) N;
-  std::vector<double> tmp(n);
+  // multi-GPU: the caller passes the whole initial condition on every rank; this rank keeps positions
+  // [own_first, own_first + own_count) of it (any split will do - the first tree build migrates every particle to the
+  // rank that owns its cell).  Nothing else is uploaded.
+  const size_t o0 = (size_t) ctx->own_first, on = (size_t) ctx->own_count;
+  std::vector<double> tmp(on);
   auto put = [&](int comp, const double *src, int stride, int off, double fill) -> int {
-    if (src) for (size_t i = 0; i < n; i++) tmp[i] = src[i*stride + off];
+    if (src) for (size_t i = 0; i < on; i++) tmp[i] = src[(o0 + i)*stride + off];
     else std::fill(tmp.begin(), tmp.end(), fill);
-    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[0][comp], tmp.data(), sizeof(double)*n, hipMemcpyHostToDevice));
+    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[0][comp] + o0, tmp.data(), sizeof(double)*on, hipMemcpyHostToDevice));
     return GH_OK;
   };
   for (int f = 0; f < D_COUNT; f++) GH_CHECK(ctx, hipMemset(ctx->fbuf[0][f], 0, sizeof(double)*n));
@@ -368,11 +377,12 @@ extern "C" int gh_download(gh_ctx *ctx, int field, double *dst)
   std::vector<int> ids;
   int rc = fetch_iorig(ctx, ids);
   if (rc) return rc;
-  const size_t n = (size_t) ctx->N;
+  // multi-GPU: only this rank's own particles are written (the caller merges the ranks' arrays)
+  const size_t o0 = (size_t) ctx->own_first, n = (size_t) ctx->own_count;
   std::vector<double> tmp(n);
   for (int k = 0; k < nc; k++) {
-    GH_CHECK(ctx, hipMemcpy(tmp.data(), ctx->fbuf[ctx->cur][first + k], sizeof(double)*n, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; i++) dst[(size_t) ids[i]*nc + k] = tmp[i];
+    GH_CHECK(ctx, hipMemcpy(tmp.data(), ctx->fbuf[ctx->cur][first + k] + o0, sizeof(double)*n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) dst[(size_t) ids[o0 + i]*nc + k] = tmp[i];
   }
   return GH_OK;
 }
@@ -385,11 +395,11 @@ extern "C" int gh_upload_field(gh_ctx *ctx, int field, const double *src)
   std::vector<int> ids;
   int rc = fetch_iorig(ctx, ids);
   if (rc) return rc;
-  const size_t n = (size_t) ctx->N;
+  const size_t o0 = (size_t) ctx->own_first, n = (size_t) ctx->own_count;
   std::vector<double> tmp(n);
   for (int k = 0; k < nc; k++) {
-    for (size_t i = 0; i < n; i++) tmp[i] = src[(size_t) ids[i]*nc + k];
-    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[ctx->cur][first + k], tmp.data(), sizeof(double)*n, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < n; i++) tmp[i] = src[(size_t) ids[o0 + i]*nc + k];
+    GH_CHECK(ctx, hipMemcpy(ctx->fbuf[ctx->cur][first + k] + o0, tmp.data(), sizeof(double)*n, hipMemcpyHostToDevice));
   }
   if (field == GH_F_R || field == GH_F_M) gh_pack_posm(ctx);
   return GH_OK;
@@ -468,14 +478,13 @@ extern "C" int gh_export_tree(gh_ctx *ctx, int32_t *cell_level, int32_t *cell_fi
 // ------------------------------------------------------------------------------------------------
 static int density_and_hmax(gh_ctx *ctx, bool count)
 {
-  int rc = gh_density_impl(ctx, count);
+  int rc = gh_dd_exchange(ctx, GH_HALO_DENSITY);         // multi-GPU: import the gather halo (cells + positions)
   if (rc) return rc;
+  if ((rc = gh_density_impl(ctx, count))) return rc;
   gh_zeta_stars_impl(ctx);                              // hybrid runs: star term of zeta (GradhSph.cpp:288-307)
   if (ctx->cfg.avisc == GH_AVISC_MON97CD2010) {         // Cullen & Dehnen switch at the end of ComputeH (GradhSph.cpp:319-321)
-    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "time_dependent_avisc = cd2010 runs on one rank");
     if ((rc = gh_cullen_dehnen_impl(ctx))) return rc;
   }
-  if (ctx->nranks > 1) return GH_OK;                    // h of the other slices arrives with the exchange
   return gh_update_hmax_impl(ctx);                      // tree->UpdateAllHmaxValues, GradhSphTree.cpp:268
 }
 
@@ -683,7 +692,6 @@ extern "C" int gh_setup(gh_ctx *ctx, int initial_h_provided, double *timestep)
   ctx->timestep = 0.0; ctx->n = 0;
   if ((rc = push_time(ctx))) return rc;
   if (ctx->cfg.Nlevels > 1) {
-    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
     ctx->nresync = 0;
     if ((rc = push_block(ctx))) return rc;
     gh_block_timesteps_impl(ctx);                        // ComputeBlockTimesteps (:539): n == nresync == 0, resynchronise
@@ -770,7 +778,6 @@ extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
   if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
   int rc;
   if (ctx->cfg.Nlevels > 1) {
-    if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "block timesteps (Nlevels > 1) run on one rank");
     for (int s = 0; s < nsteps; s++) if ((rc = block_step(ctx))) return rc;
     if ((rc = pull_time(ctx))) return rc;
     if (t) *t = ctx->t;
@@ -821,134 +828,6 @@ extern "C" int gh_reset_timers(gh_ctx *ctx)
   return GH_OK;
 }
 
-extern "C" int gh_set_shard(gh_ctx *ctx, int rank, int nranks)
-{
-  if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return GH_ERR_INVALID;
-  ctx->rank = rank; ctx->nranks = nranks;
-  return GH_OK;
-}
-
-extern "C" int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count)
-{
-  if (!ctx || !ctx->tree_valid || rank < 0 || rank >= ctx->nranks) return GH_ERR_INVALID;
-  int g0, g1;
-  gh_shard_groups(ctx, rank, g0, g1);
-  const int base = (1 << ctx->lgroup) - 1;
-  const int64_t f = g0 < ctx->ngroups ? ctx->h_cfirst[base + g0] : ctx->N;
-  const int64_t e = g1 < ctx->ngroups ? ctx->h_cfirst[base + g1] : ctx->N;
-  if (first) *first = f;
-  if (count) *count = e - f;
-  return GH_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// multi-GPU: slices, exchange sets, step sections
-// ------------------------------------------------------------------------------------------------
-void gh_derive_after_unpack(gh_ctx *ctx, int set, int64_t first, int64_t count);
-
-static int exchange_list(gh_ctx *ctx, int set, int *out)
-{
-  int n = 0;
-  if (set == GH_X_DENSITY) {
-    // hfactor, hrangesqd, u, sound, pressure, div_v are functions of these four (and of u, which the
-    // density pass only rewrites for a non-adiabatic EOS): the receiver recomputes them (k_derive_density)
-    const int l[] = {D_H, D_RHO, D_INVOMEGA, D_ZETA};
-    for (int v : l) out[n++] = v;
-  }
-  else if (set == GH_X_FORCES) {
-    for (int k = 0; k < ctx->ndim; k++) out[n++] = D_AX + k;
-    for (int k = 0; k < ctx->ndim; k++) out[n++] = D_ATX + k;
-    const int l[] = {D_GPOT, D_DUDT, D_DIV_V};            // gpot_hydro = gpot without stars: copied locally
-    for (int v : l) out[n++] = v;
-  }
-  return n;
-}
-
-extern "C" int gh_exchange_narrays(gh_ctx *ctx, int set)
-{
-  if (!ctx) return 0;
-  int l[16];
-  return exchange_list(ctx, set, l);
-}
-
-// pack / unpack kernels: one launch moves every array of the set (and, for unpack, every remote rank's slice);
-// everything is enqueued on the context's stream - the caller orders its collective after / before it
-struct ShardTab { double *fld[16]; long long first[GH_MAX_RANKS], count[GH_MAX_RANKS]; int nfld, nranks, self; };
-
-__global__ void k_shard_pack(ShardTab t, double *dst, long long stride)
-{
-  const int a = blockIdx.y;
-  const long long first = t.first[t.self], count = t.count[t.self];
-  for (long long i = blockIdx.x*(long long) blockDim.x + threadIdx.x; i < count; i += (long long) gridDim.x*blockDim.x)
-    dst[(size_t) a*stride + i] = t.fld[a][first + i];
-}
-
-// src layout: [rank][array][stride]
-__global__ void k_shard_unpack(ShardTab t, const double *src, long long stride, int only_rank)
-{
-  const int a = blockIdx.y;
-  for (int r = 0; r < t.nranks; r++) {
-    if (r == t.self || (only_rank >= 0 && r != only_rank)) continue;
-    const long long first = t.first[r], count = t.count[r];
-    const double *s = src + ((size_t) (only_rank >= 0 ? 0 : r)*t.nfld + a)*stride;
-    for (long long i = blockIdx.x*(long long) blockDim.x + threadIdx.x; i < count; i += (long long) gridDim.x*blockDim.x)
-      t.fld[a][first + i] = s[i];
-  }
-}
-
-static int shard_table(gh_ctx *ctx, int set, ShardTab &t, int64_t stride)
-{
-  if (ctx->nranks > GH_MAX_RANKS) return gh_fail(ctx, GH_ERR_INVALID, "more ranks than GH_MAX_RANKS");
-  int l[16];
-  const int n = exchange_list(ctx, set, l);
-  if (n == 0) return gh_fail(ctx, GH_ERR_INVALID, "bad exchange set");
-  t.nfld = n; t.nranks = ctx->nranks; t.self = ctx->rank;
-  for (int a = 0; a < n; a++) t.fld[a] = ctx->fbuf[ctx->cur][l[a]];
-  for (int r = 0; r < ctx->nranks; r++) {
-    int64_t first, count;
-    const int rc = gh_shard_range(ctx, r, &first, &count);
-    if (rc) return gh_fail(ctx, rc, "gh_shard_pack/unpack: no tree or bad rank");
-    if (count > stride) return gh_fail(ctx, GH_ERR_INVALID, "gh_shard_pack/unpack: stride smaller than the slice");
-    t.first[r] = first; t.count[r] = count;
-  }
-  return GH_OK;
-}
-
-extern "C" int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride)
-{
-  if (!ctx || !dst_dev) return GH_ERR_INVALID;
-  ShardTab t;
-  int rc = shard_table(ctx, set, t, stride);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_shard_pack, dim3(256, t.nfld), dim3(256), 0, ctx->stream, t, (double*) dst_dev, (long long) stride);
-  GH_CHECK(ctx, hipGetLastError());
-  return GH_OK;
-}
-
-static int shard_unpack(gh_ctx *ctx, int set, int only_rank, const void *src_dev, int64_t stride)
-{
-  if (!ctx || !src_dev) return GH_ERR_INVALID;
-  ShardTab t;
-  int rc = shard_table(ctx, set, t, stride);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_shard_unpack, dim3(256, t.nfld), dim3(256), 0, ctx->stream, t, (const double*) src_dev, (long long) stride, only_rank);
-  for (int r = 0; r < ctx->nranks; r++)
-    if (r != ctx->rank && (only_rank < 0 || r == only_rank)) gh_derive_after_unpack(ctx, set, t.first[r], t.count[r]);
-  GH_CHECK(ctx, hipGetLastError());
-  return GH_OK;
-}
-
-extern "C" int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride)
-{
-  if (!ctx || rank < 0 || rank >= ctx->nranks) return GH_ERR_INVALID;
-  return shard_unpack(ctx, set, rank, src_dev, stride);
-}
-
-extern "C" int gh_shard_unpack_all(gh_ctx *ctx, int set, const void *src_dev, int64_t stride)
-{
-  return shard_unpack(ctx, set, -1, src_dev, stride);
-}
-
 extern "C" void *gh_stream(gh_ctx *ctx) { return ctx ? (void*) ctx->stream : nullptr; }
 
 extern "C" int gh_update_hmax(gh_ctx *ctx)
@@ -956,46 +835,6 @@ extern "C" int gh_update_hmax(gh_ctx *ctx)
   if (!ctx || !ctx->tree_valid) return GH_ERR_INVALID;
   gh_update_hmax_impl(ctx);
   return gh_sync_collect(ctx, "gh_update_hmax");
-}
-
-extern "C" int gh_step_begin(gh_ctx *ctx)
-{
-  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
-  int rc;
-  ctx->n++; ctx->Nsteps++;
-  gh_advance_time_impl(ctx);
-  gh_phase_begin(ctx, GH_T_KDK);
-  gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);
-  gh_phase_end(ctx, GH_T_KDK);
-  if ((rc = build_tree_timed(ctx))) return rc;
-  if ((rc = density_and_hmax(ctx, false))) return rc;
-  return ctx->nranks > 1 ? GH_OK : gh_sync_collect(ctx, "gh_step_begin");   // multi-rank: flags are read in gh_step_end
-}
-
-extern "C" int gh_step_forces(gh_ctx *ctx)
-{
-  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
-  int rc;
-  if (ctx->nranks > 1) gh_update_hmax_impl(ctx);
-  gh_zero_acc_impl(ctx);
-  if ((rc = forces_impl(ctx))) return rc;
-  return ctx->nranks > 1 ? GH_OK : gh_sync_collect(ctx, "gh_step_forces");
-}
-
-extern "C" int gh_step_end(gh_ctx *ctx, double *t, double *timestep)
-{
-  if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
-  int rc;
-  gh_phase_begin(ctx, GH_T_KDK);
-  gh_timestep_impl(ctx);
-  gh_kdk_end_impl(ctx, 0, 0.0, 0.0);
-  gh_phase_end(ctx, GH_T_KDK);
-  ctx->n = 0;
-  if ((rc = gh_sync_collect(ctx, "gh_step_end"))) return rc;
-  if ((rc = pull_time(ctx))) return rc;
-  if (t) *t = ctx->t;
-  if (timestep) *timestep = ctx->timestep;
-  return GH_OK;
 }
 
 extern "C" void *gh_field_dev(gh_ctx *ctx, int field, int k)
@@ -1086,6 +925,7 @@ extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, 
 {
   if (!ctx || !offsets) return GH_ERR_INVALID;
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_gather_neighbours: no tree");
+  if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "gh_gather_neighbours: single-rank query");
   const size_t n = (size_t) ctx->N;
   long long *d_counts = nullptr, *d_off = nullptr; int *d_ids = nullptr;
   GH_CHECK(ctx, hipMalloc((void**) &d_counts, sizeof(long long)*n));

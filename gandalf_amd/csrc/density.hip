@@ -18,12 +18,17 @@
 #include "gh_internal.hpp"
 #include "sph_kernels.hpp"
 #include "walk.hpp"
+#include <cstdlib>
 
 struct DensityParams {
   Domain dom;
   EosParams eos;
   double h_fac, h_converge;
   const double *ktab; // kernel tables (tabulated_kernel = 1) or nullptr
+  const int *only_if; // fused kernel as the fallback of the split path: per-group flags, process a group only if
+  int only_val;       // only_if[group] == only_val (nullptr: all groups).  Flag values: 1 = list overflow / leaf retry,
+  int *fbout;         // 2 = multi-GPU: the walk reached a cell the halo exchange did not import - nothing is stored for
+  unsigned int *miss_count;   // the group, it is redone after a wider import (gh_density_impl); fbout = the flag array
 #ifdef GH_DEBUG_BLOCKTIME
   double *dbg;        // [ngroups][8] per-group timing / work record (profiling builds only)
 #endif
@@ -32,6 +37,34 @@ struct DensityParams {
 
 #define DB 4      /* candidate tiles per phase-2 batch */
 typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// normalise and store the converged sums of one particle (GradhSph.cpp:262-317)
+template <int ND, class K>
+__device__ __forceinline__ void density_store(const DevicePtrs &d, const DensityParams &P, int i, double mi, double ui,
+                                              double rho, double omg, double zet, double hlo)
+{
+  const double invndim = 1.0/(double) ND;
+  const double h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
+  const double invh1 = 1.0/h;
+  const double hfac1 = powN<ND>(invh1)*invh1;
+  const double deriv = -invndim*h/rho;                                     // h_rho_deriv, Sph.h:264
+  double invomega = 1.0 - deriv*omg;
+  invomega = 1.0/invomega;
+  const double zeta = deriv*zet*invomega;
+  double sound, press;
+  eos_eval(P.eos, rho, ui, sound, press);
+  d.f[D_H][i] = h;
+  d.f[D_RHO][i] = rho;
+  d.f[D_INVOMEGA][i] = invomega;
+  d.f[D_ZETA][i] = zeta;
+  d.f[D_HFACTOR][i] = hfac1;
+  d.f[D_HRANGESQD][i] = K::kernrangesqd*h*h;
+  d.f[D_DIV_V][i] = 0.0;
+  d.f[D_U][i] = ui;
+  d.f[D_SOUND][i] = sound;
+  d.f[D_PRESSURE][i] = press;
+}
+
 
 template <int ND, bool COUNT, int KT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
@@ -45,6 +78,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  if (P.only_if && P.only_if[q] != P.only_val) return;
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
@@ -98,6 +132,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   // reference cull radius of the first try, for the candidate statistic: kernrange*1.05*hmax(leaf)
   const double cullsqd = K::kernrangesqd*hmaxl*hmaxl;
 
+  bool miss = false;
   // ---- h iteration (GradhSph.cpp:184-257); every pass re-walks the tree with the radius it needs
   for (;;) {
     const bool running = !done;
@@ -144,7 +179,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
       const CellBox b = d.cbox[n];
       const int cn = b.N;
-      if (cn == 0) return;
+      if (cn < 0) miss = true;                             // multi-GPU: a remote cell the halo exchange did not import
+      if (cn <= 0) return;
       double sg[3], sh[3];
       code_xform(P.dom, code, sg, sh);
       bool inside = true;
@@ -277,6 +313,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #endif
     walk_dfs_stream(d, L, codes, cls, tile, flags);
     process_batch();
+    if (__any(miss)) {                                     // incomplete sums: store nothing, the host widens the import
+      if (lane == 0) { P.fbout[q] = 2; atomicAdd(P.miss_count, 1u); }
+      return;
+    }
 
     bool failed = false;
     if (running) {
@@ -315,32 +355,362 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     o[7] = d.ch[gnode].hmax;
   }
 #endif
+  if (P.only_if && lane == 0) P.fbout[q] = 0;
   // ---- normalise and store (GradhSph.cpp:262-317)
-  if (act) {
-    h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
-    const double invh1 = 1.0/h;
-    const double hfac1 = powN<ND>(invh1)*invh1;
-    const double deriv = -invndim*h/rho;                                     // h_rho_deriv, Sph.h:264
-    double invomega = 1.0 - deriv*omg;
-    invomega = 1.0/invomega;
-    const double zeta = deriv*zet*invomega;
-    double sound, press;
-    eos_eval(P.eos, rho, ui, sound, press);
-    d.f[D_H][i] = h;
-    d.f[D_RHO][i] = rho;
-    d.f[D_INVOMEGA][i] = invomega;
-    d.f[D_ZETA][i] = zeta;
-    d.f[D_HFACTOR][i] = hfac1;
-    d.f[D_HRANGESQD][i] = K::kernrangesqd*h*h;
-    d.f[D_DIV_V][i] = 0.0;
-    d.f[D_U][i] = ui;
-    d.f[D_SOUND][i] = sound;
-    d.f[D_PRESSURE][i] = press;
-  }
+  if (act) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo);
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0), c = wave_sum_u64(n_retry);
     const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
     if (lane == 0) { atomicAdd(&stats[ST_ITER], a); atomicAdd(&stats[ST_CAND], b); atomicAdd(&stats[ST_RETRY], c); atomicAdd(&stats[ST_PAIRS], t); }
+  }
+}
+
+
+// ================================================================================================
+// Split path: walk once, evaluate from a candidate list in HBM.
+//
+// The fused kernel above is bound by the latency of its serial tree walk (one dependent cell load per pop
+// step, at the 2 waves / SIMD its 256 registers allow).  The split path separates the two jobs:
+//
+//   k_dens_walk : one wavefront per group, nothing but the walk - a stack in LDS, ~50 registers, 8 waves / SIMD,
+//                 so that the walks of 32 groups per CU overlap their latencies.  The search volume is the
+//                 reference's own: every leaf cell of the group searches with kernrange * 1.05 * hmax(leaf)
+//                 (GradhSphTree.cpp:141-170; hmax is the bound ComputeH enforces on every iterate,
+//                 GradhSph.cpp:255).  Candidate particle RANGES (a leaf, or a whole subtree inside the
+//                 search box - contiguous in tree order) go to a per-group list in HBM.
+//   k_dens_eval : one wavefront per group, lane = target particle, no walk: streams the listed ranges through
+//                 the LDS tiles (packed-fp32 cull, fp64 sums over the survivors) once per h iteration - in
+//                 steady state exactly once.
+//
+// A group whose list overflows, or whose h iteration makes the reference redo a leaf cell with hmax * 1.05
+// (a larger search volume than the list covers), is flagged and done by the fused kernel afterwards
+// (device-side decision, no host round trip); the evaluation kernel leaves such a group untouched.
+// ================================================================================================
+struct DensLists {
+  int2 *rl;          // [ngroups][rcap]: (first | image code << GH_NODE_BITS, count)
+  int *rlen;         // [ngroups]
+  int *fb;           // [ngroups]: 1 = the fused kernel redoes this group
+  int rcap;
+};
+
+template <int ND, int KT>
+__global__ __launch_bounds__(64) void k_dens_walk(DevicePtrs d, DensityParams P, DensLists G, int *flags)
+{
+  typedef typename KSel<ND, KT>::type K;
+  __shared__ int s_stack[GH_SCAP];
+  __shared__ double s_lb[16][6], s_lhs[16];
+
+  const int lane = threadIdx.x;
+  const unsigned long long lt = lanemask_lt();
+  const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
+  if (lane == 0) { G.rlen[q] = 0; G.fb[q] = 0; }
+  if (gN == 0) return;
+  const int nleaf = 1 << (d.ltot - d.lgroup);
+  const int leafnode0 = (d.gtot - 1) + q*nleaf;
+  // per leaf: bounding box and search h = 1.05 * hmax(leaf); 0 for leaves without a target particle
+  double hl = 0.0;
+  if (lane < nleaf) {
+    const int ln = leafnode0 + lane;
+    const CellBox lbx = d.cbox[ln];
+    for (int k = 0; k < 3; k++) { s_lb[lane][k] = lbx.bbmin[k]; s_lb[lane][3 + k] = lbx.bbmax[k]; }
+    bool any = lbx.N > 0;
+    if (any && d.levels) {                              // block timesteps: targets are the active particles only
+      any = false;
+      for (int t = 0; t < lbx.N; t++) any = any || ((int) d.f[D_FLAGS][lbx.first + t] & 1);
+    }
+    hl = any ? 1.05*d.ch[ln].hmax : 0.0;
+    s_lhs[lane] = hl;
+  }
+  const double hs = wave_max(hl), hmn = wave_min(hl > 0.0 ? hl : 1e300);
+  if (!(hs > 0.0)) return;
+  const CellBox gb = d.cbox[gnode];
+  double lo[3], hi[3];
+  double extmax = 0.0;
+  for (int k = 0; k < 3; k++) {
+    lo[k] = k < ND ? gb.bbmin[k] - K::kernrange*hs : -1e300;
+    hi[k] = k < ND ? gb.bbmax[k] + K::kernrange*hs : 1e300;
+    if (k < ND) extmax = fmax(extmax, gb.bbmax[k] - gb.bbmin[k]);
+  }
+  // leaf-level culling where the group-level box test would let through far more than the leaves need (see k_density)
+  const bool leafcull = hs > 1.3*hmn || extmax > 4.0*K::kernrange*hmn;
+  const unsigned int codes = image_codes(P.dom, ND, lo, hi);
+  const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
+  int top = 0;
+  for (int c = 0; c < 27; c++) {
+    if (codes & (1u << c)) { if (lane == 0) s_stack[top] = 0 | (c << GH_NODE_BITS); top++; }
+  }
+  __syncthreads();
+  int nout = 0;
+  bool overflow = false, miss = false;
+  int2 *rl = G.rl + (size_t) q*G.rcap;
+  while (top > 0) {
+    const int p = pop_width(top);
+    const int newtop = top - p;
+    bool open = false, emit = false;
+    int n = 0, code = 0, first = 0, cnt = 0;
+    if (lane < p) {
+      const int e = s_stack[top - 1 - lane];
+      n = e & GH_NODE_MASK; code = e >> GH_NODE_BITS;
+      const CellBox b = d.cbox[n];
+      if (b.N < 0) miss = true;                            // multi-GPU: a remote cell the halo exchange did not import
+      if (b.N > 0) {
+        double sg[3], sh[3];
+        code_xform(P.dom, code, sg, sh);
+        bool keep = true, inside = true;
+        double gap2 = 0.0;                                 // squared distance between the two boxes
+        double bmin[3], bmax[3];
+        for (int k = 0; k < ND; k++) {
+          image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin[k], bmax[k]);
+          if (lo[k] > bmax[k] || bmin[k] > hi[k]) keep = false;           // BoxOverlap, InlineFuncs.h:362-390 (inclusive)
+          if (bmin[k] < lo[k] || bmax[k] > hi[k]) inside = false;
+          const double gk = fmax(fmax(bmin[k] - gb.bbmax[k], gb.bbmin[k] - bmax[k]), 0.0);
+          gap2 += gk*gk;
+        }
+        // farther than kernrange*hs from every particle of the group: the reference lists it and sums zeros for it
+        if (gap2 > rs2cut) keep = false;
+        if (keep && leafcull) {
+          bool any = false;
+          for (int l = 0; l < nleaf && !any; l++) {
+            const double hl_ = s_lhs[l];
+            if (hl_ > 0.0) {
+              double g2 = 0.0;
+              for (int k = 0; k < ND; k++) {
+                const double gk = fmax(fmax(bmin[k] - s_lb[l][3 + k], s_lb[l][k] - bmax[k]), 0.0);
+                g2 += gk*gk;
+              }
+              const double rl_ = K::kernrange*hl_;
+              any = g2 <= rl_*rl_*(1.0 + 1e-12);
+            }
+          }
+          keep = any;
+          inside = false;      // whole-subtree emission is a group-box shortcut: descend to the leaves instead
+        }
+        if (keep) {
+          if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = b.N; }
+          else open = true;
+        }
+      }
+    }
+    const unsigned long long om = __ballot(open), em = __ballot(emit);
+    __syncthreads();
+    if (open) {
+      const int pos = newtop + 2*__popcll(om & lt);
+      if (pos + 1 < GH_SCAP) {
+        s_stack[pos] = (2*n + 1) | (code << GH_NODE_BITS);
+        s_stack[pos + 1] = (2*n + 2) | (code << GH_NODE_BITS);
+      }
+    }
+    top = newtop + 2*__popcll(om);
+    if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
+    if (emit) {
+      const int pos = nout + __popcll(em & lt);
+      if (pos < G.rcap) rl[pos] = make_int2(first | (code << GH_NODE_BITS), cnt);
+    }
+    nout += __popcll(em);
+    __syncthreads();
+  }
+  if (nout > G.rcap) overflow = true;
+  const bool anymiss = __any(miss);
+  if (lane == 0) {
+    G.rlen[q] = (overflow || anymiss) ? 0 : nout; G.fb[q] = anymiss ? 2 : (overflow ? 1 : 0);
+    if (anymiss) atomicAdd(P.miss_count, 1u);
+  }
+}
+
+#define GH_DENS_RCAP 512   /* candidate ranges per group held by the split path */
+#define DBE 2     /* candidate tiles per phase-2 batch of the evaluation kernel */
+
+template <int ND, bool COUNT, int KT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
+                                                                                       unsigned long long *stats, int *flags)
+{
+  typedef typename KSel<ND, KT>::type K;
+  __shared__ RangeRing s_ring;
+  __shared__ int s_pre[64];
+  __shared__ double s_x[DBE*64], s_y[DBE*64], s_z[DBE*64], s_m[DBE*64];
+  __shared__ unsigned long long s_mask[DBE][64];
+  __shared__ __attribute__((aligned(8))) float s_fx[64], s_fy[64], s_fz[64];
+
+  const int lane = threadIdx.x;
+  const unsigned long long lt = lanemask_lt();
+  const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int gnode = (1 << d.lgroup) - 1 + q;
+  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
+  if (gN == 0 || G.fb[q]) return;
+  const int nr = G.rlen[q];
+  const bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  if (!__any(act)) return;
+  const int i = gfirst + (act ? lane : 0);
+  const double invndim = 1.0/(double) ND;
+  double ri[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < ND; k++) ri[k] = d.f[D_RX + k][i];
+  const double mi = d.f[D_M][i];
+  double ui = d.f[D_U][i];
+  const CellBox gb = d.cbox[gnode];
+  double gc[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < ND; k++) gc[k] = 0.5*(gb.bbmin[k] + gb.bbmax[k]);
+  float tf[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < ND; k++) tf[k] = (float) (ri[k] - gc[k]);
+  // the lane's leaf cell: hmax = 1.05 * cell.hmax bounds its iterates (first try of GradhSphTree.cpp:141-226)
+  int leafn = gnode;
+  while (leafn < d.gtot - 1) { const int c2 = 2*leafn + 2; leafn = (i >= d.cfirst[c2]) ? c2 : 2*leafn + 1; }
+  const double hmaxl = 1.05*d.ch[leafn].hmax;
+  const double h0 = d.f[D_H][i];
+  double h = h0, hlo = 0.0, hup = hmaxl;
+  int iter = 0;
+  bool done = !act;
+  double rho = 0.0, omg = 0.0, zet = 0.0;
+  double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
+  unsigned long long n_iter = 0, n_cand = 0, n_tested = 0;
+  const double cullsqd = K::kernrangesqd*hmaxl*hmaxl;
+  double Rmax = 0.0;                                       // largest |coordinate - group centre| a candidate can have
+  {
+    double hs = wave_max(act ? hmaxl : 0.0);
+    for (int k = 0; k < ND; k++) Rmax = fmax(Rmax, 0.5*(gb.bbmax[k] - gb.bbmin[k]) + K::kernrange*hs);
+  }
+  const int2 *rl = G.rl + (size_t) q*G.rcap;
+
+  for (;;) {
+    const bool running = !done;
+    if (!__any(running)) break;
+    if (running) {
+      iter++; n_iter++;
+      invh = 1.0/h;
+      hfactor = powN<ND>(invh);
+      invhsqd = invh*invh;
+      rho = 0.0; omg = 0.0; zet = 0.0;
+    }
+    // fp32 cull threshold: a superset of {invhsqd*r2 < kernrangesqd} (see k_density)
+    const float thr = running ? (float) ((K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(1.0 + 1e-6)) : -1.0f;
+    int nb = 0;
+    auto process_batch = [&]() {
+      int b = 0;
+      unsigned long long mask = nb > 0 ? s_mask[0][lane] : 0ull;
+      for (;;) {
+        while (mask == 0ull && b + 1 < nb) mask = s_mask[++b][lane];
+        if (!__any(mask != 0ull)) break;
+        if (mask != 0ull) {
+          const int c = b*64 + __ffsll((long long) mask) - 1;
+          mask &= mask - 1ull;
+          double dr[3] = {0.0, 0.0, 0.0};
+          dr[0] = s_x[c] - ri[0];
+          if (ND > 1) dr[1] = s_y[c] - ri[1];
+          if (ND > 2) dr[2] = s_z[c] - ri[2];
+          const double mj = s_m[c];
+          double r2 = dr[0]*dr[0];
+          if (ND > 1) r2 += dr[1]*dr[1];
+          if (ND > 2) r2 += dr[2]*dr[2];
+          {
+#pragma clang fp contract(fast)
+            const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
+            rho += mj*K::t_w0s2(s2, P.ktab);
+            omg += mj*invh*K::t_womegas2(s2, P.ktab);
+            zet += mj*K::t_wzetas2(s2, P.ktab);
+          }
+        }
+      }
+      __syncthreads();
+      nb = 0;
+    };
+    auto tile = [&](bool valid, int j, int code) {
+      const int o = nb*64;
+      {
+        double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
+        if (valid) {
+          const double4 v = d.posm[j];
+          double sg[3], sh[3];
+          code_xform(P.dom, code, sg, sh);
+          x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2]; m = v.w;
+        }
+        s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
+        s_fx[lane] = (float) (x - gc[0]); s_fy[lane] = ND > 1 ? (float) (y - gc[1]) : 0.f; s_fz[lane] = ND > 2 ? (float) (z - gc[2]) : 0.f;
+      }
+      __syncthreads();
+      unsigned int mlo = 0, mhi = 0;
+      {
+        const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]};
+        const float2_t *fx = (const float2_t*) s_fx, *fy = (const float2_t*) s_fy, *fz = (const float2_t*) s_fz;
+#pragma unroll 8
+        for (int c2 = 0; c2 < 32; c2++) {
+          const float2_t dx = fx[c2] - tx;
+          float2_t r2 = dx*dx;
+          if (ND > 1) { const float2_t dy = fy[c2] - ty; r2 = dy*dy + r2; }
+          if (ND > 2) { const float2_t dz = fz[c2] - tz; r2 = dz*dz + r2; }
+          const unsigned int bits = ((r2.x < thr) ? 1u : 0u) | ((r2.y < thr) ? 2u : 0u);
+          if (c2 < 16) mlo |= bits << (2*c2); else mhi |= bits << (2*c2 - 32);
+        }
+      }
+      s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);
+      if (COUNT) {
+        if (running) {
+          for (int c = 0; c < 64; c++) {
+            double r2 = 0.0;
+            { const double dx = s_x[o + c] - ri[0]; r2 = dx*dx; }
+            if (ND > 1) { const double dy = s_y[o + c] - ri[1]; r2 += dy*dy; }
+            if (ND > 2) { const double dz = s_z[o + c] - ri[2]; r2 += dz*dz; }
+            if (r2 + GH_SMALL <= cullsqd) n_cand++;
+          }
+          n_tested += 64;
+        }
+      }
+      nb++;
+      if (nb == DBE) process_batch();
+      else __syncthreads();
+    };
+    {
+      RangeState R; R.nrb = 0; R.nslots = 0;
+      for (int c0 = 0; c0 < nr; c0 += 64) {
+        const int e = c0 + lane;
+        int2 ent = make_int2(0, 0);
+        if (e < nr) ent = rl[e];
+        const unsigned long long vm = __ballot(ent.y > 0);
+        if (ent.y > 0) {
+          const int pos = R.nrb + __popcll(vm & lt);
+          s_ring.first[pos] = ent.x & GH_NODE_MASK; s_ring.cnt[pos] = ent.y; s_ring.tag[pos] = ent.x >> GH_NODE_BITS;
+        }
+        R.nrb += __popcll(vm);
+        R.nslots += wave_sum_i(ent.y);
+        range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, tile);
+      }
+      range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, tile);
+    }
+    process_batch();
+
+    bool failed = false;
+    if (running) {
+      rho *= hfactor; omg *= hfactor; zet *= invhsqd;
+      const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
+      if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
+      else {
+        if (iter < 30) h = hnew;
+        else if (iter == 30) h = 0.5*(hlo + hup);
+        else if (iter < 150) {
+          if (rho < GH_SMALL || h > hnew) hup = h; else hlo = h;
+          h = 0.5*(hlo + hup);
+        }
+        else { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
+        if (!done) {
+          if (!isfinite(h)) { atomicOr(flags, FLAG_H_NOT_CONVERGED); done = true; }
+          else if (h > hmaxl) failed = true;                                 // "return 0", :255
+          else if (!(h > hlo && h < hup)) done = true;                       // loop exit, :257
+        }
+      }
+    }
+    // the reference now redoes the leaf cell with hmax*1.05 - a search volume the list does not cover: hand the
+    // whole group to the fused kernel (nothing has been stored yet)
+    if (__any(failed)) {
+      if (lane == 0) G.fb[q] = 1;
+      return;
+    }
+  }
+
+  if (act) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo);
+  if (COUNT) {
+    const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0);
+    const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
+    if (lane == 0) { atomicAdd(&stats[ST_ITER], a); atomicAdd(&stats[ST_CAND], b); atomicAdd(&stats[ST_PAIRS], t); }
   }
 }
 
@@ -389,16 +759,60 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
+  P.only_if = nullptr; P.only_val = 1;
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
+  // split path (walk -> candidate range lists in HBM -> evaluation); GH_DENSITY_FUSED=1 keeps the fused kernel alone
+  static const bool fused_only = getenv("GH_DENSITY_FUSED") != nullptr;
+  DensLists G;
+  G.rcap = GH_DENS_RCAP;
+  if (ctx->dl_groups != ctx->ngroups) {
+    for (void *p : {(void*) ctx->dl_rl, (void*) ctx->dl_rlen}) if (p) (void) hipFree(p);
+    ctx->dl_rl = nullptr; ctx->dl_rlen = nullptr; ctx->dl_groups = 0;
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->dl_rl, sizeof(int2)*(size_t) ctx->ngroups*G.rcap));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->dl_rlen, sizeof(int)*2*(size_t) ctx->ngroups));
+    GH_CHECK(ctx, hipMemset(ctx->dl_rlen, 0, sizeof(int)*2*(size_t) ctx->ngroups));
+    ctx->dl_groups = ctx->ngroups;
+  }
+  G.rl = (int2*) ctx->dl_rl; G.rlen = ctx->dl_rlen; G.fb = ctx->dl_rlen + ctx->ngroups;
+  P.fbout = G.fb;
+  P.miss_count = (unsigned int*) (ctx->d_blk + 12);
+  const bool dd = ctx->nranks > 1;
+  if (dd) GH_CHECK(ctx, hipMemsetAsync(P.miss_count, 0, sizeof(unsigned int), s));
+  if (dd && fused_only) GH_CHECK(ctx, hipMemsetAsync(G.fb, 0, sizeof(int)*(size_t) ctx->ngroups, s));
   gh_phase_begin(ctx, GH_T_SPH_PROPERTIES);
-  if (nblocks > 0) {
+  if (nblocks > 0 && !fused_only) {
+#define LAUNCH(ND_, KT_)                                                                                      \
+    hipLaunchKernelGGL((k_dens_walk<ND_, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_flags);        \
+    if (count) hipLaunchKernelGGL((k_dens_eval<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_dens_eval<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags);
+    GH_DISPATCH(ctx, LAUNCH)
+#undef LAUNCH
+    P.only_if = G.fb;        // the fused kernel redoes what the split path flagged (early exit per group otherwise)
+  }
 #define LAUNCH(ND_, KT_)                                                                                      \
     if (count) hipLaunchKernelGGL((k_density<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
     else hipLaunchKernelGGL((k_density<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
-    GH_DISPATCH(ctx, LAUNCH)
-#undef LAUNCH
+  if (nblocks > 0) { GH_DISPATCH(ctx, LAUNCH) }
+  if (dd) {
+    // multi-GPU: groups whose walk left the imported halo stored nothing; widen the import and redo just those (the
+    // h iteration may grow a smoothing length past any margin fixed in advance - e.g. the first pass from a guessed h).
+    // The decision is collective: every rank takes part in every widened exchange.
+    P.only_if = G.fb; P.only_val = 2;
+    double widen = 1.0;
+    for (int attempt = 0; ; attempt++) {
+      int any = 0;
+      int rc = gh_dd_any(ctx, P.miss_count, &any);        // sum over ranks of the miss counters (synchronises)
+      if (rc) return rc;
+      if (!any) break;
+      if (attempt >= 24) return gh_fail(ctx, GH_ERR_CAPACITY, "gh_update_density: halo import did not converge");
+      widen *= 2.0;
+      if ((rc = gh_dd_exchange_margin(ctx, GH_HALO_DENSITY, widen))) return rc;
+      GH_CHECK(ctx, hipMemsetAsync(P.miss_count, 0, sizeof(unsigned int), s));
+      if (nblocks > 0) { GH_DISPATCH(ctx, LAUNCH) }
+    }
   }
+#undef LAUNCH
   gh_phase_end(ctx, GH_T_SPH_PROPERTIES);
 #ifdef GH_DEBUG_BLOCKTIME
   if (const char *f = getenv("GH_DEBUG_BLOCKTIME_FILE")) {
@@ -413,47 +827,3 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   return GH_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// multi-GPU: the fields of a received slice that are pure functions of (h, rho, u) - same expressions
-// as the end of k_density, so the values are bit-identical to the owner's
-// ------------------------------------------------------------------------------------------------
-template <int ND, int KT>
-__global__ void k_derive_density(DevicePtrs d, EosParams eos, int first, int count)
-{
-  const int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t >= count) return;
-  const int i = first + t;
-  typedef typename KSel<ND, KT>::type K;
-  const double h = d.f[D_H][i], rho = d.f[D_RHO][i];
-  double u = d.f[D_U][i];
-  const double invh1 = 1.0/h;
-  double sound, press;
-  eos_eval(eos, rho, u, sound, press);
-  d.f[D_HFACTOR][i] = powN<ND>(invh1)*invh1;
-  d.f[D_HRANGESQD][i] = K::kernrangesqd*h*h;
-  d.f[D_DIV_V][i] = 0.0;
-  d.f[D_U][i] = u;
-  d.f[D_SOUND][i] = sound;
-  d.f[D_PRESSURE][i] = press;
-}
-
-__global__ void k_copy_gpot_hydro(DevicePtrs d, int first, int count)
-{
-  const int t = blockIdx.x*blockDim.x + threadIdx.x;
-  if (t < count) d.f[D_GPOT_HYDRO][first + t] = d.f[D_GPOT][first + t];
-}
-
-void gh_derive_after_unpack(gh_ctx *ctx, int set, int64_t first, int64_t count)
-{
-  if (count <= 0) return;
-  DevicePtrs d = gh_dev(ctx);
-  const int nb = cdiv(count, 256);
-  if (set == GH_X_DENSITY) {
-    EosParams e;
-    gh_fill_eos(ctx, e);
-#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_derive_density<ND_, KT_>), dim3(nb), dim3(256), 0, ctx->stream, d, e, (int) first, (int) count);
-    GH_DISPATCH(ctx, LAUNCH)
-#undef LAUNCH
-  }
-  else hipLaunchKernelGGL(k_copy_gpot_hydro, dim3(nb), dim3(256), 0, ctx->stream, d, (int) first, (int) count);
-}

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &cnt) {
     const CellBox b = d.cbox[n];
     const int cn = b.N;
-    if (cn == 0) return;
+    if (cn < 0) atomicOr(flags, FLAG_LET_MISS);            // multi-GPU: a remote cell the halo exchange did not import
+    if (cn <= 0) return;
     double sg[3], sh[3];
     code_xform(P.dom, code, sg, sh);
     const CellH bh = d.ch[n];
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       n = s_stack[top - 1 - lane];
       const unsigned int fm = s_smask[top - 1 - lane];
       g = d.cgeo[n];
+      if (g.N < 0) { atomicOr(flags, FLAG_LET_MISS); g.N = 0; }     // multi-GPU: a remote cell the halo exchange did not import
       isleaf = n >= leaf0;
       const double khr = K::kernrange*g.hmax;
       // quick classification of the node against the whole group.  Every leaf centre lies within Rg of
@@ -535,7 +537,8 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, s, gh_dev_own(ctx));
+  { const int rc = gh_dd_exchange(ctx, GH_HALO_HYDRO); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_, KT_)                                                                                            \
@@ -592,7 +595,8 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
     if (!(fused && fused[0] == '1') && ctx->leafocc <= 6) return gh_grav_lists_impl(ctx, count);
   }
   if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole / gravity_mac=gadget2 need the list kernels (Nleafmax <= 6)");
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx));
+  { const int rc = gh_dd_exchange(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   int rc = gh_grav_fused_launch(ctx, count, nullptr);
   gh_phase_end(ctx, GH_T_SPH_FORCES);

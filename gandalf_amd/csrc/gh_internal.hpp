@@ -128,6 +128,9 @@ struct gh_ctx {
   size_t glist_leaves = 0;
   int glist_caps = 0;
 
+  // candidate range lists of the split density path (density.hip)
+  void *dl_rl = nullptr; int *dl_rlen = nullptr; int dl_groups = 0;
+
   // statistics / timers
   unsigned long long *d_stats = nullptr;   // device counters
   int *d_flags = nullptr;                  // device error flags
@@ -151,8 +154,12 @@ struct gh_ctx {
   double4 *star_posm = nullptr; double *star_h = nullptr, *star_out = nullptr;
   int nstars = 0, star_softening = 1; int64_t star_cap = 0;
 
-  // multi-GPU work shard
-  int rank = 0, nranks = 1;
+  // multi-GPU (comm.hip): rank r of nranks = 2^L owns level-L cell r of the global KD-tree - the static particle range
+  // [own_first, own_first + own_count) of the global tree-order index space; everything when nranks == 1
+  int rank = 0, nranks = 1, L = 0;
+  int64_t own_first = 0, own_count = 0;
+  int iota_p0 = -1;
+  struct gh_dd *dd = nullptr;
 };
 
 #define GH_MAX_RANKS 16
@@ -191,13 +198,16 @@ static inline int cdiv(int64_t a, int64_t b) { return (int) ((a + b - 1)/b); }
 
 // error-flag bits written by kernels
 enum { FLAG_FRONTIER_OVERFLOW = 1, FLAG_LEAFLIST_OVERFLOW = 2, FLAG_H_NOT_CONVERGED = 4,
-       FLAG_ILIST_OVERFLOW = 8 };
+       FLAG_ILIST_OVERFLOW = 8,
+       FLAG_LET_MISS = 16,     // multi-GPU: a walk reached a remote cell that the halo exchange did not import
+       FLAG_DD_SPLIT = 32 };   // multi-GPU: a top-level median split could not be resolved (too many equal coordinates)
 
 // stats slots
 enum { ST_ITER = 0, ST_CAND, ST_RETRY, ST_PAIRS, ST_DIRECT, ST_CELLS, ST_COUNT };
 #define ST_TOTAL (ST_COUNT + 8)   /* + diagnostic cycle stamps (GH_STAMPS builds) */
 
 DevicePtrs gh_dev(gh_ctx *ctx);
+DevicePtrs gh_dev_own(gh_ctx *ctx);   // this rank's own particles only (elementwise kernels)
 int gh_alloc_particles(gh_ctx *ctx, int64_t N);
 int gh_alloc_tree(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx);
@@ -231,3 +241,9 @@ struct Domain; struct EosParams;
 void gh_fill_domain(const gh_ctx *ctx, Domain &dom);
 void gh_fill_eos(const gh_ctx *ctx, EosParams &e);
 void gh_shard_groups(const gh_ctx *ctx, int rank, int &g0, int &g1);
+// multi-GPU (comm.hip); all no-ops on one rank
+int gh_dd_exchange(gh_ctx *ctx, int phase);    // halo / locally-essential-tree import for the walks of `phase`
+int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen);   // ... with the density search radius widened
+int gh_dd_any(gh_ctx *ctx, const unsigned int *count_dev, int *any);   // any rank's counter non-zero? (collective, synchronises)
+int gh_dd_min_dt(gh_ctx *ctx);                 // time[1] = min over ranks
+void gh_dd_free(gh_ctx *ctx);

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
       n = s_stack[top - 1 - lane];
       const unsigned int fm = s_smask[top - 1 - lane];
       g = d.cgeo[n];
+      if (g.N < 0) { atomicOr(flags, FLAG_LET_MISS); g.N = 0; }     // multi-GPU: a remote cell the halo exchange did not import
       isleaf = n >= leaf0;
       const double khr = K::kernrange*g.hmax;
       // quick classification against the whole group (see k_grav_forces): lower bound D - Rg on every
@@ -915,7 +916,8 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   const int ngroups = g1 - g0;
   const int nl = 1 << (ctx->ltot - ctx->lgroup);
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->N, 256)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, s, gh_dev_own(ctx));
+  { const int rc = gh_dd_exchange(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_GRAV_WALK);
   if (ngroups > 0) {
 #define LAUNCH(ND_, KT_) \

@@ -161,7 +161,7 @@ __global__ void k_kdk_end(DevicePtrs d, const double *time, int energy_integrati
 
 int gh_zero_acc_impl(gh_ctx *ctx)
 {
-  hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx));
+  hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx));
   return GH_OK;
 }
 
@@ -171,7 +171,7 @@ int gh_kdk_advance_impl(gh_ctx *ctx, int, double, double)
 {
   Domain dom;
   gh_fill_domain(ctx, dom);
-  hipLaunchKernelGGL(k_kdk_advance, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), dom,
+  hipLaunchKernelGGL(k_kdk_advance, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), dom,
                      gh_time_dev(ctx), ctx->cfg.energy_integration,
                      (ctx->cfg.avisc == GH_AVISC_MON97MM97 || ctx->cfg.avisc == GH_AVISC_MON97CD2010) ? 1 : 0, ctx->d_blk);
   return GH_OK;
@@ -193,15 +193,16 @@ int gh_timestep_impl_extra(gh_ctx *ctx, int nextra)
   tp.courant_mult = ctx->cfg.courant_mult; tp.accel_mult = ctx->cfg.accel_mult; tp.energy_mult = ctx->cfg.energy_mult;
   tp.energy_integration = ctx->cfg.energy_integration; tp.hydro_forces = ctx->cfg.hydro_forces;
   const int nblk = 256;
-  hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev(ctx), tp, ctx->redbuf);
+  hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev_own(ctx), tp, ctx->redbuf);
   hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, ctx->stream, ctx->redbuf, nblk + nextra, gh_time_dev(ctx));
-  hipLaunchKernelGGL(k_set_dt_next, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), gh_time_dev(ctx));
+  { const int rc = gh_dd_min_dt(ctx); if (rc) return rc; }      // multi-GPU: minimum over the ranks (Simulation.cpp:1738)
+  hipLaunchKernelGGL(k_set_dt_next, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), gh_time_dev(ctx));
   return GH_OK;
 }
 
 int gh_kdk_end_impl(gh_ctx *ctx, int, double, double)
 {
-  hipLaunchKernelGGL(k_kdk_end, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), gh_time_dev(ctx),
+  hipLaunchKernelGGL(k_kdk_end, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), gh_time_dev(ctx),
                      ctx->cfg.energy_integration, ctx->d_blk);
   return GH_OK;
 }
@@ -368,7 +369,7 @@ int gh_thermal_all_impl(gh_ctx *ctx)
 {
   EosParams eos;
   gh_fill_eos(ctx, eos);
-  hipLaunchKernelGGL(k_thermal_all, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), eos);
+  hipLaunchKernelGGL(k_thermal_all, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), eos);
   return GH_OK;
 }
 
@@ -376,8 +377,8 @@ int gh_thermal_all_impl(gh_ctx *ctx)
 int gh_block_timesteps_impl(gh_ctx *ctx)
 {
   hipStream_t s = ctx->stream;
-  const int nb = cdiv(ctx->N, 256);
-  DevicePtrs d = gh_dev(ctx);
+  const int nb = cdiv(ctx->own_count, 256);
+  DevicePtrs d = gh_dev_own(ctx);
   double *time = gh_time_dev(ctx);
   if (ctx->n == ctx->nresync) {
     const int nblk = 256;
@@ -397,6 +398,6 @@ int gh_block_timesteps_impl(gh_ctx *ctx)
 
 int gh_check_timesteps_impl(gh_ctx *ctx)
 {
-  hipLaunchKernelGGL(k_check_timesteps, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->d_blk, ctx->cfg.level_diff_max);
+  hipLaunchKernelGGL(k_check_timesteps, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), ctx->d_blk, ctx->cfg.level_diff_max);
   return GH_OK;
 }

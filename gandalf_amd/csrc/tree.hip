@@ -29,12 +29,13 @@ static const double BIG = 9.9e20;   // reference Constants.h:72 big_number
 // ------------------------------------------------------------------------------------------------
 // root box: min/max over particles of r -/+ kernrange*h           (KDTree.cpp:269-280)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */, int *cellnode0)
+__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */, int *cellnode0, int node0)
 {
+  // d is the view of this rank's own particles (all particles on one rank); cellnode0 is shifted likewise
   __shared__ double s[6][256];
   double mn[3] = {BIG, BIG, BIG}, mx[3] = {-BIG, -BIG, -BIG};
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
-    cellnode0[i] = 0;                  // every particle starts in the root cell
+    cellnode0[i] = node0;              // every particle starts in the root cell (of this rank's subtree)
     const double hr = kernrange*d.f[D_H][i];
     _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
       const double x = d.f[D_RX + k][i];
@@ -67,10 +68,10 @@ __global__ void k_rootbox_final(const double *part, int nblk, double *dbbmin, do
   }
 }
 
-__global__ void k_iota(int *v, int n)
+__global__ void k_iota(int *v, int n, int base)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i < n) v[i] = i;
+  if (i < n) v[i] = base + i;
 }
 
 __global__ void k_fill_int(int *v, int n, int val)
@@ -92,14 +93,17 @@ struct LevelArgs {
   double *dbbmin, *dbbmax;
   int *kdiv;
   int level, nwords;
+  int p0, pn;            // particle range [p0, p0 + pn) the build works on: everything on one rank, the rank's own cell otherwise
+  int jbase;             // k_build_subtree: first level-L0 cell of the range
 };
 
 // level steps 1+2: split axis + median + children's inherited boxes (KDTree.cpp:490-533) and the left (0) /
 // right (1) mark of every particle, taken from its cell's split-axis list
 __global__ void k_mark_side(DevicePtrs d, LevelArgs a)
 {
-  const int p = blockIdx.x*blockDim.x + threadIdx.x;
-  if (p >= d.N) return;
+  const int pl = blockIdx.x*blockDim.x + threadIdx.x;
+  if (pl >= a.pn) return;
+  const int p = a.p0 + pl;
   const int n = a.cellnode[p];
   const int first = d.cfirst[n], cnt = d.cN[n], half = cnt/2;
   // split axis = longest side of the inherited box (every particle of the cell recomputes it: 6 cached loads)
@@ -131,12 +135,13 @@ __global__ void k_mark_side(DevicePtrs d, LevelArgs a)
 __global__ __launch_bounds__(256) void k_ballot_words(DevicePtrs d, LevelArgs a)
 {
   __shared__ unsigned int s_cnt[3][4];
-  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  const int pl = blockIdx.x*blockDim.x + threadIdx.x;      // word / block indices are local to the range
+  const int p = a.p0 + pl;
   _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
-    const int flag = (p < d.N) ? (a.side[a.P[k][p]] == 0) : 0;
+    const int flag = (pl < a.pn) ? (a.side[a.P[k][p]] == 0) : 0;
     const unsigned long long w = __ballot(flag);
     if ((threadIdx.x & 63) == 0) {
-      if ((p >> 6) < a.nwords) a.W[k][p >> 6] = w;
+      if ((pl >> 6) < a.nwords) a.W[k][pl >> 6] = w;
       s_cnt[k][threadIdx.x >> 6] = __popcll(w);
     }
   }
@@ -187,14 +192,15 @@ __device__ __forceinline__ unsigned int rank_left(const unsigned long long *W, c
 // level step 5: stable partition of every cell segment of every axis list
 __global__ void k_partition(DevicePtrs d, LevelArgs a)
 {
-  const int p = blockIdx.x*blockDim.x + threadIdx.x;
-  if (p >= d.N) return;
+  const int pl = blockIdx.x*blockDim.x + threadIdx.x;
+  if (pl >= a.pn) return;
+  const int p = a.p0 + pl;
   const int n = a.cellnode[p];
   const int first = d.cfirst[n], half = d.cN[n]/2;
   _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     const int id = a.P[k][p];
     const int right = a.side[id];
-    const int nleft_before = (int) (rank_left(a.W[k], a.Wpre[k], p) - rank_left(a.W[k], a.Wpre[k], first));
+    const int nleft_before = (int) (rank_left(a.W[k], a.Wpre[k], pl) - rank_left(a.W[k], a.Wpre[k], first - a.p0));
     const int np = right ? first + half + ((p - first) - nleft_before) : first + nleft_before;
     a.Pn[k][np] = id;
   }
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_build_subtree(DevicePtrs d, LevelArgs 
   __shared__ unsigned long long s_W[3][GH_SEG/64];
   __shared__ unsigned int s_pre[3][GH_SEG/64 + 1];
   const int tid = threadIdx.x;
-  const int j0 = blockIdx.x;
+  const int j0 = a.jbase + blockIdx.x;
   const int n0 = (1 << L0) - 1 + j0;
   const int first0 = d.cfirst[n0], cnt = d.cN[n0];
   const int ndim = d.ndim;
@@ -310,18 +316,18 @@ __global__ __launch_bounds__(1024) void k_build_subtree(DevicePtrs d, LevelArgs 
 // ------------------------------------------------------------------------------------------------
 // gather all particle arrays into tree order
 // ------------------------------------------------------------------------------------------------
-__global__ void k_permute(double **tab /* [2*D_COUNT]: src then dst */, const int *perm, int N)
+__global__ void k_permute(double **tab /* [2*D_COUNT]: src then dst */, const int *perm, int p0, int pn)
 {
   const int f = blockIdx.y;
   const double *src = tab[f];
   double *dst = tab[D_COUNT + f];
-  for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < N; i += gridDim.x*blockDim.x) dst[i] = src[perm[i]];
+  for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < pn; i += gridDim.x*blockDim.x) dst[p0 + i] = src[perm[p0 + i]];
 }
 
-__global__ void k_permute_int(const int *src, int *dst, const int *perm, int N)
+__global__ void k_permute_int(const int *src, int *dst, const int *perm, int p0, int pn)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i < N) dst[i] = src[perm[i]];
+  if (i < pn) dst[p0 + i] = src[perm[p0 + i]];
 }
 
 __global__ void k_pack_posm(DevicePtrs d)
@@ -532,10 +538,12 @@ __device__ __forceinline__ void stock_combine(const DevicePtrs &d, int n, const 
   }
 }
 
-__global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only)
+__global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int hmax_only, int j0, int nj)
 {
-  const int j = blockIdx.x*blockDim.x + threadIdx.x;
-  if (j >= (1 << level)) return;
+  // cells [j0, j0 + nj) of the level: all of it on one rank, the rank's own subtree otherwise
+  const int jl = blockIdx.x*blockDim.x + threadIdx.x;
+  if (jl >= nj) return;
+  const int j = j0 + jl;
   const int n = (1 << level) - 1 + j;
   SRec r1, r2, o;
   srec_load(d, 2*n + 1, hmax_only, r1);
@@ -547,13 +555,14 @@ __global__ void k_stock_level(DevicePtrs d, int level, double thetamaxsqd, int h
 // level ltot-nlev and passes child records between levels through LDS (a barrier per level instead of a launch).
 #define GH_STOCK_NLEV 7
 __global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs d, double kernrange, double thetamaxsqd,
-                                                                      int hmax_only, int nlev)
+                                                                      int hmax_only, int nlev, int boff)
 {
   __shared__ SRec s_a[1 << GH_STOCK_NLEV];
   __shared__ SRec s_b[1 << (GH_STOCK_NLEV - 1)];
   const int t = threadIdx.x;
+  const int bx = boff + blockIdx.x;               // boff: first workgroup of this rank's subtree
   if (t < (1 << nlev)) {
-    const int g = (blockIdx.x << nlev) + t;
+    const int g = (bx << nlev) + t;
     const int n = d.gtot - 1 + g;
     SRec r;
     stock_leaf(d, n, kernrange, thetamaxsqd, hmax_only, r);
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs 
     __syncthreads();
     const int level = d.ltot - s;
     if (t < (1 << (nlev - s))) {
-      const int n = (1 << level) - 1 + (blockIdx.x << (nlev - s)) + t;
+      const int n = (1 << level) - 1 + (bx << (nlev - s)) + t;
       SRec o;
       stock_combine(d, n, src[2*t], src[2*t + 1], o, thetamaxsqd, hmax_only);
       dst[t] = o;
@@ -619,6 +628,18 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   return d;
 }
 
+// the same view restricted to this rank's own particles [own_first, own_first + own_count): for the elementwise kernels
+// (drift, kick, timestep, packs).  Cell tables are NOT shifted - kernels that walk the tree take gh_dev().
+DevicePtrs gh_dev_own(gh_ctx *ctx)
+{
+  DevicePtrs d = gh_dev(ctx);
+  const size_t o = (size_t) ctx->own_first;
+  for (int f = 0; f < D_COUNT; f++) d.f[f] += o;
+  d.iorig += o; d.posm += o; d.hrec += 4*o;
+  d.N = (int) ctx->own_count;
+  return d;
+}
+
 // tree size (KDTree::ComputeTreeSize, KDTree.cpp:322-352) and the static particle ranges of all cells
 int gh_alloc_tree(gh_ctx *ctx)
 {
@@ -651,6 +672,16 @@ int gh_alloc_tree(gh_ctx *ctx)
     if (mx <= GH_SEG) break;
   }
   ctx->lsub = lsub;
+  // multi-GPU: rank r owns level-L cell r of the global tree (L = log2 nranks) - a static particle range
+  {
+    int L = 0;
+    while ((1 << L) < ctx->nranks) L++;
+    if ((1 << L) != ctx->nranks || L > ctx->lgroup) return gh_fail(ctx, GH_ERR_INVALID, "the rank count must be a power of two, at most the number of particle groups");
+    ctx->L = L;
+    const int T = (1 << L) - 1 + ctx->rank;
+    ctx->own_first = ctx->h_cfirst[T]; ctx->own_count = ctx->h_cN[T];
+    if (ctx->lsub < L) ctx->lsub = L;
+  }
 
   auto re = [&](void **p, size_t bytes) -> hipError_t { if (*p) (void) hipFree(*p); *p = nullptr; return hipMalloc(p, bytes); };
   GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
@@ -684,55 +715,84 @@ int gh_alloc_tree(gh_ctx *ctx)
 
 int gh_pack_posm(gh_ctx *ctx)
 {
-  DevicePtrs d = gh_dev(ctx);
-  hipLaunchKernelGGL(k_pack_posm, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, d);
+  DevicePtrs d = gh_dev_own(ctx);
+  hipLaunchKernelGGL(k_pack_posm, dim3(cdiv(d.N, 256)), dim3(256), 0, ctx->stream, d);
   return GH_OK;
+}
+
+int gh_dd_publish(gh_ctx *ctx, int hmax_only);      // comm.hip: all-gather of the top of every rank's subtree
+
+// k_stock_top for the levels above the ranks' cells (comm.hip calls it after the all-gather)
+void gh_stock_top_levels(gh_ctx *ctx, int ltop, int hmax_only)
+{
+  if (ltop >= 0)
+    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, gh_dev(ctx), ltop, ctx->cfg.thetamaxsqd, hmax_only);
 }
 
 static int stock_tree(gh_ctx *ctx, int hmax_only)
 {
   DevicePtrs d = gh_dev(ctx);
   const double kr = KERNRANGE_OF(ctx->cfg);
-  const int nlev = std::min(ctx->ltot, GH_STOCK_NLEV);
-  hipLaunchKernelGGL(k_stock_bottom, dim3(ctx->gtot >> nlev), dim3(1 << GH_STOCK_NLEV), 0, ctx->stream, d, kr,
-                     ctx->cfg.thetamaxsqd, hmax_only, nlev);
+  const int L = ctx->L;                            // 0 on one rank: the subtree is the tree
+  const int nlev = std::min(ctx->ltot - L, GH_STOCK_NLEV);
+  const int nblk = (ctx->gtot >> L) >> nlev;
+  hipLaunchKernelGGL(k_stock_bottom, dim3(nblk), dim3(1 << GH_STOCK_NLEV), 0, ctx->stream, d, kr,
+                     ctx->cfg.thetamaxsqd, hmax_only, nlev, ctx->rank*nblk);
   const int lnext = ctx->ltot - nlev - 1;        // highest level not stocked yet
+  if (ctx->nranks > 1) {
+    for (int l = lnext; l >= L; l--)
+      hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << (l - L), 256)), dim3(256), 0, ctx->stream, d, l,
+                         ctx->cfg.thetamaxsqd, hmax_only, ctx->rank << (l - L), 1 << (l - L));
+    return gh_dd_publish(ctx, hmax_only);          // remote subtree tops, then the shared levels above the ranks' cells
+  }
   const int ltop = std::min(lnext, 9);
   for (int l = lnext; l > ltop; l--)
     hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << l, 256)), dim3(256), 0, ctx->stream, d, l,
-                       ctx->cfg.thetamaxsqd, hmax_only);
-  if (ltop >= 0)
-    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, d, ltop, ctx->cfg.thetamaxsqd, hmax_only);
+                       ctx->cfg.thetamaxsqd, hmax_only, 0, 1 << l);
+  gh_stock_top_levels(ctx, ltop, hmax_only);
   return GH_OK;
 }
 
 int gh_update_hmax_impl(gh_ctx *ctx) { return stock_tree(ctx, 1); }
 
 void stock_cell_velocities_fwd(gh_ctx *ctx);
+int gh_dd_decompose(gh_ctx *ctx);                    // comm.hip: global root box, top-level splits, particle migration
+
+// local extent of r -/+ kernrange*h over this rank's particles -> ctx->dbbmin/dbbmax[0..2]; every own particle starts in `node0`
+void gh_rootbox_local(gh_ctx *ctx, int node0)
+{
+  const int nblk = 256;
+  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev_own(ctx), KERNRANGE_OF(ctx->cfg), ctx->redbuf,
+                     ctx->cellnode[0] + ctx->own_first, node0);
+  hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, ctx->stream, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
+}
+
 int gh_tree_build_impl(gh_ctx *ctx)
 {
   int rc = gh_alloc_tree(ctx);
   if (rc) return rc;
+  const int L = ctx->L;
+  if (ctx->nranks > 1) {
+    // root box, the L shared top levels (distributed median splits) and the migration of the particles that changed
+    // cells; leaves every own particle in cell (1 << L) - 1 + rank with that cell's inherited box in dbbmin/dbbmax
+    if ((rc = gh_dd_decompose(ctx))) return rc;
+  }
+  else gh_rootbox_local(ctx, 0);
+  const int p0 = (int) ctx->own_first, pn = (int) ctx->own_count;
   const int N = (int) ctx->N;
-  const int nb = cdiv(N, 256);
+  const int nb = cdiv(pn, 256);
   DevicePtrs d = gh_dev(ctx);
   hipStream_t s = ctx->stream;
-  const double kr = KERNRANGE_OF(ctx->cfg);
-
-  // root box
-  const int nblk = 256;
-  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, s, d, kr, ctx->redbuf, ctx->cellnode[0]);
-  hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, s, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
 
   // one argsort per axis, on three streams (each sort is ~30 small launches: they overlap)
-  if (ctx->iota_N != N) {             // identity values for the argsorts: never modified
-    hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, s, ctx->sortvals, N);
-    ctx->iota_N = N;
+  if (ctx->iota_N != N || ctx->iota_p0 != p0) {             // identity values for the argsorts: never modified
+    hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, s, ctx->sortvals, pn, p0);
+    ctx->iota_N = N; ctx->iota_p0 = p0;
   }
   {
     size_t need = 0;
-    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX], ctx->sortkeys_out, ctx->sortvals,
-                                            ctx->P[0][0], (size_t) N, 0, 64, s));
+    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX] + p0, ctx->sortkeys_out, ctx->sortvals,
+                                            ctx->P[0][0] + p0, (size_t) pn, 0, 64, s));
     need = (need + 255) & ~(size_t) 255;
     if (3*need > ctx->sorttemp_bytes) {
       GH_CHECK(ctx, hipStreamSynchronize(s));
@@ -744,25 +804,26 @@ int gh_tree_build_impl(gh_ctx *ctx)
     for (int k = 0; k < ctx->ndim; k++) {
       hipStream_t sk = k == 0 ? s : ctx->aux[k - 1];
       if (k > 0) GH_CHECK(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
-      GH_CHECK(ctx, rocprim::radix_sort_pairs((char*) ctx->sorttemp + k*need, need, d.f[D_RX + k],
-                                              ctx->sortkeys_out + (size_t) k*N, ctx->sortvals, ctx->P[0][k], (size_t) N, 0, 64, sk));
+      GH_CHECK(ctx, rocprim::radix_sort_pairs((char*) ctx->sorttemp + k*need, need, d.f[D_RX + k] + p0,
+                                              ctx->sortkeys_out + (size_t) k*N, ctx->sortvals, ctx->P[0][k] + p0, (size_t) pn, 0, 64, sk));
       if (k > 0) GH_CHECK(ctx, hipEventRecord(ctx->ev_join[k - 1], sk));
     }
     for (int k = 1; k < ctx->ndim; k++) GH_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
   }
 
   int pb = 0;
-  const int nwords = (N + 63)/64;
+  const int nwords = (pn + 63)/64;
   auto level_args = [&](int l) {
     LevelArgs a;
     for (int k = 0; k < 3; k++) { a.P[k] = ctx->P[pb][k]; a.Pn[k] = ctx->P[pb ^ 1][k]; a.W[k] = ctx->W[k]; a.Wpre[k] = ctx->Wpre[k]; }
     a.cellnode = ctx->cellnode[pb]; a.cellnode_next = ctx->cellnode[pb ^ 1];
     a.side = ctx->side; a.dbbmin = ctx->dbbmin; a.dbbmax = ctx->dbbmax; a.kdiv = ctx->kdiv;
     a.level = l; a.nwords = nwords;
+    a.p0 = p0; a.pn = pn; a.jbase = 0;
     return a;
   };
   const int lsub = ctx->lsub;
-  for (int l = 0; l < lsub; l++) {
+  for (int l = L; l < lsub; l++) {
     LevelArgs a = level_args(l);
     hipLaunchKernelGGL(k_mark_side, dim3(nb), dim3(256), 0, s, d, a);
     hipLaunchKernelGGL(k_ballot_words, dim3(nb), dim3(256), 0, s, d, a);
@@ -773,7 +834,8 @@ int gh_tree_build_impl(gh_ctx *ctx)
   {
     // remaining levels: one workgroup per level-lsub cell (cellnode[pb^1] is free: used as id -> local index map)
     LevelArgs a = level_args(lsub);
-    hipLaunchKernelGGL(k_build_subtree, dim3(1 << lsub), dim3(1024), 0, s, d, a, lsub, ctx->ltot, ctx->P[pb ^ 1][0],
+    a.jbase = ctx->rank << (lsub - L);
+    hipLaunchKernelGGL(k_build_subtree, dim3(1 << (lsub - L)), dim3(1024), 0, s, d, a, lsub, ctx->ltot, ctx->P[pb ^ 1][0],
                        ctx->cellnode[pb ^ 1]);
     pb ^= 1;
   }
@@ -781,14 +843,14 @@ int gh_tree_build_impl(gh_ctx *ctx)
   // gather every particle array into tree order (perm[new] = old position).  The two pointer tables
   // (buffer 0 -> 1 and 1 -> 0) live in device memory since allocation: no host synchronisation here.
   const int *perm = ctx->P[pb][0];
-  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, N);
-  hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, N);
+  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn);
+  hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, p0, pn);
   ctx->cur ^= 1;
-  stock_tree(ctx, 0);
-  stock_cell_velocities_fwd(ctx);
-  gh_pack_posm(ctx);
-  GH_CHECK(ctx, hipGetLastError());
   ctx->tree_valid = true;
+  gh_pack_posm(ctx);
+  if ((rc = stock_tree(ctx, 0))) return rc;
+  stock_cell_velocities_fwd(ctx);
+  GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
 

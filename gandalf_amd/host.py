@@ -24,6 +24,7 @@ HOST_SYMBOLS = {
     "gah_initial_h_provided": (C.c_int, [_H]),
     "gah_get_ic": (C.c_int, [_H, _PD, _PD, _PD, _PD, _PD]),
     "gah_post_ic_setup": (C.c_int, [_H]),
+    "gah_init_comm": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "gah_upload_ic": (C.c_int, [_H]),
     "gah_setup": (C.c_int, [_H]),
     "gah_main_loop": (C.c_int, [_H, C.c_int]),
@@ -159,6 +160,10 @@ class Simulation:
 
     def initial_h_provided(self):
         return bool(self.lib.gah_initial_h_provided(self.h))
+
+    def init_comm(self, rank, nranks, ops_ptr):
+        """multi-GPU: rank, size and the collectives (address of a gh_comm_ops, multigpu.CommOps) - before the setup"""
+        self._chk(self.lib.gah_init_comm(self.h, rank, nranks, ops_ptr))
 
     def post_ic_setup(self):
         self._chk(self.lib.gah_post_ic_setup(self.h))

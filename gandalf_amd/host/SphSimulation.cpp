@@ -137,6 +137,17 @@ void SphSimulation::EnsureContext()
   int rc = gh_create(&cfg, &ctx);
   if (rc) { std::string m = ctx ? gh_last_error(ctx) : "gh_create failed"; if (ctx) gh_destroy(ctx); ctx = nullptr; throw GandalfError(m); }
   sphneib = new SphNeighbourSearch(ctx);
+  // multi-GPU run (the reference's MpiControl): rank / size and the collectives were registered with InitComm
+  if (comm_nranks > 1 && gh_comm_init(ctx, comm_rank, comm_nranks, &comm_ops)) throw GandalfError(gh_last_error(ctx));
+}
+
+// the reference's mpicontrol->InitialiseMpiProcess (MpiControl.cpp:94-150): one process per GPU, rank r owns the
+// r-th top-level cell of the global KD-tree; the collectives come from the caller (gandalf_hip.h: gh_comm_ops)
+void SphSimulation::InitComm(int rank, int nranks, const gh_comm_ops *ops)
+{
+  if (ctx) throw GandalfError("InitComm: call before the device context exists (before SetupSimulation)");
+  comm_rank = rank; comm_nranks = nranks;
+  if (ops) comm_ops = *ops;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -61,6 +61,9 @@ class SphSimulation {
 
   void ProcessParameters();                // SphSimulation.cpp:67 / GradhSphSimulation.cpp:54
   void EnsureContext();
+  void InitComm(int rank, int nranks, const gh_comm_ops *ops);
+  int comm_rank = 0, comm_nranks = 1;
+  gh_comm_ops comm_ops = {};
   void GenerateIC();                       // SimulationIC.hpp:51 (ic = box | plummer)
   void SetComFrame();                      // Simulation.cpp:1621
   void PostInitialConditionsSetup();       // SphSimulation.cpp:204

@@ -47,6 +47,14 @@ int gah_get_ic(gah_sim *s, double *r, double *v, double *m, double *h, double *u
   return 0;
 }
 int gah_post_ic_setup(gah_sim *s) { GAH_TRY(s, s->sim->PostInitialConditionsSetup()) }
+// multi-GPU: register rank, size and the collectives (gh_comm_ops*) before the setup creates the device context
+int gah_init_comm(gah_sim *s, int rank, int nranks, const void *ops)
+{
+  GAH_TRY(s, {
+    if (!s->sim) s->sim = SphSimulation::SimulationFactory(s->params.intparams["ndim"], s->params.stringparams["sim"], &s->params);
+    s->sim->InitComm(rank, nranks, (const gh_comm_ops*) ops);
+  })
+}
 // create the device context and upload the host particles without running the setup passes
 // (the multi-GPU runner drives those itself, with an exchange after every sliced pass)
 int gah_upload_ic(gah_sim *s)

@@ -1,131 +1,195 @@
-"""Multi-GPU stepping: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+"""Multi-GPU runs: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI) as the transport.
 
-Round-1 scheme: every rank keeps the full particle set and builds the same tree
-(288 GB of HBM per GPU makes replication free at these sizes); the two expensive phases - density and
-forces - are sharded by contiguous slices of tree groups (= top-level KD-tree cells), and the slices'
-outputs are all-gathered (RCCL) after each phase.  With world == 1 this is plain gh_step.
+libgandalf_hip does the domain decomposition, halo selection and packing itself (gandalf_amd/csrc/comm.hip,
+DESIGN.md section 7) and asks its host for exactly two collectives over device buffers (include/gandalf_hip.h:
+gh_comm_ops): an all-gather of equal blocks and an all-to-all of ragged blocks.  This module supplies them:
 
-The exchange is written against a small "device" interface (shard_range / exchange_narrays / shard_pack /
-shard_unpack) so that the slicing and gather logic can be exercised on CPU tensors with the gloo
-backend (tests/test_multigpu_cpu.py)."""
+  CommOps            the gh_comm_ops table as ctypes callbacks around torch.distributed
+                       nccl : all_gather_into_tensor / all_to_all_single on the library's own HIP stream
+                              (torch.cuda.ExternalStream), raw device pointers wrapped through __cuda_array_interface__
+                       gloo : the same calls staged through host memory - used by the CPU tests (host pointers) and by
+                              the functional test that runs two ranks on one GPU
+  DistributedRunner  bench.py / the tests' driver: registers the ops with the C++ host shell and runs setup / steps
+
+The reference's counterpart is its MPI layer (src/Mpi/MpiControl.cpp: MPI_Allgather :329-337, MPI_Alltoallv :1073-1150)."""
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
-
-class Exchanger:
-    """all-gather of per-rank contiguous slices of several equally long arrays"""
-
-    def __init__(self, dev, rank, world, torch_device):
-        self.dev, self.rank, self.world, self.tdev = dev, rank, world, torch_device
-        self.buf = {}
-        self.ranges = None
-        self.ext = None
-        self.simulate = False                      # timing estimate only: skip the collective (see bench.py --simulate-world)
-
-    def exchange(self, xset):
-        """pack -> all-gather -> unpack, all ordered on the device context's own stream: no host synchronisation"""
-        if self.world == 1:
-            return
-        if self.ranges is None:                     # the slices depend only on N and the rank count
-            self.ranges = [self.dev.shard_range(r) for r in range(self.world)]
-        stride = max(c for _, c in self.ranges)
-        stride = (stride + 63)//64*64
-        na = self.dev.exchange_narrays(xset)
-        key = (xset, na, stride)
-        if key not in self.buf:
-            self.buf[key] = (torch.zeros(na*stride, dtype=torch.float64, device=self.tdev),
-                             torch.zeros(self.world*na*stride, dtype=torch.float64, device=self.tdev))
-        mine, allb = self.buf[key]
-        if self.tdev.type == "cuda":
-            if self.ext is None:
-                self.ext = torch.cuda.ExternalStream(self.dev.stream_handle(), device=self.tdev)
-            with torch.cuda.stream(self.ext):       # RCCL orders its work against the current stream
-                self.dev.shard_pack(xset, mine.data_ptr(), stride)
-                if self.simulate:
-                    pass
-                elif dist.get_backend() == "gloo":
-                    # functional-test path (several ranks sharing one GPU): gloo moves host memory
-                    hm, ha = mine.cpu(), torch.empty(allb.shape, dtype=allb.dtype)
-                    dist.all_gather_into_tensor(ha, hm)
-                    allb.copy_(ha)
-                else:
-                    dist.all_gather_into_tensor(allb, mine)
-                self.dev.shard_unpack_all(xset, allb.data_ptr(), stride)
-            return
-        self.dev.shard_pack(xset, mine.data_ptr(), stride)
-        dist.all_gather_into_tensor(allb, mine)
-        self.dev.shard_unpack_all(xset, allb.data_ptr(), stride)
+_ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+_ALLTOALLV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p)
 
 
-class ShardedRunner:
-    def __init__(self, sim, rank, world, simulate=False):
+class _OpsStruct(C.Structure):          # gh_comm_ops
+    _fields_ = [("user", C.c_void_p), ("allgather", _ALLGATHER_T), ("alltoallv", _ALLTOALLV_T)]
+
+
+class _DevPtr:
+    """raw device memory as a uint8 array (torch.as_tensor accepts the CUDA array interface on ROCm too)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _host_view(ptr, nbytes):
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8)
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte*int(nbytes)).from_address(int(ptr))))
+
+
+class CommOps:
+    """gh_comm_ops on torch.distributed.  memory = "device" (pointers are HIP device memory) or "host" (CPU tests)."""
+
+    def __init__(self, memory="device", device=None, group=None):
+        self.memory = memory
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if memory == "device" else torch.device("cpu"))
+        self._streams = {}
+        self.calls = {"allgather": 0, "alltoallv": 0, "bytes": 0}
+        self.last_error = None
+        self._ag = _ALLGATHER_T(self._allgather)          # keep the callback objects alive
+        self._a2a = _ALLTOALLV_T(self._alltoallv)
+        self.struct = _OpsStruct(None, self._ag, self._a2a)
+
+    @property
+    def ptr(self):
+        return C.addressof(self.struct)
+
+    # ---- views of the library's buffers
+    def _view(self, ptr, nbytes):
+        if self.memory == "host":
+            return _host_view(ptr, nbytes)
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        return torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _stream(self, handle):
+        if handle not in self._streams:
+            self._streams[handle] = torch.cuda.ExternalStream(int(handle), device=self.device)
+        return self._streams[handle]
+
+    # ---- gh_comm_ops.allgather
+    def _allgather(self, user, send, recv, nbytes, stream):
+        try:
+            self.calls["allgather"] += 1
+            self.calls["bytes"] += int(nbytes)*self.world
+            inp, out = self._view(send, nbytes), self._view(recv, nbytes*self.world)
+            if self.memory == "device" and self.backend == "nccl":
+                with torch.cuda.stream(self._stream(stream)):          # RCCL orders its work against the current stream
+                    dist.all_gather_into_tensor(out, inp, group=self.group)
+                return 0
+            if self.memory == "device":                                  # gloo moves host memory
+                self._stream(stream).synchronize()
+                hi, ho = inp.cpu(), torch.empty(out.shape, dtype=torch.uint8)
+                dist.all_gather_into_tensor(ho, hi, group=self.group)
+                out.copy_(ho)
+                torch.cuda.synchronize(self.device)
+                return 0
+            dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group)
+            return 0
+        except Exception as e:      # noqa: BLE001 - a Python exception must not unwind through the C caller
+            self.last_error = e
+            return 1
+
+    # ---- gh_comm_ops.alltoallv
+    def _alltoallv(self, user, send, send_bytes, recv, recv_bytes, stream):
+        try:
+            self.calls["alltoallv"] += 1
+            sb = [int(send_bytes[r]) for r in range(self.world)]
+            rb = [int(recv_bytes[r]) for r in range(self.world)]
+            self.calls["bytes"] += sum(sb)
+            inp, out = self._view(send, sum(sb)), self._view(recv, sum(rb))
+            if self.memory == "device" and self.backend == "nccl":
+                with torch.cuda.stream(self._stream(stream)):
+                    dist.all_to_all_single(out, inp, rb, sb, group=self.group)
+                return 0
+            if self.memory == "device":
+                self._stream(stream).synchronize()
+                hi, ho = inp.cpu(), torch.empty(out.shape, dtype=torch.uint8)
+                self._host_alltoallv(ho, hi, rb, sb)
+                out.copy_(ho)
+                torch.cuda.synchronize(self.device)
+                return 0
+            self._host_alltoallv(out, inp, rb, sb)
+            return 0
+        except Exception as e:      # noqa: BLE001
+            self.last_error = e
+            return 1
+
+    def _host_alltoallv(self, out, inp, rb, sb):
+        """ragged all-to-all on host tensors with point-to-point messages (gloo has no all_to_all on every build)"""
+        so = np.concatenate(([0], np.cumsum(sb))).astype(np.int64)
+        ro = np.concatenate(([0], np.cumsum(rb))).astype(np.int64)
+        out[ro[self.rank]:ro[self.rank + 1]] = inp[so[self.rank]:so[self.rank + 1]]
+        reqs, keep = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if rb[r] > 0:
+                buf = torch.empty(rb[r], dtype=torch.uint8)
+                keep.append((r, buf))
+                reqs.append(dist.irecv(buf, src=r, group=self.group))
+            if sb[r] > 0:
+                reqs.append(dist.isend(inp[so[r]:so[r + 1]].contiguous(), dst=r, group=self.group))
+        for q in reqs:
+            q.wait()
+        for r, buf in keep:
+            out[ro[r]:ro[r + 1]] = buf
+
+
+class DistributedRunner:
+    """setup() / steps(n) of a gandalf_amd.host.Simulation on `world` ranks (rank r owns top-level KD cell r).
+    world == 1 is the plain single-GPU run."""
+
+    def __init__(self, sim, rank=0, world=1):
         self.sim, self.rank, self.world = sim, rank, world
-        self.simulate = simulate
+        self.ops = None
         self.dev = None
-        self.x = None
-
-    def _attach(self):
-        self.dev = self.sim.device()
-        self.dev.set_shard(self.rank, self.world)
-        self.x = Exchanger(self.dev, self.rank, self.world, torch.device("cuda", torch.cuda.current_device()))
-        self.x.simulate = self.simulate
 
     def setup(self):
-        """SphSimulation::PostInitialConditionsSetup (SphSimulation.cpp:204-565), sliced"""
-        if self.world == 1:
-            self.sim.post_ic_setup()
-            self._attach()
-            return
-        ic = self.sim.generate_ic() if self.sim.lib.gah_num_particles(self.sim.h) == 0 else None
-        del ic
-        self.sim.upload_ic()
-        self._attach()
-        d = self.dev
-        npass = 2 if self.sim.initial_h_provided() else 3
-        for _ in range(npass):
-            d.build_tree()
-            d.update_density()
-            self.x.exchange(d.X_DENSITY)
-            d.update_hmax()
-        d.zero_accelerations()
-        d.update_forces()
-        self.x.exchange(d.X_FORCES)
-        d.set_time(0.0, 0.0)
-        d.compute_global_timestep()
-        d.kdk_end(0, 0.0, 0.0)
+        if self.world > 1:
+            self.ops = CommOps("device")
+            self.sim.init_comm(self.rank, self.world, self.ops.ptr)
+        self.sim.post_ic_setup()
+        self.dev = self.sim.device()
+        self._check()
 
     def steps(self, n):
-        if n <= 0:
-            return
-        if self.world == 1:
+        if n > 0:
             self.sim.main_loop(n)
-            return
-        d = self.dev
-        for _ in range(n):
-            d.step_begin()
-            self.x.exchange(d.X_DENSITY)
-            d.step_forces()
-            self.x.exchange(d.X_FORCES)
-            if self.simulate:
-                try:                 # the other ranks' slices are stale: recoverable warnings are expected
-                    d.step_end()
-                except Exception as e:      # noqa: BLE001
-                    if getattr(e, "code", -1) <= 0:
-                        raise
-            else:
-                d.step_end()
+            self._check()
+
+    def _check(self):
+        if self.ops is not None and self.ops.last_error is not None:
+            raise self.ops.last_error
+
+    def gather(self, name):
+        """a field of all particles in caller order, merged over the ranks (every rank gets the whole array)"""
+        a = self.dev.download(name)
+        if self.world == 1:
+            return a
+        t = torch.from_numpy(np.nan_to_num(a, nan=0.0))
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)               # every particle is owned by exactly one rank: the others contribute zeros
+        return t.cpu().numpy()
 
     def count_density(self):
-        """counters of one density pass over this rank's slice, on the current state (instrumented build)"""
+        """counters of one density pass over this rank's particles, on the current state (collective)"""
         dev = self.dev
         h = dev.download("h")
         st = dev.update_density(stats=True)
-        dev.upload_field("h", h)       # leave h as it was; the next step rebuilds everything else
+        dev.upload_field("h", np.nan_to_num(h))       # leave h as it was; the next step rebuilds everything else
         return st
 
     def count_forces(self):
         dev = self.dev
-        saved = {k: dev.download(k) for k in ("a", "atree", "gpot", "gpot_hydro", "dudt", "div_v")}
+        saved = {k: np.nan_to_num(dev.download(k)) for k in ("a", "atree", "gpot", "gpot_hydro", "dudt", "div_v")}
         dev.zero_accelerations()
         st = dev.update_forces(stats=True)
         for k, v in saved.items():

@@ -54,7 +54,7 @@ enum { GH_MAC_GEOMETRIC = 0, GH_MAC_GADGET2 = 1, GH_MAC_EIGENMAC = 2 };   /* Tre
  * (Parameters.cpp:160-520; key names in comments). */
 typedef struct gh_config {
   int32_t ndim;            /* ndim: 1, 2 or 3 */
-  int32_t kernel;          /* kernel = m4 | quintic      (tabulated_kernel must be 0) */
+  int32_t kernel;          /* GH_KERNEL_*: kernel = m4 | quintic, each with tabulated_kernel = 0 | 1 */
   int32_t gas_eos;         /* gas_eos */
   int32_t avisc;           /* avisc */
   int32_t acond;           /* acond */
@@ -227,40 +227,48 @@ enum { GH_T_BUILD_TREE = 0, GH_T_SPH_PROPERTIES, GH_T_SPH_FORCES, GH_T_KDK,
 int gh_get_timers(gh_ctx *ctx, double *ms /* [GH_T_COUNT] */, gh_stats *density, gh_stats *forces);
 int gh_reset_timers(gh_ctx *ctx);
 
-/* ---- multi-GPU (one process per GPU) ---------------------------------------- */
-/* Work sharding: rank `rank` of `nranks` computes density/forces only for its contiguous slice of
- * tree groups; the caller all-gathers the result slices (RCCL via torch.distributed) through the
- * device pointers below.  With nranks=1 (default) nothing changes. */
-int gh_set_shard(gh_ctx *ctx, int rank, int nranks);
-/* particle range [first, first+count) (tree order) owned by a rank after the last gh_build_tree */
-int gh_shard_range(gh_ctx *ctx, int rank, int64_t *first, int64_t *count);
-/* exchange sets: the per-particle outputs a rank produces for its own slice in one phase.
- * GH_X_DENSITY: h rho invomega zeta (4 arrays; hfactor, hrangesqd, u, sound, pressure, div_v are
- *               recomputed by the receiver from these)
- * GH_X_FORCES : a[ndim] atree[ndim] gpot dudt div_v   (3 + 2 ndim arrays; gpot_hydro = gpot) */
-enum { GH_X_DENSITY = 0, GH_X_FORCES = 1 };
-int gh_exchange_narrays(gh_ctx *ctx, int set);
-/* copy this rank's slice of every array of `set` into dst_dev[a*stride .. ) (device memory, doubles),
- * a = 0 .. narrays-1; stride >= the largest slice of any rank.  Enqueued on the context's stream (gh_stream). */
-int gh_shard_pack(gh_ctx *ctx, int set, void *dst_dev, int64_t stride);
-/* copy the slice of rank `rank` from src_dev ([array][stride]) into the particle arrays and recompute the
- * fields derived from it.  Enqueued on the context's stream (gh_stream), like gh_shard_pack. */
-int gh_shard_unpack(gh_ctx *ctx, int set, int rank, const void *src_dev, int64_t stride);
-/* the same for every remote rank in one launch; src_dev is the all-gathered buffer [rank][array][stride] */
-int gh_shard_unpack_all(gh_ctx *ctx, int set, const void *src_dev, int64_t stride);
-/* the HIP stream (hipStream_t) every entry point enqueues on: a multi-GPU caller issues its collectives on
- * it (or orders them against it), so that a step needs no host synchronisation between its sections */
+/* ---- multi-GPU (one process per GPU) -----------------------------------
+ * Replaces the reference's MPI layer for this path: MpiKDTreeDecomposition::CreateInitialDecomposition
+ * (src/Mpi/MpiKDTreeDecomposition.cpp:56-135), MpiControl::UpdateAllBoundingBoxes / SendReceiveGhosts /
+ * ExportParticlesBeforeForceLoop / GetExportedParticlesAccelerations (src/Mpi/MpiControl.cpp:329-337, 745-1150),
+ * HydroTree::BuildPrunedTree / the pruned-tree exchange (src/Tree/HydroTree.cpp:1044-1230) and the MPI_Allreduce of
+ * the timestep (src/Common/Simulation.cpp:1738).
+ *
+ * nranks = 2^L processes, one GPU each.  Rank r owns level-L cell r of the GLOBAL KD-tree: the L shared top levels
+ * are split at exact global medians, so the union of the ranks' subtrees is the tree one GPU builds and every rank
+ * computes for its particles what one GPU computes for them.  A rank holds its own particles plus the halo it imports
+ * per phase (cells and particles of other ranks that its tree walks can reach).
+ *
+ * The library does not talk to a network itself: the host supplies two collectives over DEVICE buffers, to be
+ * enqueued on (or ordered against) the given HIP stream - RCCL through torch.distributed in gandalf_amd/multigpu.py,
+ * ncclAllGather / grouped ncclSend+ncclRecv (or MPI_Allgather / MPI_Alltoallv) in a C++ host.  Return 0 on success. */
+typedef struct gh_comm_ops {
+  void *user;
+  /* every rank contributes `bytes` bytes from send_dev; recv_dev receives nranks*bytes, ordered by rank */
+  int (*allgather)(void *user, const void *send_dev, void *recv_dev, int64_t bytes, void *hip_stream);
+  /* send_bytes[r] bytes to rank r from consecutive blocks of send_dev (rank order), recv_bytes[r] from rank r into
+   * consecutive blocks of recv_dev; the byte counts are HOST arrays [nranks] */
+  int (*alltoallv)(void *user, const void *send_dev, const int64_t *send_bytes, void *recv_dev, const int64_t *recv_bytes,
+                   void *hip_stream);
+} gh_comm_ops;
+/* call after gh_create and before gh_upload_particles.  nranks = 1 (ops may be NULL) is the single-GPU default.
+ * Multi-rank runs: open boundaries, global timestep, geometric MAC, constant-alpha viscosity, tree rebuilt every step;
+ * anything else is refused here (GH_ERR_UNSUPPORTED).  gh_upload_particles then takes the WHOLE initial condition on
+ * every rank and keeps this rank's share; gh_download / gh_upload_field touch only this rank's own particles.
+ * gh_build_tree, gh_update_density, gh_update_*_forces, gh_setup and gh_step are collective calls from then on. */
+int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops *ops);
+/* halo import for the tree walks of one phase; gh_update_density / gh_update_*_forces / gh_step call it themselves */
+enum { GH_HALO_DENSITY = 0 /* cell boxes + (r, m) */, GH_HALO_HYDRO = 1, GH_HALO_GRAVITY = 2 /* all cell records + force records */ };
+int gh_exchange_halo(gh_ctx *ctx, int phase);
+/* all-gather of the top levels of every rank's subtree (boxes, h-boxes, centres of mass, masses, quadrupoles) and
+ * re-stocking of the shared levels above them; gh_build_tree / gh_update_density call it themselves */
+int gh_allgather_multipoles(gh_ctx *ctx);
+/* this rank's particle range in the global tree order, and the number of particles it currently holds (own + imported) */
+int gh_comm_info(gh_ctx *ctx, int64_t *own_first, int64_t *own_count, int64_t *held);
+/* the HIP stream (hipStream_t) every entry point enqueues on */
 void *gh_stream(gh_ctx *ctx);
-/* replaces: KDTree::UpdateHmaxValues (KDTree.cpp:1128-1208).  gh_update_density calls it itself when
- * nranks == 1; with nranks > 1 the caller calls it after the density exchange. */
+/* replaces: KDTree::UpdateHmaxValues (KDTree.cpp:1128-1208); gh_update_density calls it itself */
 int gh_update_hmax(gh_ctx *ctx);
-/* the three sections of gh_step between which a multi-GPU caller exchanges slices:
- * begin  = clock + KDK predict + tree rebuild + density on this rank's slice   (then exchange GH_X_DENSITY)
- * forces = UpdateHmaxValues + ZeroAccelerations + forces on this rank's slice  (then exchange GH_X_FORCES)
- * end    = global timestep + KDK correct */
-int gh_step_begin(gh_ctx *ctx);
-int gh_step_forces(gh_ctx *ctx);
-int gh_step_end(gh_ctx *ctx, double *t, double *timestep);
 /* device pointer of a field's tree-ordered storage: component k of a vector field, k=0 for scalars */
 void *gh_field_dev(gh_ctx *ctx, int field, int k);
 

@@ -1,6 +1,10 @@
-"""Sharded (multi-rank) stepping must give bit-identical results to single-rank stepping: two ranks
-share GPU 0 and exchange their slices over gloo (RCCL refuses two ranks on one device; the exchange
-code path is otherwise the same as with backend nccl)."""
+"""Domain-decomposed multi-rank runs (gandalf_amd/csrc/comm.hip) against the single-rank run of the same problem.
+Two / four ranks share GPU 0 and use gloo as the transport (RCCL refuses two ranks on one device; the library-side
+code - decomposition, migration, halo selection, pack / unpack - is the same whatever carries the bytes).
+
+Every rank owns one top-level cell of the SAME global KD-tree (exact distributed median splits) and imports the halo
+its walks need, so the per-particle results must equal the single-rank ones to rounding - and do so bit for bit."""
+import json
 import os
 import socket
 import subprocess
@@ -13,25 +17,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
-import os, sys
+import json, os, sys
 import numpy as np
 import torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from gandalf_amd.host import Simulation
-from gandalf_amd.multigpu import ShardedRunner
-case, out = sys.argv[2], sys.argv[3]
+from gandalf_amd.multigpu import DistributedRunner
+case, out, nsteps = sys.argv[2], sys.argv[3], int(sys.argv[4])
+over = json.loads(sys.argv[5])
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
-sim = Simulation(os.path.join(sys.argv[1], "tests", "params", case + ".dat"))
+sim = Simulation(os.path.join(sys.argv[1], "tests", "params", case + ".dat"), **over)
 sim.generate_ic()
-run = ShardedRunner(sim, rank, world)
+run = DistributedRunner(sim, rank, world)
 run.setup()
-run.steps(2)
-dev = sim.device()
+run.steps(nsteps)
+res = {k: run.gather(k) for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot")}
+own_first, own_count, held = run.dev.comm_info()
+info = np.array([own_count, held, sim.t, sim.timestep])
+if world > 1:
+    allinfo = [None]*world
+    dist.all_gather_object(allinfo, info.tolist())
+    info = np.array(allinfo)
 if rank == 0:
-    np.savez(out, **{k: dev.download(k) for k in ("r", "v", "h", "rho", "a", "u", "dudt")})
+    np.savez(out, info=info, **res)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 '''
@@ -42,20 +53,61 @@ def _port():
     return p
 
 
-@pytest.mark.parametrize("case", ["plummer_4k", "box3d_4k"])
-def test_two_ranks_equal_one_rank(case, tmp_path):
+def _run(tmp_path, case, world, nsteps, over):
     wf = tmp_path/"worker.py"
     wf.write_text(WORKER)
-    outs = {}
-    for world in (1, 2):
-        out = str(tmp_path/("w%d.npz" % world))
-        port = _port()
-        procs = []
-        for r in range(world):
-            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, str(wf), ROOT, case, out], env=env))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
-        outs[world] = dict(np.load(out))
-    for k in outs[1]:
-        assert np.array_equal(outs[1][k], outs[2][k]), k
+    out = str(tmp_path/("w%d.npz" % world))
+    port = _port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(wf), ROOT, case, out, str(nsteps), json.dumps(over)], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return dict(np.load(out))
+
+
+def _relerr(a, b):
+    """max |a - b| relative to max(|a_i|, mean |a|); 0 for two all-zero arrays (gpot of a hydro-only run)"""
+    mag = np.abs(a) if a.ndim == 1 else np.linalg.norm(a, axis=1)
+    scale = np.maximum(mag, mag.mean())
+    if not np.any(scale > 0):
+        return float(np.max(np.abs(b)))
+    diff = np.abs(a - b) if a.ndim == 1 else np.linalg.norm(a - b, axis=1)
+    return float(np.max(diff/scale))
+
+
+CASES = {
+    "gravity": ("plummer_4k", {}),                                         # hydro + self-gravity (tree walk with MAC)
+    "hydro": ("plummer_4k", {"self_gravity": 0, "run_id": "PLUMHYD"}),      # hydro only (scatter-gather walk)
+}
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_ranks_equal_one_rank(case, world, tmp_path):
+    par, over = CASES[case]
+    one = _run(tmp_path, par, 1, 3, over)
+    many = _run(tmp_path, par, world, 3, over)
+    assert many["info"].shape == (world, 4)
+    assert np.all(many["info"][:, 2] == one["info"][2]) and np.all(many["info"][:, 3] == one["info"][3])      # t, dt
+    for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot"):
+        a, b = one[k], many[k]
+        assert np.all(np.isfinite(b)), k
+        assert _relerr(a, b) <= 1e-13, (k, _relerr(a, b))
+
+
+def test_ranks_hold_only_their_share(tmp_path):
+    """65 536-particle Plummer sphere on 2 and 4 ranks: every rank owns N / world particles and holds, with the imported
+    halo, well under the whole set (the replicated scheme of round 1 held N on every rank)"""
+    N = 65536
+    over = {"Nhydro": N, "run_id": "PLUM64K"}
+    one = _run(tmp_path, "plummer_4k", 1, 1, over)
+    for world in (2, 4):
+        many = _run(tmp_path, "plummer_4k", world, 1, over)
+        own, held = many["info"][:, 0], many["info"][:, 1]
+        assert np.all(own == N//world)
+        assert np.all(held < 0.7*N), held
+        for k in ("rho", "a", "gpot"):
+            a, b = one[k], many[k]
+            assert _relerr(a, b) <= 1e-13, k
