@@ -43,7 +43,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_particles", C.c_int64), ("n_iterations", C.c_int64), ("n_candidates", C.c_int64),
                 ("n_direct", C.c_int64), ("n_cells", C.c_int64), ("n_retries", C.c_int64),
-                ("kernel_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("n_leaf_cells", C.c_int64), ("n_leaf_direct", C.c_int64), ("n_leaf_cand", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -92,9 +92,10 @@ static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
   gh_stats loc;
   memset(&loc, 0, sizeof(loc));
   loc.n_particles = ctx->N;
-  loc.n_iterations = (int64_t) hs[ST_ITER];
+  loc.n_iterations = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_ITER] : 0;
   loc.n_candidates = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_CAND] : (int64_t) hs[ST_PAIRS];
-  loc.n_retries = (int64_t) hs[ST_RETRY];
+  loc.n_retries = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_RETRY] : 0;
+  if (phase != GH_T_SPH_PROPERTIES) { loc.n_leaf_cells = (int64_t) hs[ST_ITER]; loc.n_leaf_direct = (int64_t) hs[ST_RETRY]; loc.n_leaf_cand = (int64_t) hs[ST_CAND]; }
   loc.n_direct = phase == GH_T_SPH_PROPERTIES ? (int64_t) hs[ST_PAIRS] : (int64_t) hs[ST_DIRECT];   // density: candidate slots tested
   loc.n_cells = (int64_t) hs[ST_CELLS];
   loc.kernel_ms = ctx->dom_calls[phase] ? ctx->dom_ms[phase]/ctx->dom_calls[phase] : 0.0;

@@ -28,10 +28,12 @@
 #include "gh_internal.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #define DD_G 2048            /* histogram bins per refinement of a median search */
 #define DD_CAPL 2048         /* candidates per rank and cell gathered in the final bin */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
+#define DD_FMAX 4            /* halo selection: 2^F fine geometry entries per published bottom cell */
 #define DD_REC 43            /* doubles per migrating particle: D_COUNT_BASE fields + iorig */
 
 double *gh_time_dev(gh_ctx *ctx);
@@ -46,6 +48,7 @@ struct DDCell {                      // one cell of the level being split (devic
   double rdiv; int rdiv_id, pad;     // the split: first particle of the right half in (coordinate, id) order
 };
 struct DDCand { double key; int id, pad; };
+struct LetGeom;
 
 struct gh_dd {
   gh_comm_ops ops;
@@ -62,6 +65,9 @@ struct gh_dd {
   double *mig_send = nullptr, *mig_recv = nullptr;   // [own_count][DD_REC]
   // published subtree tops
   char *pub_send = nullptr, *pub_recv = nullptr; size_t pub_bytes = 0;
+  int F = 0;                         // fine entries: 2^F per published bottom cell
+  double fine_widen = 1.0;           // the density widening the gathered fine table was built with
+  LetGeom *fine = nullptr, *fine_all = nullptr;      // [2^(P+F)] own, [nranks][2^(P+F)] everybody's
   // locally essential tree
   int *let_cnt = nullptr;            // [2*MAX] cells / leaves marked per destination, then [2*MAX] received per source
   long long *let_off = nullptr;      // [2*MAX] send / receive block offsets in doubles
@@ -287,6 +293,77 @@ __global__ void k_mig_unpack(MigTab t, int *iorig, int narr, const int *hole, co
 // ------------------------------------------------------------------------------------------------
 struct PubRec { CellBox b; CellH h; CellGeo g; CellCom c; CellQuad q; };      // 288 bytes
 
+// Geometry of one cell of the destination rank as the halo selection sees it: the cell's boxes plus the largest leaf
+// reach below it.  Every rank publishes this for the 2^(P+F) cells F levels below its published bottom cells ("fine"
+// entries, all-gathered with the subtree tops); the opening tests run against a published bottom cell first and, where
+// that says "open", against its 2^F fine entries.  The gravity walk tests every LEAF with the leaf's own rmax and hmax
+// (Tree.cpp:659-672), so the bounds that matter are maxima over leaves - and they must be local: in a Plummer halo one
+// 1000-particle cell spans smoothing lengths from 0.3 to 2, and its innermost corner combined with its outermost
+// leaf's reach would "need" the whole core.  Hence the two boxes around the leaves' own balls (rb*, cb*).
+struct LetGeom {
+  double bbmin[3], bbmax[3], hbmin[3], hbmax[3];
+  double rbmin[3], rbmax[3];          // box around the leaves' balls of radius rmax + kernrange*hmax about their centres
+  double cbmin[3], cbmax[3];          // ... of radius rmax
+  double dbmin[3], dbmax[3];          // box around the density search boxes of its particle groups (group box -/+ kernrange*1.05^2*hmax*widen)
+  double hmax;
+  int N, pad;
+};
+
+__global__ __launch_bounds__(256) void k_pub_fine(DevicePtrs d, int L, int PF, int rank, double kernrange, double widen, LetGeom *out)
+{
+  __shared__ double s_red[4][18];
+  const int j = blockIdx.x;
+  const int n = (1 << (L + PF)) - 1 + (rank << PF) + j;
+  const int nl = 1 << (d.ltot - L - PF);                // leaves below fine cell j of this rank
+  const int leaf0 = (d.gtot - 1) + ((rank << PF) + j)*nl;
+  double v[18];                                         // rbmin, cbmin (as minima), -rbmax, -cbmax (maxima, negated), dbmin, -dbmax
+  for (int k = 0; k < 18; k++) v[k] = 9.9e20;
+  {
+    // density search boxes of the particle groups below this cell (k_dens_walk: group box -/+ kernrange * 1.05 * hmax,
+    // one retry of the reference's 1.05 growth included; `widen` grows with the retries of gh_density_impl)
+    const int ng = 1 << (d.lgroup - L - PF);
+    const int g0 = (1 << d.lgroup) - 1 + ((rank << PF) + j)*ng;
+    for (int t = threadIdx.x; t < ng; t += blockDim.x) {
+      const CellBox gb = d.cbox[g0 + t];
+      if (gb.N > 0) {
+        const double rs = kernrange*d.ch[g0 + t].hmax*(1.05*1.05)*widen*(1.0 + 1e-12);
+        for (int k = 0; k < 3; k++) { v[12 + k] = fmin(v[12 + k], gb.bbmin[k] - rs); v[15 + k] = fmin(v[15 + k], -(gb.bbmax[k] + rs)); }
+      }
+    }
+  }
+  for (int t = threadIdx.x; t < nl; t += blockDim.x) {
+    const CellGeo g = d.cgeo[leaf0 + t];
+    if (g.N > 0) {
+      const double r1 = g.rmax + kernrange*g.hmax, r2 = g.rmax;
+      for (int k = 0; k < 3; k++) {
+        v[k] = fmin(v[k], g.rcell[k] - r1); v[3 + k] = fmin(v[3 + k], g.rcell[k] - r2);
+        v[6 + k] = fmin(v[6 + k], -(g.rcell[k] + r1)); v[9 + k] = fmin(v[9 + k], -(g.rcell[k] + r2));
+      }
+    }
+  }
+  for (int k = 0; k < 18; k++) {
+    double x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x = fmin(x, __shfl_xor(x, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const CellBox cb = d.cbox[n]; const CellH ch = d.ch[n];
+    LetGeom q;
+    for (int k = 0; k < 3; k++) {
+      q.bbmin[k] = cb.bbmin[k]; q.bbmax[k] = cb.bbmax[k]; q.hbmin[k] = ch.hbmin[k]; q.hbmax[k] = ch.hbmax[k];
+      q.rbmin[k] = fmin(fmin(s_red[0][k], s_red[1][k]), fmin(s_red[2][k], s_red[3][k]));
+      q.cbmin[k] = fmin(fmin(s_red[0][3 + k], s_red[1][3 + k]), fmin(s_red[2][3 + k], s_red[3][3 + k]));
+      q.rbmax[k] = -fmin(fmin(s_red[0][6 + k], s_red[1][6 + k]), fmin(s_red[2][6 + k], s_red[3][6 + k]));
+      q.cbmax[k] = -fmin(fmin(s_red[0][9 + k], s_red[1][9 + k]), fmin(s_red[2][9 + k], s_red[3][9 + k]));
+      q.dbmin[k] = fmin(fmin(s_red[0][12 + k], s_red[1][12 + k]), fmin(s_red[2][12 + k], s_red[3][12 + k]));
+      q.dbmax[k] = -fmin(fmin(s_red[0][15 + k], s_red[1][15 + k]), fmin(s_red[2][15 + k], s_red[3][15 + k]));
+    }
+    q.hmax = ch.hmax; q.N = cb.N; q.pad = 0;
+    out[j] = q;
+  }
+}
+
 __global__ void k_pub_pack(DevicePtrs d, int L, int P, int rank, PubRec *out)
 {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
@@ -308,10 +385,10 @@ __global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, c
   const int t = blockIdx.x*blockDim.x + threadIdx.x;
   if (t >= ncell*nranks) return;
   const int r = t/ncell, e = t - r*ncell;
-  if (r == self) return;
   int p = 0;
   while (e >= (2 << p) - 1) p++;
   const int j = e - ((1 << p) - 1);
+  if (r == self) return;
   const int n = (1 << (L + p)) - 1 + (r << p) + j;
   const PubRec &q = all[t];
   d.cbox[n] = q.b; d.ch[n] = q.h; d.cgeo[n] = q.g; d.ccom[n] = q.c;
@@ -321,26 +398,22 @@ __global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, c
 // ------------------------------------------------------------------------------------------------
 // locally essential tree
 // ------------------------------------------------------------------------------------------------
-struct LetGeom {                      // what the opening tests need of a published cell of the destination rank
-  double bbmin[3], bbmax[3], hbmin[3], hbmax[3], rcell[3], rmax, hmax;
-  int N, pad;
-};
-
 // Could a walk of any leaf cell / particle group below the destination's published cell Q open cell Y (visit its
 // children; for a leaf: touch its particles)?  Conservative restatements of
 //   density : Tree::ComputeGatherNeighbourList (Tree.cpp:319-328) with the search radius kernrange*hmax*1.05^2
 //             (first try and one retry of GradhSphTree.cpp:141-226; a walk that needs more raises FLAG_LET_MISS);
 //   hydro   : Tree::ComputeNeighbourAndGhostList (Tree.cpp:579-580): overlap(bb, other.hbox) || overlap(hbox, other.bb);
 //   gravity : Tree::ComputeGravityInteractionAndGhostList (Tree.cpp:659-700) + open_cell_for_gravity (Tree.h:413-432,
-//             geometric MAC): leaf centres lie inside Q's box, leaf rmax <= Q.rmax, leaf hmax <= Q.hmax.
+//             geometric MAC): a leaf opens Y if their centres are within Y.rmax + leaf.rmax + kernrange*max(leaf.hmax, Y.hmax)
+//             - tested as "Y's ball reaches the box around the leaves' balls" - or closer than Y's opening distance
+//             (leaf centres lie inside Q's box).
 template <int PHASE>
 __device__ __forceinline__ bool let_may_open(const LetGeom &Q, const CellBox &yb, const CellH &yh, const CellGeo &yg,
                                              int ndim, double kernrange, double widen)
 {
   if (Q.N <= 0) return false;
   if (PHASE == GH_HALO_DENSITY) {
-    const double rs = kernrange*Q.hmax*(1.05*1.05)*widen*(1.0 + 1e-12);
-    for (int k = 0; k < ndim; k++) if (Q.bbmin[k] - rs > yb.bbmax[k] || yb.bbmin[k] > Q.bbmax[k] + rs) return false;
+    for (int k = 0; k < ndim; k++) if (Q.dbmin[k] > yb.bbmax[k] || yb.bbmin[k] > Q.dbmax[k]) return false;
     return true;
   }
   if (PHASE == GH_HALO_HYDRO) {
@@ -351,34 +424,48 @@ __device__ __forceinline__ bool let_may_open(const LetGeom &Q, const CellBox &yb
     }
     return o1 || o2;
   }
-  // gravity: distance from Y's centre to Q's box bounds every leaf-centre distance from below
-  double d2 = 0.0;
+  double dr2 = 0.0, dc2 = 0.0, db2 = 0.0;            // squared distance of Y's centre from the three boxes
   for (int k = 0; k < ndim; k++) {
-    const double g = fmax(fmax(Q.bbmin[k] - yg.rcell[k], yg.rcell[k] - Q.bbmax[k]), 0.0);
-    d2 += g*g;
+    const double gr = fmax(fmax(Q.rbmin[k] - yg.rcell[k], yg.rcell[k] - Q.rbmax[k]), 0.0);
+    const double gc = fmax(fmax(Q.cbmin[k] - yg.rcell[k], yg.rcell[k] - Q.cbmax[k]), 0.0);
+    const double gb = fmax(fmax(Q.bbmin[k] - yg.rcell[k], yg.rcell[k] - Q.bbmax[k]), 0.0);
+    dr2 += gr*gr; dc2 += gc*gc; db2 += gb*gb;
   }
-  d2 *= (1.0 - 1e-12);
-  const double ov = (yg.rmax + Q.rmax + kernrange*fmax(Q.hmax, yg.hmax))*(1.0 + 1e-12);
-  return d2 <= ov*ov || d2 < yg.cdistsqd;
+  const double e = 1.0 + 1e-12;
+  const double r1 = yg.rmax*e, r2 = (yg.rmax + kernrange*yg.hmax)*e;
+  return dr2 <= r1*r1*e || dc2 <= r2*r2*e || db2*(1.0 - 1e-12) < yg.cdistsqd;
 }
 
 // grid (2^P, nranks): workgroup (j, r) marks what rank r needs of the subtree below this rank's published bottom
 // cell j, level by level with the visit flags in LDS
 template <int PHASE>
-__global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int self, double kernrange, double widen,
+__global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const LetGeom *fine_all,
                                                   int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags)
 {
   const int r = blockIdx.y;
   if (r == self) return;
   __shared__ LetGeom s_q[1 << DD_PMAX];
   __shared__ unsigned char s_vis[2][2048];
-  const int nq = 1 << P;
+  const int nq = 1 << P, nf = 1 << F;
+  const LetGeom *fine = fine_all + ((size_t) r << (P + F));
   if ((int) threadIdx.x < nq) {
-    const int n = (1 << (L + P)) - 1 + (r << P) + threadIdx.x;
-    const CellBox b = d.cbox[n]; const CellH h = d.ch[n]; const CellGeo g = d.cgeo[n];
-    LetGeom q;
-    for (int k = 0; k < 3; k++) { q.bbmin[k] = b.bbmin[k]; q.bbmax[k] = b.bbmax[k]; q.hbmin[k] = h.hbmin[k]; q.hbmax[k] = h.hbmax[k]; q.rcell[k] = g.rcell[k]; }
-    q.rmax = g.rmax; q.hmax = h.hmax; q.N = b.N; q.pad = 0;
+    // published bottom cell of the destination = union of its fine entries
+    LetGeom q = fine[(size_t) threadIdx.x*nf];
+    for (int f = 1; f < nf; f++) {
+      const LetGeom &e = fine[(size_t) threadIdx.x*nf + f];
+      if (e.N <= 0) continue;
+      if (q.N <= 0) { q = e; continue; }
+      for (int k = 0; k < 3; k++) {
+        q.bbmin[k] = fmin(q.bbmin[k], e.bbmin[k]); q.bbmax[k] = fmax(q.bbmax[k], e.bbmax[k]);
+        q.hbmin[k] = fmin(q.hbmin[k], e.hbmin[k]); q.hbmax[k] = fmax(q.hbmax[k], e.hbmax[k]);
+      }
+      for (int k = 0; k < 3; k++) {
+        q.rbmin[k] = fmin(q.rbmin[k], e.rbmin[k]); q.rbmax[k] = fmax(q.rbmax[k], e.rbmax[k]);
+        q.cbmin[k] = fmin(q.cbmin[k], e.cbmin[k]); q.cbmax[k] = fmax(q.cbmax[k], e.cbmax[k]);
+        q.dbmin[k] = fmin(q.dbmin[k], e.dbmin[k]); q.dbmax[k] = fmax(q.dbmax[k], e.dbmax[k]);
+      }
+      q.hmax = fmax(q.hmax, e.hmax); q.N += e.N;
+    }
     s_q[threadIdx.x] = q;
   }
   const int depth = d.ltot - (L + P);                    // levels below the published bottom cell
@@ -400,7 +487,10 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
         const CellBox yb = d.cbox[n];
         if (yb.N > 0) {
           const CellH yh = d.ch[n]; const CellGeo yg = d.cgeo[n];
-          for (int qi = 0; qi < nq && !open; qi++) open = let_may_open<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen);
+          for (int qi = 0; qi < nq && !open; qi++) {
+            if (!let_may_open<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen)) continue;
+            for (int f = 0; f < nf && !open; f++) open = let_may_open<PHASE>(fine[(size_t) qi*nf + f], yb, yh, yg, d.ndim, kernrange, widen);
+          }
         }
       }
       if (!leaflevel && k < nn) { s_vis[cur ^ 1][2*k] = open; s_vis[cur ^ 1][2*k + 1] = open; }
@@ -568,7 +658,7 @@ void gh_dd_free(gh_ctx *ctx)
   gh_dd *D = ctx->dd;
   if (!D) return;
   void *ptrs[] = {D->topcell, D->cells, D->hist, D->hist_all, D->cand, D->cand_all, D->box6, D->box6_all, D->mig_cnt, D->mig_slot,
-                  D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
+                  D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
                   D->let_send, D->let_recv, D->dt_all};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   delete D;
@@ -598,6 +688,9 @@ static int dd_alloc(gh_ctx *ctx)
   D->pub_bytes = sizeof(PubRec)*(size_t) ((2 << D->P) - 1);
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_send, D->pub_bytes));
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_recv, D->pub_bytes*W));
+  D->F = std::max(0, std::min(DD_FMAX, ctx->lgroup - ctx->L - D->P));
+  GH_CHECK(ctx, hipMalloc((void**) &D->fine, sizeof(LetGeom)*((size_t) 1 << (D->P + D->F))));
+  GH_CHECK(ctx, hipMalloc((void**) &D->fine_all, sizeof(LetGeom)*((size_t) W << (D->P + D->F))));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cnt, sizeof(int)*8*GH_MAX_RANKS));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_off, sizeof(long long)*2*GH_MAX_RANKS));
   // a rank can need, at most, all of another rank's subtree
@@ -673,6 +766,18 @@ int gh_dd_decompose(gh_ctx *ctx)
   return GH_OK;
 }
 
+// the ranks' fine geometry tables (what the halo selection tests against)
+static int dd_publish_fine(gh_ctx *ctx, double widen)
+{
+  gh_dd *D = ctx->dd;
+  const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
+  const int PF = D->P + D->F;
+  hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->L, PF, ctx->rank, kr, widen, D->fine);
+  DD_OP(ctx, dd_allgather(ctx, D->fine, D->fine_all, sizeof(LetGeom)*((size_t) 1 << PF)));
+  D->fine_widen = widen;
+  return GH_OK;
+}
+
 // all-gather of the top P levels of every rank's subtree, then the levels above the ranks' cells
 int gh_dd_publish(gh_ctx *ctx, int hmax_only)
 {
@@ -680,6 +785,8 @@ int gh_dd_publish(gh_ctx *ctx, int hmax_only)
   const int W = ctx->nranks, L = ctx->L, P = D->P;
   const int ncell = (2 << P) - 1;
   DevicePtrs d = gh_dev(ctx);
+  const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
+  { const int rc = dd_publish_fine(ctx, 1.0); if (rc) return rc; }
   hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->pub_send);
   DD_OP(ctx, dd_allgather(ctx, D->pub_send, D->pub_recv, D->pub_bytes));
   hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, (const PubRec*) D->pub_recv);
@@ -720,12 +827,13 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   DevicePtrs d = gh_dev(ctx);
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
   if (ctx->ltot - (L + P) > 11) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU: subtree below the published levels deeper than 11 levels");
+  if (phase == GH_HALO_DENSITY && widen != D->fine_widen) { const int rc = dd_publish_fine(ctx, widen); if (rc) return rc; }
   hipLaunchKernelGGL(k_let_invalidate, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, s, d, L, P, ctx->rank, ctx->Ncell);
   GH_CHECK(ctx, hipMemsetAsync(D->let_cnt, 0, sizeof(int)*8*GH_MAX_RANKS, s));
   const dim3 grid(1 << P, W);
-  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, ctx->rank, kr, widen, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, ctx->rank, kr, widen, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, ctx->rank, kr, widen, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
   // counts to everybody (2 ints per pair), then sizes on the host
   DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*2*GH_MAX_RANKS));
   std::vector<int> all((size_t) W*2*GH_MAX_RANKS);
@@ -749,6 +857,12 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
     nimp += (long long) il*lay.occ;
   }
   if (phase != GH_HALO_DENSITY) D->held_particles = ctx->own_count + nimp;
+  if (getenv("GH_DD_DEBUG")) {
+    fprintf(stderr, "[dd] rank %d phase %d widen %.1f:", ctx->rank, phase, widen);
+    for (int r = 0; r < W; r++) if (r != ctx->rank) fprintf(stderr, "  to %d: %d cells %d leaves | from %d: %d cells %d leaves", r,
+        all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r], all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r + 1], r, rcnt[2*r], rcnt[2*r + 1]);
+    fprintf(stderr, "  (subtree: %d cells, %d leaves)\n", 2*(ctx->gtot >> L) - 1, ctx->gtot >> L);
+  }
   auto grow = [&](char **p, size_t *have, size_t need) -> hipError_t {
     if (need <= *have) return hipSuccess;
     if (*p) (void) hipFree(*p);

@@ -249,9 +249,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
           {
 #pragma clang fp contract(fast)
             const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
-            rho += mj*K::t_w0s2(s2, P.ktab);
-            omg += mj*invh*K::t_womegas2(s2, P.ktab);
-            zet += mj*K::t_wzetas2(s2, P.ktab);
+            double kw0, kwom, kwz;
+            K::t_dens3(s2, P.ktab, kw0, kwom, kwz);
+            rho += mj*kw0;
+            omg += mj*invh*kwom;
+            zet += mj*kwz;
           }
         }
       }
@@ -394,7 +396,7 @@ struct DensLists {
 };
 
 template <int ND, int KT>
-__global__ __launch_bounds__(64) void k_dens_walk(DevicePtrs d, DensityParams P, DensLists G, int *flags)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_dens_walk(DevicePtrs d, DensityParams P, DensLists G, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
@@ -438,8 +440,16 @@ __global__ __launch_bounds__(64) void k_dens_walk(DevicePtrs d, DensityParams P,
   const unsigned int codes = image_codes(P.dom, ND, lo, hi);
   const double rs2cut = (K::kernrange*hs)*(K::kernrange*hs)*(1.0 + 1e-12);
   int top = 0;
-  for (int c = 0; c < 27; c++) {
-    if (codes & (1u << c)) { if (lane == 0) s_stack[top] = 0 | (c << GH_NODE_BITS); top++; }
+  if (codes == 1u && d.lgroup >= 6) {
+    // no periodic / mirror images: start from the 64 cells of level 6 instead of the root - the first pop classifies
+    // them side by side instead of descending six levels one dependent cell load at a time
+    s_stack[lane] = 63 + lane;
+    top = 64;
+  }
+  else {
+    for (int c = 0; c < 27; c++) {
+      if (codes & (1u << c)) { if (lane == 0) s_stack[top] = 0 | (c << GH_NODE_BITS); top++; }
+    }
   }
   __syncthreads();
   int nout = 0;
@@ -521,20 +531,22 @@ __global__ __launch_bounds__(64) void k_dens_walk(DevicePtrs d, DensityParams P,
 
 #define GH_DENS_RCAP 512   /* candidate ranges per group held by the split path */
 #define DBE 2     /* candidate tiles per phase-2 batch of the evaluation kernel */
+#define GH_DENS_ICAP 1536   /* candidate slots of one group held in LDS as particle indices */
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 template <int ND, bool COUNT, int KT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
                                                                                        unsigned long long *stats, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
-  __shared__ RangeRing s_ring;
-  __shared__ int s_pre[64];
+  __shared__ int s_idx[GH_DENS_ICAP];                      // particle index | image code << GH_NODE_BITS, -1 = padding
   __shared__ double s_x[DBE*64], s_y[DBE*64], s_z[DBE*64], s_m[DBE*64];
   __shared__ unsigned long long s_mask[DBE][64];
-  __shared__ __attribute__((aligned(8))) float s_fx[64], s_fy[64], s_fz[64];
+  // current tile in fp32, relative to the group centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
+  // records: one 16-byte + one 8-byte LDS read feed two packed-fp32 distance evaluations)
+  __shared__ __attribute__((aligned(16))) float s_f[32][8];
 
   const int lane = threadIdx.x;
-  const unsigned long long lt = lanemask_lt();
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
@@ -542,6 +554,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const int nr = G.rlen[q];
   const bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
   if (!__any(act)) return;
+
+  // ---- the group's candidate ranges are expanded into a flat index list in LDS, GH_DENS_ICAP slots at a time: the
+  //      tile loop then knows every address in advance (the next tile's records are in flight while the current one
+  //      is culled).  Most groups fit in one fill, which is then kept for all h iterations.
+  const int2 *rl = G.rl + (size_t) q*G.rcap;
+  int c0 = 0, ntot = 0;
+  bool whole = false;
+  // returns false if a single chunk of 64 ranges does not fit (whole subtrees inside the search box: a halo group whose
+  // kernels cover the core) - the fused kernel streams those
+  auto fill = [&]() -> bool {
+    ntot = 0;
+    const int cstart = c0;
+    while (c0 < nr) {
+      const int e = c0 + lane;
+      int2 ent = make_int2(0, 0);
+      if (e < nr) ent = rl[e];
+      const int first = ent.x & GH_NODE_MASK, code = ent.x >> GH_NODE_BITS, cnt = ent.y;
+      int inc = cnt;
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+      const int excl = inc - cnt, tot = __shfl(inc, 63, 64);
+      if (ntot + tot > GH_DENS_ICAP) {
+        if (ntot == 0) return false;
+        break;
+      }
+      const bool big = cnt > 8;
+      if (!big) for (int k = 0; k < cnt; k++) s_idx[ntot + excl + k] = (first + k) | (code << GH_NODE_BITS);
+      unsigned long long bm = __ballot(big);               // whole subtrees inside the search box: the wave writes them together
+      while (bm) {
+        const int src = __ffsll((long long) bm) - 1;
+        bm &= bm - 1ull;
+        const int f = __shfl(first, src, 64), c = __shfl(cnt, src, 64), o = __shfl(excl, src, 64), cd = __shfl(code, src, 64);
+        for (int k = lane; k < c; k += 64) s_idx[ntot + o + k] = (f + k) | (cd << GH_NODE_BITS);
+      }
+      ntot += tot;
+      c0 += 64;
+    }
+    const int padded = (ntot + 63) & ~63;
+    if (ntot + lane < padded) s_idx[ntot + lane] = -1;
+    whole = cstart == 0 && c0 >= nr;
+    __syncthreads();
+    return true;
+  };
+
   const int i = gfirst + (act ? lane : 0);
   const double invndim = 1.0/(double) ND;
   double ri[3] = {0.0, 0.0, 0.0};
@@ -570,7 +625,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     double hs = wave_max(act ? hmaxl : 0.0);
     for (int k = 0; k < ND; k++) Rmax = fmax(Rmax, 0.5*(gb.bbmax[k] - gb.bbmin[k]) + K::kernrange*hs);
   }
-  const int2 *rl = G.rl + (size_t) q*G.rcap;
+  const bool images = P.dom.periodic[0] | P.dom.periodic[1] | P.dom.periodic[2] | P.dom.mirror[0][0] | P.dom.mirror[0][1] |
+                      P.dom.mirror[1][0] | P.dom.mirror[1][1] | P.dom.mirror[2][0] | P.dom.mirror[2][1];
 
   for (;;) {
     const bool running = !done;
@@ -605,76 +661,91 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
           {
 #pragma clang fp contract(fast)
             const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
-            rho += mj*K::t_w0s2(s2, P.ktab);
-            omg += mj*invh*K::t_womegas2(s2, P.ktab);
-            zet += mj*K::t_wzetas2(s2, P.ktab);
+            double kw0, kwom, kwz;
+            K::t_dens3(s2, P.ktab, kw0, kwom, kwz);
+            rho += mj*kw0;
+            omg += mj*invh*kwom;
+            zet += mj*kwz;
           }
         }
       }
       __syncthreads();
       nb = 0;
     };
-    auto tile = [&](bool valid, int j, int code) {
-      const int o = nb*64;
-      {
-        double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
-        if (valid) {
-          const double4 v = d.posm[j];
-          double sg[3], sh[3];
-          code_xform(P.dom, code, sg, sh);
-          x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2]; m = v.w;
-        }
-        s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
-        s_fx[lane] = (float) (x - gc[0]); s_fy[lane] = ND > 1 ? (float) (y - gc[1]) : 0.f; s_fz[lane] = ND > 2 ? (float) (z - gc[2]) : 0.f;
-      }
-      __syncthreads();
-      unsigned int mlo = 0, mhi = 0;
-      {
-        const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]};
-        const float2_t *fx = (const float2_t*) s_fx, *fy = (const float2_t*) s_fy, *fz = (const float2_t*) s_fz;
-#pragma unroll 8
-        for (int c2 = 0; c2 < 32; c2++) {
-          const float2_t dx = fx[c2] - tx;
-          float2_t r2 = dx*dx;
-          if (ND > 1) { const float2_t dy = fy[c2] - ty; r2 = dy*dy + r2; }
-          if (ND > 2) { const float2_t dz = fz[c2] - tz; r2 = dz*dz + r2; }
-          const unsigned int bits = ((r2.x < thr) ? 1u : 0u) | ((r2.y < thr) ? 2u : 0u);
-          if (c2 < 16) mlo |= bits << (2*c2); else mhi |= bits << (2*c2 - 32);
+    // software pipeline over the tiles: record of tile t+1 loaded while tile t is staged and culled
+    if (!whole) c0 = 0;
+    for (bool first_fill = true; first_fill || c0 < nr; first_fill = false) {
+      if (!whole || ntot == 0) {
+        __syncthreads();
+        if (!fill()) {
+          if (lane == 0) G.fb[q] = 1;
+          return;
         }
       }
-      s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);
-      if (COUNT) {
-        if (running) {
-          for (int c = 0; c < 64; c++) {
-            double r2 = 0.0;
-            { const double dx = s_x[o + c] - ri[0]; r2 = dx*dx; }
-            if (ND > 1) { const double dy = s_y[o + c] - ri[1]; r2 += dy*dy; }
-            if (ND > 2) { const double dz = s_z[o + c] - ri[2]; r2 += dz*dz; }
-            if (r2 + GH_SMALL <= cullsqd) n_cand++;
+      const int ntiles = (ntot + 63) >> 6;
+      int idn = s_idx[lane];
+      double4 vn = d.posm[idn < 0 ? 0 : (idn & GH_NODE_MASK)];
+      for (int t = 0; t < ntiles; t++) {
+        const int id = idn;
+        double4 v = vn;
+        if (t + 1 < ntiles) {
+          idn = s_idx[(t + 1)*64 + lane];
+          vn = d.posm[idn < 0 ? 0 : (idn & GH_NODE_MASK)];
+        }
+        const int o = nb*64;
+        {
+          double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
+          if (id >= 0) {
+            x = v.x; y = v.y; z = v.z; m = v.w;
+            if (images) {
+              double sg[3], sh[3];
+              code_xform(P.dom, id >> GH_NODE_BITS, sg, sh);
+              x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2];
+            }
           }
-          n_tested += 64;
+          s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
+          s_f[lane >> 1][lane & 1] = (float) (x - gc[0]);
+          s_f[lane >> 1][2 + (lane & 1)] = ND > 1 ? (float) (y - gc[1]) : 0.f;
+          s_f[lane >> 1][4 + (lane & 1)] = ND > 2 ? (float) (z - gc[2]) : 0.f;
         }
-      }
-      nb++;
-      if (nb == DBE) process_batch();
-      else __syncthreads();
-    };
-    {
-      RangeState R; R.nrb = 0; R.nslots = 0;
-      for (int c0 = 0; c0 < nr; c0 += 64) {
-        const int e = c0 + lane;
-        int2 ent = make_int2(0, 0);
-        if (e < nr) ent = rl[e];
-        const unsigned long long vm = __ballot(ent.y > 0);
-        if (ent.y > 0) {
-          const int pos = R.nrb + __popcll(vm & lt);
-          s_ring.first[pos] = ent.x & GH_NODE_MASK; s_ring.cnt[pos] = ent.y; s_ring.tag[pos] = ent.x >> GH_NODE_BITS;
+        __syncthreads();
+        // support mask in packed fp32: dd = |r_c - r_i|^2 - thr from three packed FMAs per candidate pair; its sign bit
+        // (set = inside the conservative threshold) is shifted into the mask by one v_alignbit_b32 per candidate, so
+        // candidate c lands in bit 31 - (c & 31) of word c >> 5: the words are bit-reversed at the end.
+        unsigned int mlo = 0, mhi = 0;
+        {
+          const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]}, nthr = {-thr, -thr};
+#pragma unroll 8
+          for (int c2 = 0; c2 < 32; c2++) {
+            const float4_t xy = *((const float4_t*) &s_f[c2][0]);
+            const float2_t zz = *((const float2_t*) &s_f[c2][4]);
+            const float2_t dx = (float2_t) {xy.x, xy.y} - tx;
+            float2_t dd = __builtin_elementwise_fma(dx, dx, nthr);
+            if (ND > 1) { const float2_t dy = (float2_t) {xy.z, xy.w} - ty; dd = __builtin_elementwise_fma(dy, dy, dd); }
+            if (ND > 2) { const float2_t dz = zz - tz; dd = __builtin_elementwise_fma(dz, dz, dd); }
+            if (c2 < 16) { mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(dd.x), 31); mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(dd.y), 31); }
+            else { mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(dd.x), 31); mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(dd.y), 31); }
+          }
+          mlo = __brev(mlo); mhi = __brev(mhi);
         }
-        R.nrb += __popcll(vm);
-        R.nslots += wave_sum_i(ent.y);
-        range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, false, tile);
+        s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);
+        if (COUNT) {
+          if (running) {
+            for (int c = 0; c < 64; c++) {
+              double r2 = 0.0;
+              { const double dx = s_x[o + c] - ri[0]; r2 = dx*dx; }
+              if (ND > 1) { const double dy = s_y[o + c] - ri[1]; r2 += dy*dy; }
+              if (ND > 2) { const double dz = s_z[o + c] - ri[2]; r2 += dz*dz; }
+              if (r2 + GH_SMALL <= cullsqd) n_cand++;
+            }
+            n_tested += 64;
+          }
+        }
+        nb++;
+        if (nb == DBE) process_batch();
+        else __syncthreads();
       }
-      range_drain_raw(s_ring.first, s_ring.cnt, s_ring.tag, s_pre, R, true, tile);
+      if (whole) break;
     }
     process_batch();
 

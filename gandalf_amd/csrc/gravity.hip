@@ -427,6 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
   for (int i = 0; i < MAXOCC; i++) { for (int k = 0; k < 3; k++) acc[i].at[k] = 0.0; acc[i].gpot = 0.0; }
   unsigned long long n_cells = 0, n_direct = 0, n_pairs = 0;
+  unsigned long long n_lcell = 0, n_ldir = 0, n_lcand = 0;     // what the wave LOADS: list entries / particles, once per leaf
 
   // ---- accepted cells: monopole terms                            (NeighbourSearch.h:350-377)
   // two-level gather (node id from the list, then the 32-byte COM record from the L2-resident table):
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         vcur = vnext; id2 = idfix(id3, c0 + 128);
       }
     }
-    if (COUNT) n_cells += (unsigned long long) ltot_*Nt;      // counted once per wave below
+    if (COUNT) { n_cells += (unsigned long long) ltot_*Nt; n_lcell += (unsigned long long) ltot_; }      // counted once per wave below
   }
   // ---- direct-only leaves: Newtonian particle terms              (GradhSph.cpp:671-686)
   for (int c0 = 0; c0 < lend; c0 += 64) {
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       const double mk = k < pn ? v.w : 0.0;
 #pragma unroll
       for (int i = 0; i < MAXOCC; i++) point_mass_pm<ND>(s_tg[i], acc[i], v.x, v.y, v.z, mk);
-      if (COUNT) n_direct += (k < pn) ? Nt : 0;
+      if (COUNT) { n_direct += (k < pn) ? Nt : 0; n_ldir += (k < pn) ? 1 : 0; }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+v"(vn.x), "+v"(vn.y), "+v"(vn.z), "+v"(vn.w));
       v = vn;
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     double4 q0 = r[0];
     double hr2 = r[1].w;
     if (!valid) { q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0; }
+    if (COUNT) n_lcand += valid ? 1 : 0;
     hyd_process(valid, j, q0, hr2);
   };
   {
@@ -853,7 +855,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     atomicAdd(&stats[ST_CELLS], n_cells);
     atomicAdd(&stats[ST_PAIRS], n_pairs);
   }
-  if (COUNT) { const unsigned long long b = wave_sum_u64(n_direct); if (lane == 0) atomicAdd(&stats[ST_DIRECT], b); }
+  if (COUNT) {
+    const unsigned long long b = wave_sum_u64(n_direct), c = wave_sum_u64(n_ldir), e = wave_sum_u64(n_lcand);
+    if (lane == 0) { atomicAdd(&stats[ST_DIRECT], b); atomicAdd(&stats[ST_ITER], n_lcell); atomicAdd(&stats[ST_RETRY], c); atomicAdd(&stats[ST_CAND], e); }
+  }
 }
 
 // ================================================================================================

@@ -137,6 +137,24 @@ template <int ND> struct M4 {
   __device__ static __forceinline__ double t_w0s2(double s2, const double *) { return w0(gh_fast_sqrt(s2)); }
   __device__ static __forceinline__ double t_womegas2(double s2, const double *) { return womega(gh_fast_sqrt(s2)); }
   __device__ static __forceinline__ double t_wzetas2(double s2, const double *) { return wzeta(gh_fast_sqrt(s2)); }
+  // The three density-pass functions of one s^2 together, branch-free: with a = max(2 - s, 0), b = max(1 - s, 0) the
+  // piecewise polynomials above are exactly
+  //   w0 = norm (a^3/4 - b^3),   w1 = norm (3 b^2 - 3/4 a^2),   womega = -(ND w0 + s w1),
+  //   wzeta = a^4 (0.1 + 0.2 s) - b^4 (0.2 + 0.8 s)
+  // (expand for s < 1 and 1 <= s < 2).  One square root, ~20 fused operations and no divergent branch per pair instead
+  // of three two-sided branches; values agree with the forms above to a few ulp of the kernel's maximum.
+  __device__ static __forceinline__ void t_dens3(double s2, const double *, double &o_w0, double &o_womega, double &o_wzeta)
+  {
+#pragma clang fp contract(fast)
+    const double s = gh_fast_sqrt(s2);
+    const double a = fmax(2.0 - s, 0.0), b = fmax(1.0 - s, 0.0);
+    const double a2 = a*a, b2 = b*b;
+    const double w = norm()*(0.25*(a2*a) - b2*b);
+    const double w1_ = norm()*(3.0*b2 - 0.75*a2);
+    o_w0 = w;
+    o_womega = -((double) ND*w + s*w1_);
+    o_wzeta = (a2*a2)*(0.1 + 0.2*s) - (b2*b2)*(0.2 + 0.8*s);
+  }
   __device__ static __forceinline__ double t_w1(double s, const double *) { return w1(s); }
   __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *) { return wgrav_i(s, invs); }
   __device__ static __forceinline__ double t_wpot(double s, double invs, const double *) { return wpot_i(s, invs); }
@@ -224,6 +242,11 @@ template <int ND> struct Quintic {
   __device__ static __forceinline__ double t_w0s2(double s2, const double *) { return w0(gh_fast_sqrt(s2)); }
   __device__ static __forceinline__ double t_womegas2(double s2, const double *) { return womega(gh_fast_sqrt(s2)); }
   __device__ static __forceinline__ double t_wzetas2(double s2, const double *) { return wzeta(gh_fast_sqrt(s2)); }
+  __device__ static __forceinline__ void t_dens3(double s2, const double *, double &o_w0, double &o_womega, double &o_wzeta)
+  {
+    const double s = gh_fast_sqrt(s2);
+    o_w0 = w0(s); o_womega = womega(s); o_wzeta = wzeta(s);
+  }
   __device__ static __forceinline__ double t_w1(double s, const double *) { return w1(s); }
   __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *) { return wgrav_i(s, invs); }
   __device__ static __forceinline__ double t_wpot(double s, double invs, const double *) { return wpot_i(s, invs); }
@@ -252,6 +275,10 @@ template <int ND, class Base> struct TabK {
   __device__ static __forceinline__ double t_w0s2(double s2, const double *tab) { return looksqd(tab, GH_TAB_W0S2, s2); }
   __device__ static __forceinline__ double t_womegas2(double s2, const double *tab) { return looksqd(tab, GH_TAB_WOMEGAS2, s2); }
   __device__ static __forceinline__ double t_wzetas2(double s2, const double *tab) { return looksqd(tab, GH_TAB_WZETAS2, s2); }
+  __device__ static __forceinline__ void t_dens3(double s2, const double *tab, double &o_w0, double &o_womega, double &o_wzeta)
+  {
+    o_w0 = looksqd(tab, GH_TAB_W0S2, s2); o_womega = looksqd(tab, GH_TAB_WOMEGAS2, s2); o_wzeta = looksqd(tab, GH_TAB_WZETAS2, s2);
+  }
   __device__ static __forceinline__ double t_w1(double s, const double *tab) { return look(tab, GH_TAB_W1, s); }
   __device__ static __forceinline__ double t_wgrav(double s, double invs, const double *tab)
   {

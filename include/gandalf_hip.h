@@ -116,7 +116,11 @@ typedef struct gh_stats {
   int64_t n_direct;        /* gravity: direct (Newtonian) particle interactions */
   int64_t n_cells;         /* gravity: cell (multipole) interactions */
   int64_t n_retries;       /* density: groups redone with a larger search radius */
-  double  kernel_ms;       /* device time of the dominant kernel of the call (hipEvent) */
+  double  kernel_ms;       /* device time of the call's kernels (hipEvent) */
+  /* gravity evaluation: what the kernel loads, counted once per LEAF (its 4-6 particles share every loaded entry) */
+  int64_t n_leaf_cells;    /* accepted-cell list entries read (4-byte id + 32-byte centre-of-mass record each) */
+  int64_t n_leaf_direct;   /* particles of direct-sum leaves read (32-byte (r, m) record each) */
+  int64_t n_leaf_cand;     /* hydro-candidate particles read and classified (40 bytes each) */
 } gh_stats;
 
 /* ---- lifetime ----------------------------------------------------------------------------- */

@@ -114,6 +114,29 @@ def levels(name, nsteps=40):
         print(name, "levels ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+
+def treeerror(n=32768):
+    """the reference's tree-accuracy measurement (tests/paper_tests/treeerror.py:22-35): RMS relative force error of the
+    KD-tree run against neib_search = bruteforce on the same Plummer sphere.  Stored: the brute-force accelerations and
+    potentials (float32 is ample for a 5e-3 effect) and the reference's own tree error."""
+    src = open(os.path.join(ROOT, "tests", "params", "plummer_4k.dat")).read().replace("Nhydro = 4096", "Nhydro = %d" % n)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, text in (("kd", src), ("bf", src.replace("neib_search = kdtree", "neib_search = bruteforce"))):
+            par = os.path.join(tmp, tag + ".dat")
+            open(par, "w").write(text)
+            run(["steps", par, os.path.join(tmp, tag), "0"], tmp)
+            res[tag] = read_gdmp(os.path.join(tmp, tag + "_setup.gdmp"))
+    kd, bf = res["kd"], res["bf"]
+    assert np.array_equal(kd["iorig"], bf["iorig"])
+    ferr = np.sqrt(np.mean(np.sum((kd["a"] - bf["a"])**2, axis=1)/np.sum(bf["a"]**2, axis=1)))
+    perr = np.sqrt(np.mean((kd["gpot"] - bf["gpot"])**2))
+    np.savez_compressed(os.path.join(GOLD, "plummer_32k_treeerror.npz"), Nhydro=np.array([n]), iorig=bf["iorig"].astype(np.int32),
+                        a_bruteforce=bf["a"].astype(np.float32), gpot_bruteforce=bf["gpot"].astype(np.float32),
+                        ref_force_error=np.array([ferr]), ref_gpot_error=np.array([perr]))
+    print("treeerror: reference force error %.4e gpot error %.4e" % (ferr, perr))
+
+
 def fromfile(name, nsteps=20):
     """a run that starts from a snapshot file (ic = file): setup + nsteps, in_file resolved against the repo root"""
     par = os.path.join(ROOT, "tests", "params", name + ".dat")
@@ -177,6 +200,8 @@ if __name__ == "__main__":
             fromfile(cfg)
         elif cfg.endswith("_levels") or cfg.endswith("_levels_single"):
             levels(cfg)
+        elif cfg == "treeerror":
+            treeerror()
         elif cfg == "nbody":
             nbody(256, 0)
             nbody(256, 1)
