@@ -929,6 +929,10 @@ extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, 
   if (ctx->nranks > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "gh_gather_neighbours: single-rank query");
   const size_t n = (size_t) ctx->N;
   long long *d_counts = nullptr, *d_off = nullptr; int *d_ids = nullptr;
+  struct Scratch {          // freed on every return path
+    long long *&a, *&b; int *&c;
+    ~Scratch() { if (a) (void) hipFree(a); if (b) (void) hipFree(b); if (c) (void) hipFree(c); }
+  } scratch{d_counts, d_off, d_ids};
   GH_CHECK(ctx, hipMalloc((void**) &d_counts, sizeof(long long)*n));
   GH_CHECK(ctx, hipMalloc((void**) &d_off, sizeof(long long)*(n + 1)));
   Domain dom; gh_fill_domain(ctx, dom);
@@ -936,17 +940,16 @@ extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, 
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
   hipLaunchKernelGGL(k_gather_count_fill, dim3(ctx->ngroups), dim3(64), 0, ctx->stream, d, dom, kr, 0, d_off, d_counts, d_ids, ctx->d_flags);
   int rc = gh_sync_collect(ctx, "gh_gather_neighbours");
-  if (rc) { (void) hipFree(d_counts); (void) hipFree(d_off); return rc; }
+  if (rc) return rc;
   std::vector<long long> cnt(n);
   GH_CHECK(ctx, hipMemcpy(cnt.data(), d_counts, sizeof(long long)*n, hipMemcpyDeviceToHost));
   offsets[0] = 0;
   for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + cnt[i];
-  if (offsets[n] > cap || !ids) { (void) hipFree(d_counts); (void) hipFree(d_off); return gh_fail(ctx, GH_ERR_CAPACITY, "gh_gather_neighbours: ids buffer too small"); }
+  if (offsets[n] > cap || !ids) return gh_fail(ctx, GH_ERR_CAPACITY, "gh_gather_neighbours: ids buffer too small");
   GH_CHECK(ctx, hipMemcpy(d_off, offsets, sizeof(long long)*(n + 1), hipMemcpyHostToDevice));
   GH_CHECK(ctx, hipMalloc((void**) &d_ids, sizeof(int)*(size_t) std::max<int64_t>(offsets[n], 1)));
   hipLaunchKernelGGL(k_gather_count_fill, dim3(ctx->ngroups), dim3(64), 0, ctx->stream, d, dom, kr, 1, d_off, d_counts, d_ids, ctx->d_flags);
   rc = gh_sync_collect(ctx, "gh_gather_neighbours");
   if (!rc) GH_CHECK(ctx, hipMemcpy(ids, d_ids, sizeof(int)*(size_t) offsets[n], hipMemcpyDeviceToHost));
-  (void) hipFree(d_counts); (void) hipFree(d_off); (void) hipFree(d_ids);
   return rc;
 }

@@ -715,17 +715,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         unsigned int mlo = 0, mhi = 0;
         {
           const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]}, nthr = {-thr, -thr};
-#pragma unroll 8
-          for (int c2 = 0; c2 < 32; c2++) {
+          auto pairbits = [&](int c2, unsigned int m) -> unsigned int {
             const float4_t xy = *((const float4_t*) &s_f[c2][0]);
             const float2_t zz = *((const float2_t*) &s_f[c2][4]);
             const float2_t dx = (float2_t) {xy.x, xy.y} - tx;
             float2_t dd = __builtin_elementwise_fma(dx, dx, nthr);
             if (ND > 1) { const float2_t dy = (float2_t) {xy.z, xy.w} - ty; dd = __builtin_elementwise_fma(dy, dy, dd); }
             if (ND > 2) { const float2_t dz = zz - tz; dd = __builtin_elementwise_fma(dz, dz, dd); }
-            if (c2 < 16) { mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(dd.x), 31); mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(dd.y), 31); }
-            else { mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(dd.x), 31); mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(dd.y), 31); }
-          }
+            m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.x), 31);
+            return __builtin_amdgcn_alignbit(m, __float_as_uint(dd.y), 31);
+          };
+#pragma unroll
+          for (int c2 = 0; c2 < 16; c2++) mlo = pairbits(c2, mlo);
+#pragma unroll
+          for (int c2 = 16; c2 < 32; c2++) mhi = pairbits(c2, mhi);
           mlo = __brev(mlo); mhi = __brev(mhi);
         }
         s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);

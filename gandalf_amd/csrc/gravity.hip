@@ -402,23 +402,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     s_out[lane][8] = (d.f[D_M][first + lane]/d.f[D_H][first + lane])*K::t_wpot0(P.ktab);    // self term, GradhSphTree.cpp:512
   }
   __syncthreads();
-#if defined(GH_DEBUG_SKIP_ALL)       /* timing experiments only: drop the point-mass and / or the SPH part */
-  const int lenc = 0, lend = 0, lenh = 0;
-#elif defined(GH_DEBUG_SKIP_PM)
-  const int lenc = 0, lend = 0, lenh = G.len[(size_t) gl*3 + 2];
-#elif defined(GH_DEBUG_SKIP_SPH)
-  const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = 0;
-#else
   const int lenc = G.len[(size_t) gl*3 + 0], lend = G.len[(size_t) gl*3 + 1], lenh = G.len[(size_t) gl*3 + 2];
-#endif
   const int *cells = G.cells + (size_t) gl*G.cap_c, *dirl = G.dirl + (size_t) gl*G.cap_d;
   const int nlg = 1 << (d.ltot - d.lgroup);
   const int grp = gl/nlg;
-#if defined(GH_DEBUG_SKIP_PM)
-  const int leng = 0;
-#else
   const int leng = G.glen[grp];
-#endif
   const int *gcells = G.gcells + (size_t) grp*G.cap_g;
   const int2 *hydl = G.hydl + (size_t) gl*G.cap_h;
 
@@ -714,11 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   for (int i = 0; i < MAXOCC; i++) {
     if (i < Nt) {
       const TargetI ti = s_tg[i];
-#if defined(GH_DEBUG_SKIP_PAIRS)
-      const int ns = 0;
-#else
       const int ns = ((ovfmask >> i) & 1u) ? 0 : min(nsph[i], SPHCAP);
-#endif
       Accum A;
       for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
       A.dudt = 0.0; A.div_v = 0.0; A.gpot = 0.0;

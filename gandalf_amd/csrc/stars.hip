@@ -218,6 +218,7 @@ extern "C" int gh_set_stars(gh_ctx *ctx, int64_t nstars, const double *r, const 
     if (ctx->star_posm) (void) hipFree(ctx->star_posm);
     if (ctx->star_h) (void) hipFree(ctx->star_h);
     if (ctx->star_out) (void) hipFree(ctx->star_out);
+    ctx->star_posm = nullptr; ctx->star_h = nullptr; ctx->star_out = nullptr; ctx->star_cap = 0; ctx->nstars = 0;
     GH_CHECK(ctx, hipMalloc((void**) &ctx->star_posm, sizeof(double4)*(size_t) nstars));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->star_h, sizeof(double)*(size_t) nstars));
     GH_CHECK(ctx, hipMalloc((void**) &ctx->star_out, sizeof(double)*4*(size_t) nstars));

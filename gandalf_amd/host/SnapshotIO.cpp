@@ -119,6 +119,8 @@ void ReadSerenUnformSnapshotFile(const std::string &filename, Snapshot &s)
   for (int i = 0; i < 50; i++) ddata[i] = get<double>(in);
   const int N = idata[0], Nstar = idata[1], nunit = idata[19], ndata = idata[20];
   if (Nstar != 0) throw GandalfError("snapshots with stars / sinks are not read on this path : " + filename);
+  // the header comes from a file: bound everything that sizes a buffer before using it
+  if (N < 0 || ndata < 0 || ndata > 50 || nunit < 0 || nunit > 50) throw GandalfError("Corrupt snapshot header : " + filename);
   for (int i = 0; i < nunit; i++) get_str(in);
   std::vector<std::string> ids(ndata);
   for (int a = 0; a < ndata; a++) ids[a] = get_str(in);
@@ -130,11 +132,16 @@ void ReadSerenUnformSnapshotFile(const std::string &filename, Snapshot &s)
   s.m.assign(N, 0.0); s.h.assign(N, 0.0); s.rho.assign(N, 0.0); s.u.assign(N, 0.0); s.iorig.assign(N, 0);
   for (int a = 0; a < ndata; a++) {
     const int width = typ[(size_t) a*5], count = typ[(size_t) a*5 + 2], code = typ[(size_t) a*5 + 3];
+    if (width < 0 || count < 0) throw GandalfError("Corrupt array descriptor in snapshot : " + ids[a]);
     std::vector<double> *dst = nullptr;
     if (ids[a] == "r") dst = &s.r; else if (ids[a] == "v") dst = &s.v; else if (ids[a] == "m") dst = &s.m;
     else if (ids[a] == "h") dst = &s.h; else if (ids[a] == "rho") dst = &s.rho; else if (ids[a] == "u") dst = &s.u;
     if (ids[a] == "porig" && count == N) in.read(reinterpret_cast<char*>(s.iorig.data()), sizeof(int32_t)*(size_t) N);
-    else if (dst && code == 4 && count == N) in.read(reinterpret_cast<char*>(dst->data()), sizeof(double)*(size_t) N*width);
+    else if (dst && code == 4 && count == N) {
+      // the declared width must be the one the destination was sized for (ndim for r and v, 1 for the scalars)
+      if ((size_t) N*width != dst->size()) throw GandalfError("Array '" + ids[a] + "' has the wrong width in snapshot : " + filename);
+      in.read(reinterpret_cast<char*>(dst->data()), sizeof(double)*(size_t) N*width);
+    }
     else {                                   // an array this path does not use: skip it by its declared size
       const size_t el = code == 2 ? 4 : (code == 4 ? 8 : (code == 3 ? 8 : 0));
       if (!el) throw GandalfError("unknown array type in snapshot : " + ids[a]);

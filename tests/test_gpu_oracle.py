@@ -66,9 +66,64 @@ def test_box256k_net_force_and_idempotence():
     assert 30 < cnt.mean() < 80 and cnt.min() >= 1
 
 
-def test_plummer1m_tree_gravity_vs_direct_sum():
-    """config 3 at full size: Barnes-Hut accelerations of 64 sample particles against the O(N) direct sum
-    (the reference's own accuracy method, tests/paper_tests/treeerror.py: tree vs brute force)"""
+@pytest.mark.parametrize("case,n,nsteps", [("box3d_4k", 262144, 2), ("plummer_4k", 131072, 1)])
+def test_bench_sizes_vs_oracle(case, n, nsteps):
+    """HIP vs oracle at the sizes that are benchmarked: BASELINE configs[1] in full (262 144-particle periodic box, setup +
+    2 steps) and the per-GPU share of configs[3] (131 072-particle Plummer sphere with self-gravity, setup + 1 step).
+    Deep trees (ltot 16 / 15), the LDS-resident subtree build, the split density path with its list capacities and the
+    gravity interaction lists are all exercised at the sizes they run at; same tolerances as the small cases."""
+    from gandalf_amd.host import Simulation
+    from oracle.pyoracle import Oracle
+    pf = os.path.join(PARAMS, case + ".dat")
+    sim = Simulation(pf, Nhydro=n)
+    ic = sim.generate_ic()
+    sim.post_ic_setup()
+    sim.main_loop(nsteps)
+    dev = sim.device()
+    p = read_params_file(pf)
+    o = Oracle(p)
+    o.set_particles(ic["r"], ic["m"], ic["h"], v=ic["v"], u=ic["u"])
+    o.setup(h_provided=ic["initial_h_provided"])
+    o.step(nsteps)
+    assert abs(sim.t - o.t) <= 1e-12*abs(o.t)
+    assert abs(sim.timestep - o.timestep) <= 1e-9*o.timestep
+    assert np.max(np.abs(dev.download("r") - o.get("r"))) < 1e-11*np.abs(o.get("r")).max()
+    assert np.max(np.abs(dev.download("h")/o.get("h") - 1)) < 1e-10
+    assert np.max(np.abs(dev.download("rho")/o.get("rho") - 1)) < 1e-10
+    assert vec_err(dev.download("a"), o.get("a")) < 1e-9
+    if int(p.get("self_gravity", 0)):
+        assert np.max(np.abs(dev.download("gpot")/o.get("gpot") - 1)) < 1e-10
+
+
+def _tree_force_error(a_tree, a_bf):
+    """the reference's tree-accuracy metric, tests/paper_tests/treeerror.py:22-35"""
+    return float(np.sqrt(np.mean(np.sum((a_tree - a_bf)**2, axis=1)/np.sum(a_bf**2, axis=1))))
+
+
+def test_tree_force_error_matches_reference():
+    """the RMS force error of the tree against neib_search = bruteforce (the reference's treeerror.py metric),
+    on the 32 768-particle Plummer sphere at theta = 0.5, monopole.  The fixture holds the reference's brute-force
+    accelerations and the error the reference's own KD-tree run makes against them (4.96e-3); the GPU tree run must make
+    the same error to better than two significant digits."""
+    from gandalf_amd.host import Simulation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "plummer_32k_treeerror.npz"))
+    n = int(g["Nhydro"][0])
+    sim = Simulation(os.path.join(PARAMS, "plummer_4k.dat"), Nhydro=n)
+    sim.generate_ic()
+    sim.post_ic_setup()
+    dev = sim.device()
+    a = dev.download("a")
+    err = _tree_force_error(a, g["a_bruteforce"].astype(np.float64))
+    ref = float(g["ref_force_error"][0])
+    assert abs(err/ref - 1.0) < 5e-3, (err, ref)
+    gerr = float(np.sqrt(np.mean((dev.download("gpot") - g["gpot_bruteforce"].astype(np.float64))**2)))
+    assert abs(gerr/float(g["ref_gpot_error"][0]) - 1.0) < 5e-3
+
+
+def test_plummer1m_tree_force_error():
+    """config 3 at full size: the same metric for 256 sample particles against the O(N) direct sum of the Newtonian far
+    field (the softened near field is common to both sums).  At 1M particles the error of the theta = 0.5 monopole tree
+    sits where the 32k reference measurement puts it (a few 1e-3), not at the loose 2 % bound of round 1."""
     from gandalf_amd.host import Simulation
     sim = Simulation(os.path.join(PARAMS, "plummer_4k.dat"), Nhydro=1048576)
     sim.generate_ic()
@@ -77,23 +132,30 @@ def test_plummer1m_tree_gravity_vs_direct_sum():
     r, m, h = dev.download("r"), dev.download("m"), dev.download("h")
     atree = dev.download("atree")
     rng = np.random.default_rng(1)
-    idx = rng.choice(len(m), 64, replace=False)
-    err = []
+    idx = rng.choice(len(m), 256, replace=False)
+    num = den = 0.0
     for i in idx:
         dr = r - r[i]
         d2 = (dr*dr).sum(axis=1)
-        far = d2 > (2*np.maximum(h, h[i]))**2         # beyond kernel softening: Newtonian
-        adir = (m[far, None]*dr[far]/d2[far, None]**1.5).sum(axis=0)
-        # the softened near field is identical in both sums; evaluate it from the tree result's complement
+        far = d2 > (2*np.maximum(h, h[i]))**2         # beyond kernel softening: Newtonian in both sums
+        afar = (m[far, None]*dr[far]/d2[far, None]**1.5).sum(axis=0)
+        # tree value of the same far field: subtract the exactly summed near field (kernel-softened, identical in the tree
+        # run: near particles are always direct / SPH neighbours there) by evaluating it with the reference's wgrav
         near = ~far
         near[i] = False
-        s = np.sqrt(d2[near])
-        # kernel-softened pair term needs wgrav; compare only particles whose near field is small
-        err.append(np.linalg.norm(atree[i] - adir)/np.linalg.norm(adir))
-    err = np.array(err)
-    # theta = 0.5 monopole: per-particle error is dominated by the tree approximation (~1e-3) plus the
-    # softened near field we left out (a few neighbours out of 1e6): well below 5 %
-    assert np.median(err) < 2e-2
+        anear = np.zeros(3)
+        if near.any():
+            s = np.sqrt(d2[near])
+            def wgrav(x):                               # M4Kernel::wgrav, SmoothingKernel.h:205-219
+                return np.where(x < 1, 4/3*x - 1.2*x**3 + 0.5*x**4,
+                                np.where(x < 2, 8/3*x - 3*x*x + 1.2*x**3 - x**4/6 - 1/(15*x*x), 1/(x*x)))
+            hi, hj = h[i], h[near]
+            f = 0.5*(wgrav(s/hi)/hi**2 + wgrav(s/hj)/hj**2)      # GradhSph.cpp:538-544 without the zeta terms
+            anear = (m[near, None]*dr[near]/s[:, None]*f[:, None]).sum(axis=0)
+        num += np.sum((atree[i] - anear - afar)**2)/np.sum((afar + anear)**2)
+        den += 1
+    err = np.sqrt(num/den)
+    assert err < 1.5e-2, err
 
 
 def test_config1_full_run_vs_reference():
