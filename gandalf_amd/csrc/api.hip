@@ -261,7 +261,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   gh_dd_free(ctx);
   free_particles(ctx);
-  void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->leafact, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -753,7 +753,8 @@ static int block_step(gh_ctx *ctx)
   gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // all particles drift; active = end of own step
   gh_phase_end(ctx, GH_T_KDK);
   if ((rc = step_tree_timed(ctx))) return rc;
-  for (;;) {
+  for (int pass = 0; ; pass++) {
+    if (pass > 0) gh_leaf_active_counters(ctx);          // "if (activecount > 0) UpdateActiveParticleCounters" (:663)
     if ((rc = density_and_hmax(ctx, false))) return rc;
     gh_zero_acc_impl(ctx);
     gh_thermal_all_impl(ctx);                            // :665-679, nradstep = 1

@@ -66,11 +66,17 @@ __device__ __forceinline__ void density_store(const DevicePtrs &d, const Density
 }
 
 
-template <int ND, bool COUNT, int KT>
+// STALE: the tree has been extrapolated (ntreestockstep > 1, Tree.cpp:172-198) since its last stocking - the search is
+// then the reference's per-leaf-cell one against the drifted boxes (walk_dfs_stream_masked), including its list filter
+// |r_j - rcell|^2 < (rmax + kernrange*hmax)^2 with the drifted centre (Tree.cpp:369-376), so that the neighbours the
+// reference loses are lost here too.
+template <int ND, bool COUNT, int KT, bool STALE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_density(DevicePtrs d, DensityParams P, unsigned long long *stats, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ WalkLDS<int> L;
+  __shared__ unsigned short s_smask[STALE ? GH_SCAP : 1], s_tagm[STALE ? DB*64 : 1];   // leaf masks of stack entries / tile slots
+  __shared__ double s_lrc[STALE ? 16 : 1][3], s_lrm[STALE ? 16 : 1];                   // drifted leaf centres, leaf rmax
   __shared__ double s_x[DB*64], s_y[DB*64], s_z[DB*64], s_m[DB*64];   // a batch of DB candidate tiles
   __shared__ unsigned long long s_mask[DB][64];                       // per tile, per lane: entries in support
   __shared__ __attribute__((aligned(8))) float s_fx[64], s_fy[64], s_fz[64];  // current tile, fp32, relative to the group centre
@@ -87,7 +93,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   unsigned long long dbg_tiles = 0, dbg_passes = 0;
 #endif
   // block timesteps: only the active particles are targets (GradhSphTree.cpp:128-131)
-  const bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  if (STALE && d.leafact) {
+    // ... of the cells the reference still has on its active list (cell.Nactive of the last stocking, see k_leaf_nactive)
+    const int ip = gfirst + (lane < gN ? lane : 0);
+    int ln = gnode;
+    while (ln < d.gtot - 1) { const int c2 = 2*ln + 2; ln = (ip >= d.cfirst[c2]) ? c2 : 2*ln + 1; }
+    act = act && d.leafact[ln - (d.gtot - 1)] > 0;
+  }
   const int i = gfirst + (act ? lane : 0);
 
   const double invndim = 1.0/(double) ND;
@@ -119,7 +132,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   if (lane < nleaf) {
     const CellBox lbx = d.cbox[leafnode0 + lane];
     for (int k = 0; k < 3; k++) { s_lb[lane][k] = lbx.bbmin[k]; s_lb[lane][3 + k] = lbx.bbmax[k]; }
+    if (STALE) {
+      const CellGeo lg = d.cgeo[leafnode0 + lane];
+      for (int k = 0; k < 3; k++) s_lrc[lane][k] = lg.rcell[k];
+      s_lrm[lane] = lg.rmax;
+    }
   }
+  const int li = leafn - leafnode0;                      // the lane's leaf within the group
 
   // per-lane iteration state (GradhSph.cpp:148-158)
   const double h0 = d.f[D_H][i];
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     if (!__any(running)) break;
     // the search volume covers kernrange*h of every lane still iterating (Tree.cpp:319-328 uses
     // bb +/- kernrange*hmax; where the reference's hmax is too small it retries with hmax*1.05)
-    const double hs = wave_max(running ? h : 0.0);
+    const double hs = wave_max(running ? (STALE ? hmaxl : h) : 0.0);
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
       lo[k] = k < ND ? gb.bbmin[k] - K::kernrange*hs : -1e300;
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     // Elongated groups (thin KD cells of a sparse halo that reach into a dense region) would stream every
     // particle near their bounding box with the largest h of the group: there, cells are also culled against
     // each leaf box with that leaf's own search radius (wave-uniform switch, below).
-    s_hl[lane] = running ? h : 0.0;
+    s_hl[lane] = running ? (STALE ? hmaxl : h) : 0.0;      // STALE: the reference's search radius is that of the try, kernrange*hmax
     __syncthreads();
     if (lane < nleaf) {
       const int ln = leafnode0 + lane;
@@ -242,10 +261,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
           dr[0] = s_x[c] - ri[0];
           if (ND > 1) dr[1] = s_y[c] - ri[1];
           if (ND > 2) dr[2] = s_z[c] - ri[2];
-          const double mj = s_m[c];
+          double mj = s_m[c];
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
+          if (STALE) {
+            // the candidate is on this particle's list only if the walk of ITS leaf reached the candidate's leaf and the
+            // reference's list filter keeps it: |r_j - rcell|^2 < (rmax + kernrange*hmax)^2   (Tree.cpp:369-376)
+            double dc = s_x[c] - s_lrc[li][0], d2c = dc*dc;
+            if (ND > 1) { dc = s_y[c] - s_lrc[li][1]; d2c += dc*dc; }
+            if (ND > 2) { dc = s_z[c] - s_lrc[li][2]; d2c += dc*dc; }
+            const double hrm = s_lrm[li] + K::kernrange*hmaxl;
+            if (!((s_tagm[c] >> li) & 1) || !(d2c < hrm*hrm)) mj = 0.0;
+          }
           {
 #pragma clang fp contract(fast)
             const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
@@ -267,10 +295,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
         if (valid) {
           const double4 v = d.posm[j];
           double sg[3], sh[3];
-          code_xform(P.dom, code, sg, sh);
+          code_xform(P.dom, STALE ? (code & 31) : code, sg, sh);
           x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2]; m = v.w;
         }
         s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
+        if (STALE) s_tagm[o + lane] = (unsigned short) (valid ? (code >> 5) : 0);
         s_fx[lane] = (float) (x - gc[0]); s_fy[lane] = ND > 1 ? (float) (y - gc[1]) : 0.f; s_fz[lane] = ND > 2 ? (float) (z - gc[2]) : 0.f;
       }
       __syncthreads();
@@ -313,7 +342,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #ifdef GH_DEBUG_BLOCKTIME
     dbg_passes++;
 #endif
-    walk_dfs_stream(d, L, codes, cls, tile, flags);
+    if (STALE) {
+      // per (node, leaf): BoxOverlap(leaf.bb -/+ kernrange*hmax, node.bb), inclusive (Tree.cpp:319-328, InlineFuncs.h:362-390)
+      auto clsm = [&](int n, int code, unsigned int inmask, int &first, int &cnt) -> unsigned int {
+        const CellBox b = d.cbox[n];
+        first = b.first; cnt = b.N;
+        if (b.N <= 0) return 0u;
+        double sg[3], sh[3];
+        code_xform(P.dom, code, sg, sh);
+        double bmin[3] = {0.0, 0.0, 0.0}, bmax[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < ND; k++) image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin[k], bmax[k]);
+        unsigned int om = 0;
+        for (int l = 0; l < nleaf; l++) {
+          const double hl = s_lhs[l];
+          if (!((inmask >> l) & 1) || !(hl > 0.0)) continue;
+          bool ov = true;
+          for (int k = 0; k < ND; k++) {
+            if (s_lb[l][k] - K::kernrange*hl > bmax[k]) ov = false;
+            if (bmin[k] > s_lb[l][3 + k] + K::kernrange*hl) ov = false;
+          }
+          if (ov) om |= 1u << l;
+        }
+        return om;
+      };
+      unsigned int m0 = 0;
+      for (int l = 0; l < nleaf; l++) if (s_lhs[l] > 0.0) m0 |= 1u << l;
+      walk_dfs_stream_masked(d, L, s_smask, codes, m0, clsm, tile, flags);
+    }
+    else walk_dfs_stream(d, L, codes, cls, tile, flags);
     process_batch();
     if (__any(miss)) {                                     // incomplete sums: store nothing, the host widens the import
       if (lane == 0) { P.fbout[q] = 2; atomicAdd(P.miss_count, 1u); }
@@ -837,7 +893,9 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
   // split path (walk -> candidate range lists in HBM -> evaluation); GH_DENSITY_FUSED=1 keeps the fused kernel alone
-  static const bool fused_only = getenv("GH_DENSITY_FUSED") != nullptr;
+  // an extrapolated tree (ntreestockstep > 1) is searched the reference's way, leaf cell by leaf cell (k_density<.., STALE>)
+  const bool stale = ctx->tree_stale;
+  const bool fused_only = stale || getenv("GH_DENSITY_FUSED") != nullptr;
   DensLists G;
   G.rcap = GH_DENS_RCAP;
   if (ctx->dl_groups != ctx->ngroups) {
@@ -865,7 +923,8 @@ int gh_density_impl(gh_ctx *ctx, bool count)
     P.only_if = G.fb;        // the fused kernel redoes what the split path flagged (early exit per group otherwise)
   }
 #define LAUNCH(ND_, KT_)                                                                                      \
-    if (count) hipLaunchKernelGGL((k_density<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    if (stale) hipLaunchKernelGGL((k_density<ND_, false, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    else if (count) hipLaunchKernelGGL((k_density<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
     else hipLaunchKernelGGL((k_density<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
   if (nblocks > 0) { GH_DISPATCH(ctx, LAUNCH) }
   if (dd) {

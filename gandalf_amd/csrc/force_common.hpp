@@ -16,6 +16,7 @@ struct ForceParams {
   int mac;              // GH_MAC_*
   int fastquad;         // multipole = fast_quadrupole: the fast_monopole kernel also adds the cells' quadrupole terms
   int group0;
+  int stale;            // the tree has been extrapolated since its last stocking (Tree::ExtrapolateCellProperties): see k_density<.., STALE>
 };
 
 // per-neighbour record of the force tiles (reference HydroForcesParticle, Particle.h:313-364)

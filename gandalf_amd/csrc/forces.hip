@@ -26,12 +26,17 @@
 // ================================================================================================
 // hydro only                                                     (GradhSphTree.cpp:280-435)
 // ================================================================================================
-template <int ND, bool COUNT, int KT, bool LV>
+// STALE: extrapolated tree (see k_density<.., STALE>): the candidate walk is the reference's per-leaf-cell one
+// (Tree.cpp:562-617 against the drifted boxes) followed by NeighbourManager::_EndSearch's list filter with the drifted
+// cell centre (NeighbourManager.h:440-455), so that the neighbours the reference loses are lost here too.
+template <int ND, bool COUNT, int KT, bool LV, bool STALE = false>
 __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags)
 {
   __shared__ WalkLDS<int> L;
   __shared__ double s_t[T_NFA][64];
   __shared__ int s_tj[LV ? 64 : 1], s_tlv[LV ? 64 : 1];   // block timesteps: particle index and level of every tile slot
+  __shared__ unsigned short s_smask[STALE ? GH_SCAP : 1], s_tagm[STALE ? 64 : 1];
+  __shared__ double s_lbb[STALE ? 16 : 1][6], s_lhb[STALE ? 16 : 1][6], s_lrc[STALE ? 16 : 1][3], s_lrm[STALE ? 16 : 1], s_lhm[STALE ? 16 : 1];
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
@@ -41,13 +46,39 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
   // block timesteps (Nlevels > 1: the LV instantiation): targets are the active particles only and the pair loop also
   // maintains levelneib
   constexpr bool lv = LV;
-  const bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  bool act = lane < gN && (!lv || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  if (STALE && d.leafact) {                         // cells on the reference's (stale) active list only, see k_leaf_nactive
+    const int ip = gfirst + (lane < gN ? lane : 0);
+    int ln = gnode;
+    while (ln < d.gtot - 1) { const int c2 = 2*ln + 2; ln = (ip >= d.cfirst[c2]) ? c2 : 2*ln + 1; }
+    act = act && d.leafact[ln - (d.gtot - 1)] > 0;
+  }
   if (lv && !__any(act)) return;
   const int i = gfirst + (act ? lane : 0);
   const int mylevel = lv ? (int) d.f[D_LEVEL][i] : 0;
   int lnmax = 0;
   TargetI ti;
   load_target(d, i, ND, ti);
+  // STALE: the leaf cells of the group, and which of them hold an active particle (Tree::ComputeActiveCellList)
+  const int nleaf = 1 << (d.ltot - d.lgroup);
+  const int leafnode0 = (d.gtot - 1) + (gnode - ((1 << d.lgroup) - 1))*nleaf;
+  int li = 0;
+  unsigned int m0 = 0;
+  if (STALE) {
+    int leafn = gnode;
+    while (leafn < d.gtot - 1) { const int c2 = 2*leafn + 2; leafn = (i >= d.cfirst[c2]) ? c2 : 2*leafn + 1; }
+    li = leafn - leafnode0;
+    if (lane < nleaf) {
+      const CellBox lb = d.cbox[leafnode0 + lane]; const CellH lh = d.ch[leafnode0 + lane]; const CellGeo lg = d.cgeo[leafnode0 + lane];
+      for (int k = 0; k < 3; k++) {
+        s_lbb[lane][k] = lb.bbmin[k]; s_lbb[lane][3 + k] = lb.bbmax[k]; s_lhb[lane][k] = lh.hbmin[k]; s_lhb[lane][3 + k] = lh.hbmax[k];
+        s_lrc[lane][k] = lg.rcell[k];
+      }
+      s_lrm[lane] = lg.rmax; s_lhm[lane] = lh.hmax;
+    }
+    for (int l = 0; l < nleaf; l++) if (__any(act && li == l)) m0 |= 1u << l;
+    __syncthreads();
+  }
   const bool mm97 = P.avisc == GH_AVISC_MON97MM97;
   const bool tdav = mm97 || P.avisc == GH_AVISC_MON97CD2010;      // per-particle alpha (the pair term uses the mean)
   ti.alpha = tdav ? d.f[D_ALPHA][i] : 0.0;
@@ -87,11 +118,13 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = cn; }
     else open = true;
   };
-  auto tile = [&](bool valid, int j, int code) {
+  auto tile = [&](bool valid, int j, int tag) {
+    const int code = STALE ? (tag & 31) : tag;
     {
       double sg[3], sh[3];
       code_xform(P.dom, code, sg, sh);
       stage_neib(d, ND, s_t, lane, j, sg, sh, valid);
+      if (STALE) s_tagm[lane] = (unsigned short) (valid ? (tag >> 5) : 0);
       if (tdav) s_t[T_ALPHA][lane] = valid ? d.f[D_ALPHA][j] : 0.0;
       if (lv) { s_tj[lane] = valid ? j : 0; s_tlv[lane] = valid ? (int) d.f[D_LEVEL][j] : 0; }
     }
@@ -105,7 +138,19 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
         if (ND > 1) { const double dy = s_t[T_Y][c] - ti.r[1]; r2 += dy*dy; }
         if (ND > 2) { const double dz = s_t[T_Z][c] - ti.r[2]; r2 += dz*dz; }
         // neighbour unless (r2 >= hrangesqd_i && r2 >= hrangesqd_j)      (NeighbourManager.h:521)
-        if (!(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c])) mask |= 1ull << c;
+        if (!(r2 >= ti.hr2 && r2 >= s_t[T_HR2][c])) {
+          bool keep = true;
+          if (STALE) {
+            // on this particle's list only if the walk of ITS leaf reached the candidate's leaf and _EndSearch keeps it:
+            // |r_j - rcell|^2 < (rmax + kernrange*hmax_cell)^2 or < (rmax + kernrange*h_j)^2
+            double dc = s_t[T_X][c] - s_lrc[li][0], d2c = dc*dc;
+            if (ND > 1) { dc = s_t[T_Y][c] - s_lrc[li][1]; d2c += dc*dc; }
+            if (ND > 2) { dc = s_t[T_Z][c] - s_lrc[li][2]; d2c += dc*dc; }
+            const double h1 = s_lrm[li] + KSel<ND, KT>::type::kernrange*s_lhm[li], h2 = s_lrm[li] + KSel<ND, KT>::type::kernrange/s_t[T_INVH][c];
+            keep = ((s_tagm[c] >> li) & 1) && (d2c < h1*h1 || d2c < h2*h2);
+          }
+          if (keep) mask |= 1ull << c;
+        }
       }
     }
     while (__any(mask != 0ull)) {
@@ -129,7 +174,35 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
     }
     __syncthreads();
   };
-  walk_dfs_stream(d, L, codes, cls, tile, flags);
+  if (STALE) {
+    // per (node, leaf): overlap(leaf.bb, node.hbox) || overlap(leaf.hbox, node.bb)          (Tree.cpp:579-580)
+    auto clsm = [&](int n, int code, unsigned int inmask, int &first, int &cnt) -> unsigned int {
+      const CellBox b = d.cbox[n];
+      first = b.first; cnt = b.N;
+      if (b.N <= 0) return 0u;
+      const CellH bh = d.ch[n];
+      double sg[3], sh[3];
+      code_xform(P.dom, code, sg, sh);
+      double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, hmin[3] = {0, 0, 0}, hmx[3] = {0, 0, 0};
+      for (int k = 0; k < ND; k++) {
+        image_interval(sg[k], sh[k], b.bbmin[k], b.bbmax[k], bmin[k], bmax[k]);
+        image_interval(sg[k], sh[k], bh.hbmin[k], bh.hbmax[k], hmin[k], hmx[k]);
+      }
+      unsigned int om = 0;
+      for (int l = 0; l < nleaf; l++) {
+        if (!((inmask >> l) & 1)) continue;
+        bool o1 = true, o2 = true;
+        for (int k = 0; k < ND; k++) {
+          if (s_lbb[l][k] > hmx[k] || hmin[k] > s_lbb[l][3 + k]) o1 = false;
+          if (s_lhb[l][k] > bmax[k] || bmin[k] > s_lhb[l][3 + k]) o2 = false;
+        }
+        if (o1 || o2) om |= 1u << l;
+      }
+      return om;
+    };
+    walk_dfs_stream_masked(d, L, s_smask, codes, m0, clsm, tile, flags);
+  }
+  else walk_dfs_stream(d, L, codes, cls, tile, flags);
 
   if (act) {
     // GradhSph.cpp:451-453 then GradhSphTree.cpp:396-404 (accumulate on the zeroed main array)
@@ -525,6 +598,7 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
   int g0, g1;
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   P.group0 = g0;
+  P.stale = ctx->tree_stale ? 1 : 0;
 }
 
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
@@ -542,7 +616,11 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_, KT_)                                                                                            \
-    if (ctx->cfg.Nlevels > 1) { \
+    if (ctx->tree_stale) { \
+      if (ctx->cfg.Nlevels > 1) hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_, true, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_, false, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
+    } \
+    else if (ctx->cfg.Nlevels > 1) { \
       if (count) hipLaunchKernelGGL((k_hydro_forces<ND_, true, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
       else hipLaunchKernelGGL((k_hydro_forces<ND_, false, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
     } \

@@ -75,6 +75,8 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
   int levels;                      // Nlevels > 1: targets are the ACTIVE particles only (flags bit 0)
+  const int *leafact;              // extrapolated tree + block timesteps: active-particle count of every leaf AS OF THE LAST STOCKING
+                                   // (the reference does not refresh cell.Nactive on extrapolation steps, SphSimulation.cpp:663) or nullptr
 };
 
 struct gh_ctx {
@@ -103,6 +105,7 @@ struct gh_ctx {
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
   double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
+  int *leafact = nullptr;          // [gtot] active particles per leaf at the last stocking (ntreestockstep > 1 and Nlevels > 1 only)
   double *leaf_amin = nullptr;
   bool mac_bootstrap = false;      // gh_setup's first force pass of a relative MAC runs geometric (SphSimulation.cpp:381-388)
   double *ktab = nullptr;          // tabulated kernel tables [GH_TAB_COUNT][GH_TAB_RES] (device), or nullptr
@@ -121,6 +124,7 @@ struct gh_ctx {
   int lsub = 0;                    // first level built by the LDS-resident subtree kernel
   double *redbuf = nullptr;        // reduction scratch
   bool tree_valid = false;
+  bool tree_stale = false;         // cells extrapolated since the last stocking (Tree::ExtrapolateCellProperties): per-leaf searches
   bool rebuild_tree = true;        // SimulationBase::rebuild_tree: raised by upload / setup, lowered at the end of a step
 
   // gravity interaction lists in HBM (gravity.hip)
@@ -212,6 +216,7 @@ int gh_alloc_particles(gh_ctx *ctx, int64_t N);
 int gh_alloc_tree(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx);
 int gh_tree_extrapolate_impl(gh_ctx *ctx);  // Tree::ExtrapolateCellProperties: cells drift with their stocked mean velocity
+int gh_leaf_active_counters(gh_ctx *ctx);   // KDTree::UpdateActiveParticleCounters (KDTree.cpp:1217-1254)
 int gh_tree_restock_impl(gh_ctx *ctx);   // KDTree::StockTree: same cells and particle order, properties from the current r, h
 int gh_update_hmax_impl(gh_ctx *ctx);
 // the *_impl functions only enqueue work on ctx->stream (no host synchronisation)

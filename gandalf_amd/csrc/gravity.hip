@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
       const int f0 = d.cfirst[leafnode0 + l], cn = d.cN[leafnode0 + l];
       bool a = false;
       for (int t = 0; t < cn; t++) a = a || ((int) d.f[D_FLAGS][f0 + t] & 1);
+      if (d.leafact) a = a && d.leafact[q*nl + l] > 0;      // extrapolated tree: the reference's stale active-cell list
       if (a) am |= 1u << l;
     }
     allmask &= am;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
               // would list ALL its particles as hydro candidates - emit the whole range, do not open
               const double rr = s_lrmax[l] + s_lhr[l];
               const double dd_ = sqrt(drsqd) + g.rmax;
-              if (g.N > 0 && dd_ <= rr*(1.0 - 1e-12)) hydm |= 1u << l;
+              // (not with an extrapolated tree: the drifted centres of a node and its descendants no longer nest)
+              if (g.N > 0 && !P.stale && dd_ <= rr*(1.0 - 1e-12)) hydm |= 1u << l;
               else openm |= 1u << l;
             }
           }
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   if (lv) {
     actmask = 0;
     for (int t = 0; t < Nt; t++) if ((int) d.f[D_FLAGS][first + t] & 1) actmask |= 1u << t;
+    if (d.leafact && d.leafact[gl] <= 0) actmask = 0;
     if (!actmask) return;
   }
 
@@ -626,7 +629,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   int nsph[MAXOCC];
 #pragma unroll
   for (int i = 0; i < MAXOCC; i++) nsph[i] = 0;
+  // extrapolated tree: NeighbourManager::_EndSearch's list filter with the leaf's drifted centre (NeighbourManager.h:440-455);
+  // a hydro candidate that fails it is demoted to the direct list - here: never classified as an SPH neighbour
+  const CellGeo lgeo = d.cgeo[node];
   auto hyd_process = [&](bool valid, int j, const double4 &q0, double hr2) {
+    bool keepleaf = true;
+    if (P.stale) {
+      double dc = q0.x - lgeo.rcell[0], d2c = dc*dc;
+      if (ND > 1) { dc = q0.y - lgeo.rcell[1]; d2c += dc*dc; }
+      if (ND > 2) { dc = q0.z - lgeo.rcell[2]; d2c += dc*dc; }
+      const double h1 = lgeo.rmax + K::kernrange*lgeo.hmax, h2 = lgeo.rmax + sqrt(hr2);
+      keepleaf = d2c < h1*h1 || d2c < h2*h2;
+    }
 #pragma unroll
     for (int i = 0; i < MAXOCC; i++) {
       if (i < Nt) {
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         double r2 = dr[0]*dr[0];
         if (ND > 1) r2 += dr[1]*dr[1];
         if (ND > 2) r2 += dr[2]*dr[2];
-        const bool sph = valid && !(r2 >= ti.hr2 && r2 >= hr2);
+        const bool sph = valid && keepleaf && !(r2 >= ti.hr2 && r2 >= hr2);
         const unsigned long long sm = __ballot(sph);
         if (sm) {
           const int pos = nsph[i] + __popcll(sm & lt);
@@ -897,6 +911,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   if (ctx->cfg.avisc == GH_AVISC_MON97MM97) { P.avisc = GH_AVISC_MON97; P.alpha_visc = ctx->cfg.alpha_visc_min; }   // see sph_pair
   P.macerror = ctx->cfg.macerror; P.mac = ctx->mac_bootstrap ? GH_MAC_GEOMETRIC : ctx->cfg.gravity_mac;
   P.fastquad = ctx->cfg.multipole == GH_MULTIPOLE_FAST_QUADRUPOLE ? 1 : 0;
+  P.stale = ctx->tree_stale ? 1 : 0;
   const int mpole = ctx->cfg.multipole;
   const bool lists_only = mpole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC;   // the fused fallback has neither
   int g0, g1;

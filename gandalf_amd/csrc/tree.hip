@@ -625,6 +625,7 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   d.N = (int) ctx->N; d.ndim = ctx->ndim; d.ltot = ctx->ltot; d.gtot = ctx->gtot;
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
   d.levels = ctx->cfg.Nlevels > 1 ? 1 : 0;
+  d.leafact = (d.levels && ctx->tree_stale) ? ctx->leafact : nullptr;
   return d;
 }
 
@@ -691,6 +692,7 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ccom, sizeof(CellCom)*Ncell));
   if (ctx->cfg.ntreestockstep > 1) GH_CHECK(ctx, re((void**) &ctx->cvel, sizeof(double)*3*Ncell));
+  if (ctx->cfg.ntreestockstep > 1 && ctx->cfg.Nlevels > 1) GH_CHECK(ctx, re((void**) &ctx->leafact, sizeof(int)*gtot));
   if (ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC && ctx->cfg.self_gravity) {
     GH_CHECK(ctx, re((void**) &ctx->leaf_amin, sizeof(double)*gtot));
     GH_CHECK(ctx, hipMemsetAsync(ctx->leaf_amin, 0, sizeof(double)*gtot, ctx->stream));
@@ -847,6 +849,7 @@ int gh_tree_build_impl(gh_ctx *ctx)
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, p0, pn);
   ctx->cur ^= 1;
   ctx->tree_valid = true;
+  ctx->tree_stale = false;
   gh_pack_posm(ctx);
   if ((rc = stock_tree(ctx, 0))) return rc;
   stock_cell_velocities_fwd(ctx);
@@ -892,9 +895,31 @@ __global__ void k_extrapolate_cells(DevicePtrs d, const double *cvel, const doub
     d.ccom[n].com[k] += dx;
   }
 }
+// cell.Nactive of the leaf cells (StockCellProperties KDTree.cpp:856 / UpdateActiveParticleCounters :1217-1254).  The
+// reference refreshes it when it builds or stocks the tree and at the top of a repeated pass of MainLoop's
+// do ... while (activecount > 0) - NOT on a step that only extrapolates the tree (SphSimulation.cpp:663), where the
+// active cells are therefore those of the last stocking; restated as it is.
+__global__ void k_leaf_nactive(DevicePtrs d, int *leafact)
+{
+  const int l = blockIdx.x*blockDim.x + threadIdx.x;
+  if (l >= d.gtot) return;
+  const int n = d.gtot - 1 + l;
+  const int first = d.cfirst[n], cn = d.cN[n];
+  int na = 0;
+  for (int t = 0; t < cn; t++) na += (int) d.f[D_FLAGS][first + t] & 1;
+  leafact[l] = na;
+}
+int gh_leaf_active_counters(gh_ctx *ctx)
+{
+  if (!ctx->leafact) return GH_OK;
+  hipLaunchKernelGGL(k_leaf_nactive, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->leafact);
+  return GH_OK;
+}
+
 void stock_cell_velocities_fwd(gh_ctx *ctx) ;
 static void stock_cell_velocities(gh_ctx *ctx)
 {
+  gh_leaf_active_counters(ctx);
   if (ctx->cfg.ntreestockstep <= 1 || !ctx->cvel) return;
   DevicePtrs d = gh_dev(ctx);
   hipLaunchKernelGGL(k_cellv_leaf, dim3(cdiv(ctx->gtot, 256)), dim3(256), 0, ctx->stream, d, ctx->cvel);
@@ -907,6 +932,7 @@ int gh_tree_extrapolate_impl(gh_ctx *ctx)
 {
   if (!ctx->tree_valid || !ctx->cvel) return gh_tree_build_impl(ctx);
   hipLaunchKernelGGL(k_extrapolate_cells, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->cvel, gh_time_dev(ctx), ctx->Ncell);
+  ctx->tree_stale = true;
   gh_pack_posm(ctx);
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
@@ -920,5 +946,6 @@ int gh_tree_restock_impl(gh_ctx *ctx)
   gh_pack_posm(ctx);
   GH_CHECK(ctx, hipGetLastError());
   ctx->tree_valid = true;
+  ctx->tree_stale = false;
   return GH_OK;
 }

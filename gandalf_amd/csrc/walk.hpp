@@ -208,6 +208,61 @@ __device__ void walk_dfs_stream(const DevicePtrs &d, WalkLDS<int> &L, unsigned i
   range_drain(L, R, true, tile);
 }
 
+
+// Depth-first walk whose stack entries carry a 16-bit mask of the group's LEAF cells that still descend through the node.
+// The reference walks the tree once per leaf cell (Tree.cpp:291-381, 562-617).  With a freshly stocked tree a group-level
+// walk plus distance tests finds the same neighbours; with an EXTRAPOLATED tree (Tree::ExtrapolateCellProperties: every
+// cell drifted with its own mean velocity) the boxes of a parent and its children no longer nest and particles may have
+// left their cell's box, so the reference loses neighbours - exactly those whose leaf, or any ancestor of it, fails the
+// box test of the target leaf.  To lose the same ones every (node, leaf) decision is taken with that leaf's own box:
+// cls(node, code, inmask, first, cnt) returns the mask of leaves whose test the node passes.  Ranges are emitted with
+// tag = image code | leaf mask << 5.
+template <class Classify, class Tile>
+__device__ void walk_dfs_stream_masked(const DevicePtrs &d, WalkLDS<int> &L, unsigned short *smask, unsigned int codes,
+                                       unsigned int mask0, Classify cls, Tile tile, int *flags)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = lanemask_lt();
+  int top = 0;
+  for (int c = 0; c < 27; c++) {
+    if (codes & (1u << c)) { if (lane == 0) { L.stack[top] = 0 | (c << GH_NODE_BITS); smask[top] = (unsigned short) mask0; } top++; }
+  }
+  RangeState R; R.nrb = 0; R.nslots = 0;
+  __syncthreads();
+  while (top > 0) {
+    const int p = pop_width(top);
+    const int newtop = top - p;
+    unsigned int om = 0;
+    int n = 0, code = 0, first = 0, cnt = 0;
+    if (lane < p) {
+      const int e = L.stack[top - 1 - lane];
+      n = e & GH_NODE_MASK; code = e >> GH_NODE_BITS;
+      om = cls(n, code, (unsigned int) smask[top - 1 - lane], first, cnt);
+    }
+    const bool open = om != 0 && n < d.gtot - 1, emit = om != 0 && n >= d.gtot - 1 && cnt > 0;
+    const unsigned long long opm = __ballot(open), em = __ballot(emit);
+    __syncthreads();
+    if (open) {
+      const int pos = newtop + 2*__popcll(opm & lt);
+      if (pos + 1 < GH_SCAP) {
+        L.stack[pos] = (2*n + 1) | (code << GH_NODE_BITS); smask[pos] = (unsigned short) om;
+        L.stack[pos + 1] = (2*n + 2) | (code << GH_NODE_BITS); smask[pos + 1] = (unsigned short) om;
+      }
+    }
+    top = newtop + 2*__popcll(opm);
+    if (top > GH_SCAP) { if (lane == 0) atomicOr(flags, FLAG_FRONTIER_OVERFLOW); top = GH_SCAP; }
+    if (emit) {
+      const int pos = R.nrb + __popcll(em & lt);
+      L.rb_first[pos] = first; L.rb_cnt[pos] = cnt; L.rb_tag[pos] = code | ((int) om << 5);
+    }
+    R.nrb += __popcll(em);
+    R.nslots += wave_sum_i(emit ? cnt : 0);
+    if (R.nslots >= 64 || R.nrb > GH_RBCAP - 64) range_drain(L, R, false, tile);
+    else __syncthreads();
+  }
+  range_drain(L, R, true, tile);
+}
+
 // which periodic image codes a search box [lo,hi] needs
 __device__ __forceinline__ unsigned int image_codes(const Domain &dom, int ndim, const double lo[3], const double hi[3])
 {

@@ -186,7 +186,10 @@ def test_gravity_list_overflow_falls_back_to_fused_kernel(monkeypatch):
 
 
 LEVEL_CASES = ["adsod_1d_levels", "box3d_4k_levels", "plummer_4k_levels", "adsod_1d_levels_single", "plummer_4k_levels_single",
-               "adsod_1d_combo_levels", "plummer_4k_combo_levels"]   # combinations with cd2010, conductivity, re-stock / extrapolation, fast_quadrupole, gadget2
+               "adsod_1d_combo_levels", "plummer_4k_combo_levels",
+               "adsod_1d_ts3_levels"]   # + tree extrapolation between stockings (ntreestockstep = 3, block timesteps): the per-leaf search of
+                                        # stale boxes.  (The same on the Plummer sphere makes the reference itself abort: its assertion
+                                        # GradhSph.cpp:684 finds a lost neighbour on the direct list.)   # combinations with cd2010, conductivity, re-stock / extrapolation, fast_quadrupole, gadget2
 
 
 @pytest.mark.parametrize("case", LEVEL_CASES)
