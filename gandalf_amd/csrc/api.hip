@@ -64,6 +64,12 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
   }
   int flags = 0;
   GH_CHECK(ctx, hipMemcpy(&flags, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (!ctx->exact_armed && ctx->nranks == 1) {
+    // a tree build split equal coordinates at a median: from now on every build also enqueues the (gated) exact kernels
+    int tie[2] = {0, 0};
+    GH_CHECK(ctx, hipMemcpy(tie, ctx->d_blk + 13, sizeof(tie), hipMemcpyDeviceToHost));
+    if (tie[0] | tie[1]) ctx->exact_armed = true;
+  }
   if (flags) {
     GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
     std::string m = std::string(where) + ":";
@@ -248,8 +254,9 @@ static void free_particles(gh_ctx *ctx)
     if (ctx->W[k]) (void) hipFree(ctx->W[k]); ctx->W[k] = nullptr;
     if (ctx->Wpre[k]) (void) hipFree(ctx->Wpre[k]); ctx->Wpre[k] = nullptr;
   }
-  void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals};
+  void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals, ctx->qs_ids, ctx->qs_keys};
   for (void *p : ptrs) if (p) (void) hipFree(p);
+  ctx->qs_ids = nullptr; ctx->qs_keys = nullptr;
   ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
   ctx->iota_N = -1;
   ctx->Ncap = 0; ctx->N = 0; ctx->tree_layout_N = -1; ctx->tree_valid = false;
@@ -356,6 +363,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->n = 0; ctx->Nsteps = 0; ctx->t = 0.0; ctx->timestep = 0.0;
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
   ctx->rebuild_tree = true;
+  ctx->exact_armed = false;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
   GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
@@ -412,9 +420,7 @@ extern "C" int gh_upload_field(gh_ctx *ctx, int field, const double *src)
 extern "C" int gh_build_tree(gh_ctx *ctx)
 {
   if (!ctx || ctx->N <= 0) return GH_ERR_INVALID;
-  gh_phase_begin(ctx, GH_T_BUILD_TREE);
-  int rc = gh_tree_build_impl(ctx);
-  gh_phase_end(ctx, GH_T_BUILD_TREE);
+  int rc = gh_tree_build_checked(ctx);
   if (rc) return rc;
   return gh_sync_collect(ctx, "gh_build_tree");
 }
@@ -656,6 +662,22 @@ static int build_tree_timed(gh_ctx *ctx)
   return rc;
 }
 
+// build at a point where the host may synchronise (gh_build_tree, the setup passes): a build that meets the context's
+// first tie between equal coordinates at a median is redone at once in exact mode, so that lattice initial conditions
+// get the reference's tree from the first pass on.  (A first tie inside a multi-step gh_step call is resolved by the
+// fast rule for that one build; the exact kernels are armed from the next synchronisation on.)
+int gh_tree_build_checked(gh_ctx *ctx)
+{
+  int rc = build_tree_timed(ctx);
+  if (rc || ctx->exact_armed || ctx->nranks > 1) return rc;
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int tie[2] = {0, 0};
+  GH_CHECK(ctx, hipMemcpy(tie, ctx->d_blk + 13, sizeof(tie), hipMemcpyDeviceToHost));
+  if (!(tie[0] | tie[1])) return GH_OK;
+  ctx->exact_armed = true;
+  return build_tree_timed(ctx);
+}
+
 // HydroTree::BuildTree as MainLoop calls it (HydroTree.cpp:325-343): rebuild every ntreebuildstep steps and on the first
 // step after the setup (rebuild_tree), re-stock the existing tree otherwise
 static int step_tree_timed(gh_ctx *ctx)
@@ -714,7 +736,7 @@ int gh_setup_passes(gh_ctx *ctx, int initial_h_provided)
   // first if no h was provided, then tree + density, then (iteration loop :381-473) tree + density + forces
   const int npass = initial_h_provided ? 2 : 3;
   for (int p = 0; p < npass; p++) {
-    if ((rc = build_tree_timed(ctx))) return rc;
+    if ((rc = gh_tree_build_checked(ctx))) return rc;
     if ((rc = density_and_hmax(ctx, false))) return rc;
     if ((rc = gh_sync_collect(ctx, "gh_setup/density"))) return rc;
   }
@@ -726,7 +748,7 @@ int gh_setup_passes(gh_ctx *ctx, int initial_h_provided)
   if ((rc = forces_impl(ctx))) return rc;
   ctx->mac_bootstrap = false;
   if (relmac) {
-    if ((rc = build_tree_timed(ctx))) return rc;
+    if ((rc = gh_tree_build_checked(ctx))) return rc;
     gh_zero_acc_impl(ctx);
     if ((rc = forces_impl(ctx))) return rc;
   }

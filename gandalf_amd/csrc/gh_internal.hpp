@@ -105,6 +105,8 @@ struct gh_ctx {
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
   double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
+  int *qs_ids = nullptr; double *qs_keys = nullptr;   // exact (quick-select order) build, tree.hip
+  bool exact_armed = false;        // a build split equal coordinates: every later build runs the gated exact kernels
   int *leafact = nullptr;          // [gtot] active particles per leaf at the last stocking (ntreestockstep > 1 and Nlevels > 1 only)
   double *leaf_amin = nullptr;
   bool mac_bootstrap = false;      // gh_setup's first force pass of a relative MAC runs geometric (SphSimulation.cpp:381-388)
@@ -215,6 +217,7 @@ DevicePtrs gh_dev_own(gh_ctx *ctx);   // this rank's own particles only (element
 int gh_alloc_particles(gh_ctx *ctx, int64_t N);
 int gh_alloc_tree(gh_ctx *ctx);
 int gh_tree_build_impl(gh_ctx *ctx);
+int gh_tree_build_checked(gh_ctx *ctx);   // ... and, at a host synchronisation point, redone in exact mode if it met its first tie
 int gh_tree_extrapolate_impl(gh_ctx *ctx);  // Tree::ExtrapolateCellProperties: cells drift with their stocked mean velocity
 int gh_leaf_active_counters(gh_ctx *ctx);   // KDTree::UpdateActiveParticleCounters (KDTree.cpp:1217-1254)
 int gh_tree_restock_impl(gh_ctx *ctx);   // KDTree::StockTree: same cells and particle order, properties from the current r, h

@@ -92,6 +92,7 @@ struct LevelArgs {
   unsigned int *Wpre[3];
   double *dbbmin, *dbbmax;
   int *kdiv;
+  int *tie;              // set when a median split separates equal coordinates (the reference's quick-select order then matters)
   int level, nwords;
   int p0, pn;            // particle range [p0, p0 + pn) the build works on: everything on one rank, the rank's own cell otherwise
   int jbase;             // k_build_subtree: first level-L0 cell of the range
@@ -121,6 +122,7 @@ __global__ void k_mark_side(DevicePtrs d, LevelArgs a)
   if (p == first) {
     // the cell's first particle also writes the children's inherited boxes (median = first of the right half)
     const double rdiv = d.f[D_RX + kd][a.P[kd][first + half]];
+    if (half > 0 && d.f[D_RX + kd][a.P[kd][first + half - 1]] == rdiv) *a.tie = 1;
     const int c1 = 2*n + 1, c2 = 2*n + 2;
     for (int k = 0; k < 3; k++) {
       a.dbbmin[c1*3 + k] = bmin[k]; a.dbbmax[c1*3 + k] = (k == kd) ? rdiv : bmax[k];
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(1024) void k_build_subtree(DevicePtrs d, LevelArgs 
       }
       double rdiv = a.dbbmin[n*3 + kd];
       if (c > 0) rdiv = d.f[D_RX + kd][s_gid[s_L[cur][kd][first - first0 + c/2]]];
+      if (c > 1 && d.f[D_RX + kd][s_gid[s_L[cur][kd][first - first0 + c/2 - 1]]] == rdiv) *a.tie = 1;
       const int c1 = 2*n + 1, c2 = 2*n + 2;
       for (int k = 0; k < 3; k++) {
         a.dbbmin[c1*3 + k] = a.dbbmin[n*3 + k]; a.dbbmax[c1*3 + k] = a.dbbmax[n*3 + k];
@@ -311,6 +314,156 @@ __global__ __launch_bounds__(1024) void k_build_subtree(DevicePtrs d, LevelArgs 
     cur ^= 1;
   }
   for (int i = tid; i < cnt; i += 1024) perm_out[first0 + i] = s_gid[s_L[cur][0][i]];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Exact mode: KDTree::QuickSelect restated (KDTree.cpp:682-750).
+//
+// The level-wise build above puts the cN/2 particles with the smallest coordinate on the left; WHICH of several
+// particles with exactly the median coordinate go left is decided, in the reference, by the dynamics of its in-place
+// quick-select on the index array `ids` (pivot = middle element of the current range, moved to the end; one Lomuto pass
+// that keeps the "<= pivot" elements in order and rotates the "> pivot" ones; repeat on the side that holds the
+// median).  Lattice initial conditions (particle_distribution = cubic_lattice / hexagonal_lattice in a box) have
+// thousands of equal coordinates, and the tree - hence the tree force - depends on that order.  When the fast build
+// reports such a tie (LevelArgs::tie) the build is redone by this kernel: one workgroup per cell of a level performs
+// the SAME sequence of passes and swaps on the SAME initial order (ids[i] = i in the caller's particle order,
+// KDTree.cpp:281), a block of up to 1024 consecutive elements per step.  A Lomuto step "ids[j] <= pivot: swap with
+// ids[jguess++]" touches position j and the front of the region of "> pivot" elements [jguess, j); as long as a block
+// is no longer than that region, its swaps are disjoint and can be done side by side - the result is the serial
+// algorithm's, element for element.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_qsel_init(DevicePtrs d, int *ids, const int *gate)
+{
+  if (gate && !*gate) return;
+  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  if (p < d.N) ids[d.iorig[p]] = p;                 // caller order -> current storage position
+}
+
+__global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level, int *ids, double *keys, double *dbbmin, double *dbbmax,
+                                                        int *kdiv, const int *gate)
+{
+  if (gate && !*gate) return;
+  __shared__ int s_wave[16];
+  __shared__ int s_tot;
+  __shared__ double s_piv;
+  const int n = (1 << level) - 1 + blockIdx.x;
+  const int first = d.cfirst[n], cnt = d.cN[n];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  double rkmax = 0.0;
+  int kd = 0;
+  for (int k = 0; k < d.ndim; k++) { const double ext = dbbmax[n*3 + k] - dbbmin[n*3 + k]; if (ext > rkmax) { rkmax = ext; kd = k; } }
+  for (int p = first + tid; p < first + cnt; p += nt) keys[p] = d.f[D_RX + kd][ids[p]];
+  __syncthreads();
+  int left = first, right = first + cnt - 1;
+  const int jpivot = first + cnt/2;
+  double rpivot = dbbmin[n*3 + kd];
+  // block-wide: exclusive prefix of a flag over the threads, and the total
+  auto scan = [&](bool f, int &pre) -> int {
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) s_wave[wv] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int w = 0; w < nw; w++) { const int c = s_wave[w]; s_wave[w] = run; run += c; } s_tot = run; }
+    __syncthreads();
+    pre = s_wave[wv] + __popcll(m & (lane ? ((~0ull) >> (64 - lane)) : 0ull));
+    const int tot = s_tot;
+    __syncthreads();
+    return tot;
+  };
+  if (cnt > 0) {
+    for (;;) {
+      const int jg0 = (left + right)/2;                       // pivot guess: the middle element ...
+      if (tid == 0) {
+        s_piv = keys[jg0];
+        const int ti = ids[jg0]; ids[jg0] = ids[right]; ids[right] = ti;        // ... parked at the end of the range
+        const double tk = keys[jg0]; keys[jg0] = keys[right]; keys[right] = tk;
+      }
+      __syncthreads();
+      rpivot = s_piv;
+      int jguess = left, j = left;
+      while (j < right) {
+        const int g = j - jguess;                             // elements > pivot seen so far: they occupy [jguess, j)
+        if (g == 0) {
+          // elements <= pivot swap with themselves: skip the whole run, stop at the first element > pivot
+          const int nv = min(nt, right - j);
+          const bool gt = tid < nv && !(keys[j + tid] <= rpivot);
+          int pre;
+          const int ngt = scan(gt, pre);
+          int run = nv;
+          if (ngt > 0) {                                       // position of the first one
+            if (gt && pre == 0) s_tot = tid;
+            __syncthreads();
+            run = s_tot;
+            __syncthreads();
+          }
+          jguess += run; j += run;
+          if (run < nv) j += 1;
+        }
+        else {
+          const int w = min(min(nt, g), right - j);
+          bool le = false; int idb = 0; double kb = 0.0;
+          if (tid < w) { kb = keys[j + tid]; idb = ids[j + tid]; le = kb <= rpivot; }
+          int pre;
+          const int c = scan(le, pre);
+          int idt = 0; double kt = 0.0;
+          if (le) { idt = ids[jguess + pre]; kt = keys[jguess + pre]; }
+          __syncthreads();
+          if (le) { ids[jguess + pre] = idb; keys[jguess + pre] = kb; ids[j + tid] = idt; keys[j + tid] = kt; }
+          __syncthreads();
+          jguess += c; j += w;
+        }
+      }
+      if (tid == 0) {                                          // the pivot goes between the two sides
+        const int ti = ids[right]; ids[right] = ids[jguess]; ids[jguess] = ti;
+        const double tk = keys[right]; keys[right] = keys[jguess]; keys[jguess] = tk;
+      }
+      __syncthreads();
+      if (jguess < jpivot) left = jguess + 1;
+      else if (jguess > jpivot) right = jguess - 1;
+      else break;
+    }
+  }
+  if (tid == 0) {
+    const int c1 = 2*n + 1, c2 = 2*n + 2;
+    for (int k = 0; k < 3; k++) {
+      dbbmin[c1*3 + k] = dbbmin[n*3 + k]; dbbmax[c1*3 + k] = (k == kd) ? rpivot : dbbmax[n*3 + k];
+      dbbmin[c2*3 + k] = (k == kd) ? rpivot : dbbmin[n*3 + k]; dbbmax[c2*3 + k] = dbbmax[n*3 + k];
+    }
+    kdiv[n] = kd;
+  }
+}
+
+__global__ void k_tie_reset(int *t) { t[1] |= t[0]; t[0] = 0; }
+
+__global__ void k_copy_if(const int *src, int *dst, int n, const int *gate)
+{
+  if (gate && !*gate) return;
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// enqueue the exact build behind the fast one; every kernel returns at once unless *gate (the fast build's tie flag) is set.
+// Leaves the reference's final `ids` order in perm_out.
+static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
+{
+  const int N = (int) ctx->N;
+  if (!ctx->qs_ids) {
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->qs_ids, sizeof(int)*(size_t) ctx->Ncap));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->qs_keys, sizeof(double)*(size_t) ctx->Ncap));
+  }
+  DevicePtrs d = gh_dev(ctx);
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_qsel_init, dim3(cdiv(N, 256)), dim3(256), 0, s, d, ctx->qs_ids, gate);
+  for (int l = 0; l < ctx->ltot; l++) {
+    int mx = 1;
+    for (int j = 0; j < (1 << l); j += std::max(1, (1 << l)/64)) mx = std::max(mx, ctx->h_cN[(1 << l) - 1 + j]);   // cells of a level differ by at most 1
+    mx += 1;
+    int bs = 64;
+    while (bs < mx && bs < 1024) bs <<= 1;
+    hipLaunchKernelGGL(k_qselect_level, dim3(1 << l), dim3(bs), 0, s, d, l, ctx->qs_ids, ctx->qs_keys, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, gate);
+  }
+  hipLaunchKernelGGL(k_copy_if, dim3(cdiv(N, 256)), dim3(256), 0, s, ctx->qs_ids, perm_out, N, gate);
+  return GH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -813,6 +966,8 @@ int gh_tree_build_impl(gh_ctx *ctx)
     for (int k = 1; k < ctx->ndim; k++) GH_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
   }
 
+  // d_blk[13]: this build split equal coordinates; d_blk[14]: ... some build since the last look did (sticky)
+  hipLaunchKernelGGL(k_tie_reset, dim3(1), dim3(1), 0, s, ctx->d_blk + 13);
   int pb = 0;
   const int nwords = (pn + 63)/64;
   auto level_args = [&](int l) {
@@ -820,6 +975,7 @@ int gh_tree_build_impl(gh_ctx *ctx)
     for (int k = 0; k < 3; k++) { a.P[k] = ctx->P[pb][k]; a.Pn[k] = ctx->P[pb ^ 1][k]; a.W[k] = ctx->W[k]; a.Wpre[k] = ctx->Wpre[k]; }
     a.cellnode = ctx->cellnode[pb]; a.cellnode_next = ctx->cellnode[pb ^ 1];
     a.side = ctx->side; a.dbbmin = ctx->dbbmin; a.dbbmax = ctx->dbbmax; a.kdiv = ctx->kdiv;
+    a.tie = ctx->d_blk + 13;
     a.level = l; a.nwords = nwords;
     a.p0 = p0; a.pn = pn; a.jbase = 0;
     return a;
@@ -844,6 +1000,8 @@ int gh_tree_build_impl(gh_ctx *ctx)
 
   // gather every particle array into tree order (perm[new] = old position).  The two pointer tables
   // (buffer 0 -> 1 and 1 -> 0) live in device memory since allocation: no host synchronisation here.
+  // equal coordinates at a median: the reference's own quick-select order decides (exact mode, armed once a tie was seen)
+  if (ctx->exact_armed && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], ctx->d_blk + 13))) return rc; }
   const int *perm = ctx->P[pb][0];
   hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn);
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, p0, pn);
