@@ -82,6 +82,7 @@ SYMBOLS = {
     "gh_get_block_clock": (C.c_int, [_CTX, _PI, _PD]),
     "gh_get_active_count": (C.c_int, [_CTX, _PL, C.c_int]),
     "gh_gather_neighbours": (C.c_int, [_CTX, C.c_int64, _PL, _PI]),
+    "gh_gather_neighbours_at": (C.c_int, [_CTX, _PD, C.c_double, _PI, C.c_int32]),
     "gh_get_timers": (C.c_int, [_CTX, _PD, C.POINTER(Stats), C.POINTER(Stats)]),
     "gh_reset_timers": (C.c_int, [_CTX]),
     "gh_comm_init": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_void_p]),
@@ -375,6 +376,17 @@ class GandalfHip:
             rc = self.lib.gh_gather_neighbours(self.ctx, cap, offs.ctypes.data_as(_PL), ids.ctypes.data_as(_PI))
         self._chk(rc)
         return offs, ids[:offs[n]]
+
+    def gather_neighbours_at(self, rp, rsearch, cap=4096):
+        """point query (Tree.cpp:208-280): ids of the particles within rsearch of rp; None if more than cap"""
+        rp = np.ascontiguousarray(rp, dtype=np.float64)
+        out = np.zeros(cap, dtype=np.int32)
+        n = self.lib.gh_gather_neighbours_at(self.ctx, _dp(rp), float(rsearch), out.ctypes.data_as(_PI), cap)
+        if n == -1:
+            return None
+        if n < 0:
+            raise GhError(n, self.lib.gh_last_error(self.ctx).decode())
+        return out[:n]
 
     def timers(self):
         ms = (C.c_double * len(GH_T_NAMES))()

@@ -66,6 +66,8 @@ struct gh_dd {
   // published subtree tops
   char *pub_send = nullptr, *pub_recv = nullptr; size_t pub_bytes = 0;
   int F = 0;                         // fine entries: 2^F per published bottom cell
+  const char *fine_base = nullptr; size_t fine_stride = 0;   // where the gathered fine tables currently are
+  char *comb_send = nullptr, *comb_recv = nullptr;           // subtree tops + fine tables in one all-gather
   double fine_widen = 1.0;           // the density widening the gathered fine table was built with
   LetGeom *fine = nullptr, *fine_all = nullptr;      // [2^(P+F)] own, [nranks][2^(P+F)] everybody's
   // locally essential tree
@@ -379,7 +381,7 @@ __global__ void k_pub_pack(DevicePtrs d, int L, int P, int rank, PubRec *out)
   out[e] = r;
 }
 
-__global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, const PubRec *all)
+__global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, const char *all, size_t stride)
 {
   const int ncell = (2 << P) - 1;
   const int t = blockIdx.x*blockDim.x + threadIdx.x;
@@ -390,7 +392,7 @@ __global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, c
   const int j = e - ((1 << p) - 1);
   if (r == self) return;
   const int n = (1 << (L + p)) - 1 + (r << p) + j;
-  const PubRec &q = all[t];
+  const PubRec &q = ((const PubRec*) (all + (size_t) r*stride))[e];
   d.cbox[n] = q.b; d.ch[n] = q.h; d.cgeo[n] = q.g; d.ccom[n] = q.c;
   if (d.cquad) d.cquad[n] = q.q;
 }
@@ -439,7 +441,7 @@ __device__ __forceinline__ bool let_may_open(const LetGeom &Q, const CellBox &yb
 // grid (2^P, nranks): workgroup (j, r) marks what rank r needs of the subtree below this rank's published bottom
 // cell j, level by level with the visit flags in LDS
 template <int PHASE>
-__global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const LetGeom *fine_all,
+__global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const char *fine_base, size_t fine_stride,
                                                   int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags)
 {
   const int r = blockIdx.y;
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
   __shared__ LetGeom s_q[1 << DD_PMAX];
   __shared__ unsigned char s_vis[2][2048];
   const int nq = 1 << P, nf = 1 << F;
-  const LetGeom *fine = fine_all + ((size_t) r << (P + F));
+  const LetGeom *fine = (const LetGeom*) (fine_base + (size_t) r*fine_stride);
   if ((int) threadIdx.x < nq) {
     // published bottom cell of the destination = union of its fine entries
     LetGeom q = fine[(size_t) threadIdx.x*nf];
@@ -658,7 +660,7 @@ void gh_dd_free(gh_ctx *ctx)
   gh_dd *D = ctx->dd;
   if (!D) return;
   void *ptrs[] = {D->topcell, D->cells, D->hist, D->hist_all, D->cand, D->cand_all, D->box6, D->box6_all, D->mig_cnt, D->mig_slot,
-                  D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
+                  D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->comb_send, D->comb_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
                   D->let_send, D->let_recv, D->dt_all};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   delete D;
@@ -691,6 +693,11 @@ static int dd_alloc(gh_ctx *ctx)
   D->F = std::max(0, std::min(DD_FMAX, ctx->lgroup - ctx->L - D->P));
   GH_CHECK(ctx, hipMalloc((void**) &D->fine, sizeof(LetGeom)*((size_t) 1 << (D->P + D->F))));
   GH_CHECK(ctx, hipMalloc((void**) &D->fine_all, sizeof(LetGeom)*((size_t) W << (D->P + D->F))));
+  {
+    const size_t blk = D->pub_bytes + sizeof(LetGeom)*((size_t) 1 << (D->P + D->F));
+    GH_CHECK(ctx, hipMalloc((void**) &D->comb_send, blk));
+    GH_CHECK(ctx, hipMalloc((void**) &D->comb_recv, blk*W));
+  }
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cnt, sizeof(int)*8*GH_MAX_RANKS));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_off, sizeof(long long)*2*GH_MAX_RANKS));
   // a rank can need, at most, all of another rank's subtree
@@ -775,6 +782,7 @@ static int dd_publish_fine(gh_ctx *ctx, double widen)
   hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->L, PF, ctx->rank, kr, widen, D->fine);
   DD_OP(ctx, dd_allgather(ctx, D->fine, D->fine_all, sizeof(LetGeom)*((size_t) 1 << PF)));
   D->fine_widen = widen;
+  D->fine_base = (const char*) D->fine_all; D->fine_stride = sizeof(LetGeom)*((size_t) 1 << PF);
   return GH_OK;
 }
 
@@ -786,10 +794,14 @@ int gh_dd_publish(gh_ctx *ctx, int hmax_only)
   const int ncell = (2 << P) - 1;
   DevicePtrs d = gh_dev(ctx);
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
-  { const int rc = dd_publish_fine(ctx, 1.0); if (rc) return rc; }
-  hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->pub_send);
-  DD_OP(ctx, dd_allgather(ctx, D->pub_send, D->pub_recv, D->pub_bytes));
-  hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, (const PubRec*) D->pub_recv);
+  // subtree tops and fine geometry tables travel in ONE all-gather: per rank [PubRec x ncell | LetGeom x 2^(P+F)]
+  const int PF = P + D->F;
+  const size_t fine_bytes = sizeof(LetGeom)*((size_t) 1 << PF), blk = D->pub_bytes + fine_bytes;
+  hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->comb_send);
+  hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, d, L, PF, ctx->rank, kr, 1.0, (LetGeom*) (D->comb_send + D->pub_bytes));
+  DD_OP(ctx, dd_allgather(ctx, D->comb_send, D->comb_recv, blk));
+  D->fine_widen = 1.0; D->fine_base = D->comb_recv + D->pub_bytes; D->fine_stride = blk;
+  hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, D->comb_recv, blk);
   gh_stock_top_levels(ctx, L - 1, hmax_only);
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
@@ -831,9 +843,9 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   hipLaunchKernelGGL(k_let_invalidate, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, s, d, L, P, ctx->rank, ctx->Ncell);
   GH_CHECK(ctx, hipMemsetAsync(D->let_cnt, 0, sizeof(int)*8*GH_MAX_RANKS, s));
   const dim3 grid(1 << P, W);
-  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_all, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
   // counts to everybody (2 ints per pair), then sizes on the host
   DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*2*GH_MAX_RANKS));
   std::vector<int> all((size_t) W*2*GH_MAX_RANKS);

@@ -223,6 +223,11 @@ int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep);
  * offsets: [N+1]; ids: [cap]; returns GH_ERR_CAPACITY (and the needed size in offsets[N]) if
  * cap is too small. */
 int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, int32_t *ids);
+/* replaces: NeighbourSearch::GetGatherNeighbourList(rp, rsearch, ...) -> Tree::ComputeGatherNeighbourList (NeighbourSearch.h:82,
+ * Tree.cpp:208-280; the sink search uses it): caller-order ids of the particles with |r - rp|^2 < rsearch^2 around an arbitrary
+ * point rp[ndim].  Returns the count (>= 0), -1 if more than `cap` were found (the reference's overflow answer), or
+ * GH_ERR_HIP / GH_ERR_UNSUPPORTED (bad arguments, no tree, more than one rank). */
+int gh_gather_neighbours_at(gh_ctx *ctx, const double *rp, double rsearch, int32_t *list, int32_t cap);
 /* device time (ms) spent in each phase since the last call to gh_reset_timers, reference block
  * names (CodeTiming: BUILD_TREE, SPH_PROPERTIES, SPH_HYDRO_FORCES / SPH_ALL_FORCES, KDK) */
 enum { GH_T_BUILD_TREE = 0, GH_T_SPH_PROPERTIES, GH_T_SPH_FORCES, GH_T_KDK,

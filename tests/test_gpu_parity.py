@@ -306,3 +306,21 @@ def test_hybrid_run_from_ic_matches_reference():
     assert relerr(sim.download("rho"), g["final_rho"]) < 1e-9
     assert np.max(np.abs(nb.download("r") - g["final_star_r"])) < 1e-10*np.abs(g["final_star_r"]).max()
     assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9
+
+
+def test_point_gather_query_matches_brute_force():
+    """gh_gather_neighbours_at (NeighbourSearch::GetGatherNeighbourList(rp, rsearch, ...), Tree.cpp:208-280): the set
+    of particles within rsearch of arbitrary points, against a brute-force distance test; overflow answer -1"""
+    g = load_golden("plummer_4k_passes")
+    sim, _ = make("plummer_4k")
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.build_tree()
+    r = g["in_r"]
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        rp = r[rng.integers(len(r))] + 0.05*rng.standard_normal(3)
+        rs = float(rng.uniform(0.05, 1.5))
+        ids = sim.gather_neighbours_at(rp, rs, cap=8192)
+        want = np.nonzero(((r - rp)**2).sum(axis=1) < rs*rs)[0]
+        assert ids is not None and np.array_equal(np.sort(ids), want)
+    assert sim.gather_neighbours_at(np.zeros(3), 5.0, cap=16) is None
