@@ -81,3 +81,10 @@ clean:
 	rm -rf $(OUT)
 
 .PHONY: all clean
+
+# ---- compile + link check of the reference-side binding (include/reference_shell/HipSphTree.h) against the reference's
+#      headers and libgandalf_hip.so.  Build container only; the binary is never run.
+hipshell: $(OUT)/hipshell_check
+$(OUT)/hipshell_check: oracle/hipshell_check.cpp include/reference_shell/HipSphTree.h include/gandalf_hip.h gandalf_amd/csrc/libgandalf_hip.so | $(OUT)/obj
+	$(CXX) -O0 -fno-exceptions -DGANDALF_DOUBLE_PRECISION -I$(REF)/src/Headers -I$(REF)/src/Common -Iinclude -Iinclude/reference_shell -w \
+	  oracle/hipshell_check.cpp -o $@ -Lgandalf_amd/csrc -lgandalf_hip -L$(OUT) -lgandalf_ref -fopenmp -Wl,-rpath,$(abspath gandalf_amd/csrc) -Wl,--unresolved-symbols=ignore-in-shared-libs
