@@ -33,7 +33,7 @@
 #define DD_G 2048            /* histogram bins per refinement of a median search */
 #define DD_CAPL 2048         /* candidates per rank and cell gathered in the final bin */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
-#define DD_FMAX 4            /* halo selection: 2^F fine geometry entries per published bottom cell */
+#define DD_FMAX 6            /* halo selection: 2^F fine geometry entries per published bottom cell */
 #define DD_REC 43            /* doubles per migrating particle: D_COUNT_BASE fields + iorig */
 
 double *gh_time_dev(gh_ctx *ctx);
@@ -48,7 +48,7 @@ struct DDCell {                      // one cell of the level being split (devic
   double rdiv; int rdiv_id, pad;     // the split: first particle of the right half in (coordinate, id) order
 };
 struct DDCand { double key; int id, pad; };
-struct LetGeom;
+struct LetGeomF;
 
 struct gh_dd {
   gh_comm_ops ops;
@@ -69,7 +69,7 @@ struct gh_dd {
   const char *fine_base = nullptr; size_t fine_stride = 0;   // where the gathered fine tables currently are
   char *comb_send = nullptr, *comb_recv = nullptr;           // subtree tops + fine tables in one all-gather
   double fine_widen = 1.0;           // the density widening the gathered fine table was built with
-  LetGeom *fine = nullptr, *fine_all = nullptr;      // [2^(P+F)] own, [nranks][2^(P+F)] everybody's
+  LetGeomF *fine = nullptr, *fine_all = nullptr;      // [2^(P+F)] own, [nranks][2^(P+F)] everybody's
   // locally essential tree
   int *let_cnt = nullptr;            // [2*MAX] cells / leaves marked per destination, then [2*MAX] received per source
   long long *let_off = nullptr;      // [2*MAX] send / receive block offsets in doubles
@@ -307,11 +307,26 @@ struct LetGeom {
   double rbmin[3], rbmax[3];          // box around the leaves' balls of radius rmax + kernrange*hmax about their centres
   double cbmin[3], cbmax[3];          // ... of radius rmax
   double dbmin[3], dbmax[3];          // box around the density search boxes of its particle groups (group box -/+ kernrange*1.05^2*hmax*widen)
-  double hmax;
   int N, pad;
 };
+// as it travels: single precision, every box face rounded OUTWARD (the tests only have to be conservative), 128 bytes
+struct LetGeomF {
+  float b[5][6];                      // bb, hb, rb, cb, db: min[3] then max[3]
+  int N, pad;
+};
+__device__ __forceinline__ float f_down(double x) { float f = (float) x; return (double) f > x ? nextafterf(f, -INFINITY) : f; }
+__device__ __forceinline__ float f_up(double x) { float f = (float) x; return (double) f < x ? nextafterf(f, INFINITY) : f; }
+__device__ __forceinline__ void let_expand(const LetGeomF &e, LetGeom &q)
+{
+  for (int k = 0; k < 3; k++) {
+    q.bbmin[k] = e.b[0][k]; q.bbmax[k] = e.b[0][3 + k]; q.hbmin[k] = e.b[1][k]; q.hbmax[k] = e.b[1][3 + k];
+    q.rbmin[k] = e.b[2][k]; q.rbmax[k] = e.b[2][3 + k]; q.cbmin[k] = e.b[3][k]; q.cbmax[k] = e.b[3][3 + k];
+    q.dbmin[k] = e.b[4][k]; q.dbmax[k] = e.b[4][3 + k];
+  }
+  q.N = e.N; q.pad = 0;
+}
 
-__global__ __launch_bounds__(256) void k_pub_fine(DevicePtrs d, int L, int PF, int rank, double kernrange, double widen, LetGeom *out)
+__global__ __launch_bounds__(256) void k_pub_fine(DevicePtrs d, int L, int PF, int rank, double kernrange, double widen, LetGeomF *out)
 {
   __shared__ double s_red[4][18];
   const int j = blockIdx.x;
@@ -351,17 +366,16 @@ __global__ __launch_bounds__(256) void k_pub_fine(DevicePtrs d, int L, int PF, i
   __syncthreads();
   if (threadIdx.x == 0) {
     const CellBox cb = d.cbox[n]; const CellH ch = d.ch[n];
-    LetGeom q;
+    LetGeomF q;
+    auto red = [&](int c) { return fmin(fmin(s_red[0][c], s_red[1][c]), fmin(s_red[2][c], s_red[3][c])); };
     for (int k = 0; k < 3; k++) {
-      q.bbmin[k] = cb.bbmin[k]; q.bbmax[k] = cb.bbmax[k]; q.hbmin[k] = ch.hbmin[k]; q.hbmax[k] = ch.hbmax[k];
-      q.rbmin[k] = fmin(fmin(s_red[0][k], s_red[1][k]), fmin(s_red[2][k], s_red[3][k]));
-      q.cbmin[k] = fmin(fmin(s_red[0][3 + k], s_red[1][3 + k]), fmin(s_red[2][3 + k], s_red[3][3 + k]));
-      q.rbmax[k] = -fmin(fmin(s_red[0][6 + k], s_red[1][6 + k]), fmin(s_red[2][6 + k], s_red[3][6 + k]));
-      q.cbmax[k] = -fmin(fmin(s_red[0][9 + k], s_red[1][9 + k]), fmin(s_red[2][9 + k], s_red[3][9 + k]));
-      q.dbmin[k] = fmin(fmin(s_red[0][12 + k], s_red[1][12 + k]), fmin(s_red[2][12 + k], s_red[3][12 + k]));
-      q.dbmax[k] = -fmin(fmin(s_red[0][15 + k], s_red[1][15 + k]), fmin(s_red[2][15 + k], s_red[3][15 + k]));
+      q.b[0][k] = f_down(cb.bbmin[k]); q.b[0][3 + k] = f_up(cb.bbmax[k]);
+      q.b[1][k] = f_down(ch.hbmin[k]); q.b[1][3 + k] = f_up(ch.hbmax[k]);
+      q.b[2][k] = f_down(red(k)); q.b[2][3 + k] = f_up(-red(6 + k));
+      q.b[3][k] = f_down(red(3 + k)); q.b[3][3 + k] = f_up(-red(9 + k));
+      q.b[4][k] = f_down(red(12 + k)); q.b[4][3 + k] = f_up(-red(15 + k));
     }
-    q.hmax = ch.hmax; q.N = cb.N; q.pad = 0;
+    q.N = cb.N; q.pad = 0;
     out[j] = q;
   }
 }
@@ -449,24 +463,24 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
   __shared__ LetGeom s_q[1 << DD_PMAX];
   __shared__ unsigned char s_vis[2][2048];
   const int nq = 1 << P, nf = 1 << F;
-  const LetGeom *fine = (const LetGeom*) (fine_base + (size_t) r*fine_stride);
+  const LetGeomF *fine = (const LetGeomF*) (fine_base + (size_t) r*fine_stride);
   if ((int) threadIdx.x < nq) {
     // published bottom cell of the destination = union of its fine entries
-    LetGeom q = fine[(size_t) threadIdx.x*nf];
+    LetGeom q;
+    let_expand(fine[(size_t) threadIdx.x*nf], q);
     for (int f = 1; f < nf; f++) {
-      const LetGeom &e = fine[(size_t) threadIdx.x*nf + f];
+      LetGeom e;
+      let_expand(fine[(size_t) threadIdx.x*nf + f], e);
       if (e.N <= 0) continue;
       if (q.N <= 0) { q = e; continue; }
       for (int k = 0; k < 3; k++) {
         q.bbmin[k] = fmin(q.bbmin[k], e.bbmin[k]); q.bbmax[k] = fmax(q.bbmax[k], e.bbmax[k]);
         q.hbmin[k] = fmin(q.hbmin[k], e.hbmin[k]); q.hbmax[k] = fmax(q.hbmax[k], e.hbmax[k]);
-      }
-      for (int k = 0; k < 3; k++) {
         q.rbmin[k] = fmin(q.rbmin[k], e.rbmin[k]); q.rbmax[k] = fmax(q.rbmax[k], e.rbmax[k]);
         q.cbmin[k] = fmin(q.cbmin[k], e.cbmin[k]); q.cbmax[k] = fmax(q.cbmax[k], e.cbmax[k]);
         q.dbmin[k] = fmin(q.dbmin[k], e.dbmin[k]); q.dbmax[k] = fmax(q.dbmax[k], e.dbmax[k]);
       }
-      q.hmax = fmax(q.hmax, e.hmax); q.N += e.N;
+      q.N += e.N;
     }
     s_q[threadIdx.x] = q;
   }
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
           const CellH yh = d.ch[n]; const CellGeo yg = d.cgeo[n];
           for (int qi = 0; qi < nq && !open; qi++) {
             if (!let_may_open<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen)) continue;
-            for (int f = 0; f < nf && !open; f++) open = let_may_open<PHASE>(fine[(size_t) qi*nf + f], yb, yh, yg, d.ndim, kernrange, widen);
+            for (int f = 0; f < nf && !open; f++) { LetGeom e; let_expand(fine[(size_t) qi*nf + f], e); open = let_may_open<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen); }
           }
         }
       }
@@ -691,10 +705,10 @@ static int dd_alloc(gh_ctx *ctx)
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_send, D->pub_bytes));
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_recv, D->pub_bytes*W));
   D->F = std::max(0, std::min(DD_FMAX, ctx->lgroup - ctx->L - D->P));
-  GH_CHECK(ctx, hipMalloc((void**) &D->fine, sizeof(LetGeom)*((size_t) 1 << (D->P + D->F))));
-  GH_CHECK(ctx, hipMalloc((void**) &D->fine_all, sizeof(LetGeom)*((size_t) W << (D->P + D->F))));
+  GH_CHECK(ctx, hipMalloc((void**) &D->fine, sizeof(LetGeomF)*((size_t) 1 << (D->P + D->F))));
+  GH_CHECK(ctx, hipMalloc((void**) &D->fine_all, sizeof(LetGeomF)*((size_t) W << (D->P + D->F))));
   {
-    const size_t blk = D->pub_bytes + sizeof(LetGeom)*((size_t) 1 << (D->P + D->F));
+    const size_t blk = D->pub_bytes + sizeof(LetGeomF)*((size_t) 1 << (D->P + D->F));
     GH_CHECK(ctx, hipMalloc((void**) &D->comb_send, blk));
     GH_CHECK(ctx, hipMalloc((void**) &D->comb_recv, blk*W));
   }
@@ -780,9 +794,9 @@ static int dd_publish_fine(gh_ctx *ctx, double widen)
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
   const int PF = D->P + D->F;
   hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->L, PF, ctx->rank, kr, widen, D->fine);
-  DD_OP(ctx, dd_allgather(ctx, D->fine, D->fine_all, sizeof(LetGeom)*((size_t) 1 << PF)));
+  DD_OP(ctx, dd_allgather(ctx, D->fine, D->fine_all, sizeof(LetGeomF)*((size_t) 1 << PF)));
   D->fine_widen = widen;
-  D->fine_base = (const char*) D->fine_all; D->fine_stride = sizeof(LetGeom)*((size_t) 1 << PF);
+  D->fine_base = (const char*) D->fine_all; D->fine_stride = sizeof(LetGeomF)*((size_t) 1 << PF);
   return GH_OK;
 }
 
@@ -796,9 +810,9 @@ int gh_dd_publish(gh_ctx *ctx, int hmax_only)
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
   // subtree tops and fine geometry tables travel in ONE all-gather: per rank [PubRec x ncell | LetGeom x 2^(P+F)]
   const int PF = P + D->F;
-  const size_t fine_bytes = sizeof(LetGeom)*((size_t) 1 << PF), blk = D->pub_bytes + fine_bytes;
+  const size_t fine_bytes = sizeof(LetGeomF)*((size_t) 1 << PF), blk = D->pub_bytes + fine_bytes;
   hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->comb_send);
-  hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, d, L, PF, ctx->rank, kr, 1.0, (LetGeom*) (D->comb_send + D->pub_bytes));
+  hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, d, L, PF, ctx->rank, kr, 1.0, (LetGeomF*) (D->comb_send + D->pub_bytes));
   DD_OP(ctx, dd_allgather(ctx, D->comb_send, D->comb_recv, blk));
   D->fine_widen = 1.0; D->fine_base = D->comb_recv + D->pub_bytes; D->fine_stride = blk;
   hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, D->comb_recv, blk);
