@@ -4,7 +4,8 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgandalf_hip.so")
+# GANDALF_HIP_LIB: another build of the same library (A/B timing of kernel variants); never a different implementation
+LIB_PATH = os.environ.get("GANDALF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgandalf_hip.so")
 
 GH_T_NAMES = ["BUILD_TREE", "SPH_PROPERTIES", "SPH_FORCES", "KDK", "GRAV_WALK"]
 

@@ -28,16 +28,18 @@ static const FLOAT big_number = 9.9e20;         // Constants.h:72
 static const FLOAT small_number = 1.0e-20;      // Constants.h:73
 static const double small_number_dp = 1.0e-50;  // Constants.h:90
 static const double big_number_dp = 9.9e50;     // Constants.h:89
+static const FLOAT pi_const = 3.14159265358979; // Constants.h:60
 static const FLOAT twopi = 6.28318530717959;    // Constants.h:61
 static const FLOAT invpi = 0.31830988618379;    // Constants.h:63
 static const FLOAT invlogetwo = 1.44269504088896;  // Constants.h:64
 static const FLOAT twothirds = 0.66666666666666666666666;
 static const FLOAT ghost_range = 2.5;           // Hydrodynamics.h:52
 
-enum { F_DEAD = 1, F_ACTIVE = 2, F_END = 4 };      // dead / active / end_timestep (Flags.h)
+enum { F_DEAD = 1, F_ACTIVE = 2, F_END = 4, F_POTMIN = 8 };      // dead / active / end_timestep / potmin (Flags.h:29-35)
 
 struct Part {                                   // Particle.h:133-223 + GradhSphParticle :285-368 (hot fields)
   int flags, iorig;
+  int sinkid;                                     // sink the particle lies inside, -1 = none (Particle.h:139)
   int level, levelneib, nstep, nlast;             // block timesteps (Particle.h:137-142)
   FLOAT r[3], v[3], a[3], atree[3], r0[3], v0[3], a0[3];
   FLOAT m, h, hrangesqd, hfactor, sound, rho, pressure, u, u0, dudt0, dudt, gpot, gpot_hydro;
@@ -63,6 +65,14 @@ struct Params {
   int ntreebuildstep, ntreestockstep;
   FLOAT boxmin[3], boxmax[3], boxsize[3], boxhalf[3];
   FLOAT h_fac, h_converge, alpha_visc, beta_visc, gamma, thetamaxsqd, courant_mult, accel_mult, energy_mult;
+  // sink particles (SphSimulation.cpp:116-136): sink_radius_mode 0 fixed, 1 hmult, 2 anything else (kernrange*h)
+  int sink_particles = 0, create_sinks = 0, smooth_accretion = 0, sink_radius_mode = 1, Nsinkfixed = -1;
+  FLOAT rho_sink = 0.0, sink_radius = 0.0, alpha_ss = 0.0, smooth_accrete_frac = 0.0, smooth_accrete_dt = 0.0;
+};
+
+struct Sink {                                   // SinkParticle, Sinks.h:48-100 (star = NbodyOracle::s[istar])
+  int istar, Ngas;
+  FLOAT radius, dmdt, menc, mmax, ketot, gpetot, rotketot, utot, taccrete, trad, trot, tvisc, angmom[3];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -73,7 +83,7 @@ struct Params {
 static inline FLOAT pow_ref(FLOAT x, int n) { return n == 1 ? x : (n == 2 ? x*x : pow(x, (FLOAT) n)); }
 
 struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKernel.h:281-408, QuinticKernel.cpp:39-60)
-  int ndim, type, tabulated; FLOAT kernnorm, kernrange, kernrangesqd;
+  int ndim, type, tabulated; FLOAT kernnorm, kernrange, kernrangesqd, invkernrange;
   // TabulatedKernel (SmoothingKernel.h:547-756, TabulatedKernel.cpp:57-100): piecewise-constant tables
   static const int res = 1000;
   FLOAT resinvkernrange, resinvkernrangesqd;
@@ -87,6 +97,7 @@ struct M4 {            // kernel object: type 0 = M4, 1 = quintic (SmoothingKern
       kernrange = 3.0; kernrangesqd = 9.0;
       kernnorm = nd == 1 ? (FLOAT) (1.0/120.0) : (nd == 2 ? invpi*(FLOAT) (7.0/478.0) : invpi*(FLOAT) (1/120.));
     }
+    invkernrange = type == 0 ? (FLOAT) 0.5 : (FLOAT) (1.0/3.0);        // M4Kernel.cpp:45, QuinticKernel.cpp:48
     resinvkernrange = res/kernrange; resinvkernrangesqd = res/kernrangesqd;
     if (tabulated) {
       const FLOAT step = kernrange/res, stepsq = kernrangesqd/res;
@@ -523,6 +534,8 @@ struct GasStar { FLOAT r[3], a[3], m, h, gpot; };
 struct Oracle {
   std::vector<GasStar> stars;
   int star_softening = 1;                         // nbody_softening
+  std::vector<Sink> sinks;                        // Sinks::sink
+  FLOAT mmean = 0.0;                              // Hydrodynamics::mmean
   Params P; M4 kern; FLOAT invndim;
   int mac_now;                          // MAC in force (geometric during the setup bootstrap, SphSimulation.cpp:381-388)
   std::vector<Part> p;          // [0,Nhydro) real, then periodic ghosts
@@ -587,7 +600,28 @@ struct Oracle {
       Ntot = Nhydro + Nghost;
     }
   }
-  void BuildTree() { p.resize(Nhydro); Nghost = 0; tree.BuildTree(0, Nhydro, p); }
+  // Hydrodynamics::DoDeleteDeadParticles, Hydrodynamics.h:158-202: every dead slot takes the last particle of the array
+  int DeleteDeadParticles() {
+    int Ndead = 0, ilast = Nhydro;
+    for (int i = 0; i < Nhydro; i++) {
+      int itype = p[i].flags;
+      while (itype & F_DEAD) {
+        Ndead++; ilast--;
+        if (i < ilast) { p[i] = p[ilast]; p[ilast].flags |= F_DEAD; p[ilast].m = 0.0; }
+        else break;
+        itype = p[i].flags;
+      }
+      if (i >= ilast - 1) break;
+    }
+    if (Ndead == 0) return 0;
+    Nhydro -= Ndead;
+    return Ndead;
+  }
+  void BuildTree() {                                                 // HydroTree::BuildTree, HydroTree.cpp:332-343
+    p.resize(Nhydro); Nghost = 0;
+    if (P.sink_particles) { DeleteDeadParticles(); p.resize(Nhydro); }
+    tree.BuildTree(0, Nhydro, p);
+  }
   // HydroTree::BuildTree inside MainLoop (HydroTree.cpp:310-372): rebuild every ntreebuildstep steps, re-stock otherwise
   // (ntreestockstep = 1; ExtrapolateCellProperties is not restated)
   void StepTree() {
@@ -612,6 +646,10 @@ struct Oracle {
     const int nd = P.ndim;
     int iteration = 0; const int iteration_max = 30;
     FLOAT dr[3], h_lower_bound = 0.0, h_upper_bound = hmax, invh, invhsqd, ssqd;
+    if (P.sink_particles) {                                            // GradhSph.cpp:163-169
+      h_lower_bound = P.h_fac*pow(pi.m/P.rho_sink, invndim);
+      if (hmax < h_lower_bound) return -1;
+    }
     const int Nneib = (int) ngb2.size();
     do {
       iteration++;
@@ -644,6 +682,24 @@ struct Oracle {
     pi.hfactor = pow_ref(invh, nd + 1);
     pi.hrangesqd = kern.kernrangesqd*pi.h*pi.h;
     pi.div_v = 0.0;
+    // potential-minimum flag for the sink search, GradhSph.cpp:270-280 - as written there: the distance tested for
+    // neighbour j is that of the neighbour before it (dr is refreshed after drsqd is taken; for j = 0 it is what the
+    // density loop left behind), and invhsqd is still that of the last h iteration
+    if (P.create_sinks == 1) {
+      pi.flags |= F_POTMIN;
+      for (int j = 0; j < Nneib; j++) {
+        const Part &ngb = p[ngb2[j]];
+        const FLOAT drsqd = Dot(dr, dr, nd);
+        for (int k = 0; k < nd; k++) dr[k] = ngb.r[k] - pi.r[k];
+        if (ngb.gpot > (FLOAT) 1.000000001*pi.gpot && drsqd*invhsqd < kern.kernrangesqd) pi.flags &= ~F_POTMIN;
+      }
+    }
+    if (pi.sinkid != -1) {                                             // inside a sink: GradhSph.cpp:309-312
+      pi.invomega = (FLOAT) 1.0; pi.zeta = (FLOAT) 0.0;
+      Thermal(pi);
+      if (P.tdavisc == 2) CullenDehnen(pi, ngb2);
+      return pi.h <= hmax ? 1 : -1;
+    }
     pi.invomega = 1.0 - h_rho_deriv(pi.h, pi.rho)*pi.invomega;
     pi.invomega = 1.0/pi.invomega;
     // Hubber et al. (2013) SPH-star conservative-gravity term in zeta (conservative_sph_star_gravity = 1, the default),
@@ -1339,6 +1395,7 @@ struct Oracle {
   void AdvanceParticles() {
     for (int i = 0; i < Nhydro; i++) {
       Part &q = p[i];
+      if (q.flags & F_DEAD) continue;                                  // SphLeapfrogKDK.cpp:99
       const FLOAT dt = t - q.tlast;
       for (int k = 0; k < P.ndim; k++) q.r[k] = q.r0[k] + q.v0[k]*dt + 0.5*q.a0[k]*dt*dt;
       for (int k = 0; k < P.ndim; k++) q.v[k] = q.v0[k] + q.a0[k]*dt;
@@ -1373,7 +1430,10 @@ struct Oracle {
   }
   void ComputeGlobalTimestep() {
     double dt_min = big_number_dp;
-    for (int i = 0; i < Nhydro; i++) { p[i].dt_next = Timestep(p[i]); dt_min = std::min(dt_min, p[i].dt_next); }
+    for (int i = 0; i < Nhydro; i++) {
+      p[i].level = 0; p[i].levelneib = 0; p[i].nstep = 1;             // Simulation.cpp:1700-1704 (level_step = 0)
+      p[i].dt_next = Timestep(p[i]); dt_min = std::min(dt_min, p[i].dt_next);
+    }
     timestep = dt_min; n = 0;
     for (int i = 0; i < Nhydro; i++) p[i].dt_next = timestep;
   }
@@ -1494,6 +1554,7 @@ struct Oracle {
   void EndTimestepBlock() {                                          // SphLeapfrogKDK.cpp:219-272
     for (int i = 0; i < Nhydro; i++) {
       Part &q = p[i];
+      if (q.flags & F_DEAD) continue;
       if (!(q.flags & F_END)) continue;
       for (int k = 0; k < P.ndim; k++) q.v[k] += 0.5*q.dt*(q.a[k] - q.a0[k]);
       for (int k = 0; k < P.ndim; k++) { q.r0[k] = q.r[k]; q.v0[k] = q.v[k]; q.a0[k] = q.a[k]; }
@@ -1509,6 +1570,7 @@ struct Oracle {
     if (P.Nlevels > 1) { EndTimestepBlock(); return; }
     for (int i = 0; i < Nhydro; i++) {
       Part &q = p[i];
+      if (q.flags & F_DEAD) { q.flags |= F_END; continue; }            // SphLeapfrogKDK.cpp:238 (end_timestep was set by ComputeGlobalTimestep)
       for (int k = 0; k < P.ndim; k++) q.v[k] += 0.5*q.dt*(q.a[k] - q.a0[k]);
       for (int k = 0; k < P.ndim; k++) { q.r0[k] = q.r[k]; q.v0[k] = q.v[k]; q.a0[k] = q.a[k]; }
       if (P.energy_integration) {
@@ -1574,7 +1636,8 @@ struct Oracle {
 struct Star {
   FLOAT r[3], v[3], a[3], adot[3], r0[3], v0[3], a0[3], adot0[3];
   FLOAT m, h, gpot, dt, dt_next, tlast, dt_internal;
-  int nstep, nlast; bool active, end_timestep;
+  FLOAT invh;                                     // 1/h of the gas particle a sink was made from (Sinks.cpp:317)
+  int nstep, nlast, level; bool active, end_timestep;
 };
 
 struct NbodyOracle {
@@ -1724,7 +1787,7 @@ void orc_set_particles(Oracle *o, int N, const double *r, const double *v, const
   for (int i = 0; i < N; i++) {
     Part &q = o->p[i];
     memset(&q, 0, sizeof(Part));
-    q.flags = F_ACTIVE; q.iorig = i;
+    q.flags = F_ACTIVE; q.iorig = i; q.sinkid = -1;
     for (int k = 0; k < nd; k++) { q.r[k] = r[i*nd + k]; q.r0[k] = q.r[k]; q.v[k] = v ? v[i*nd + k] : 0.0; q.v0[k] = q.v[k]; }
     q.m = m[i]; q.h = h[i]; q.u = u ? u[i] : 0.0; q.u0 = q.u;
     q.alpha = o->P.tdavisc ? o->P.alpha_visc_min : o->P.alpha_visc;   // SphSimulation.cpp:252-257
@@ -1789,7 +1852,7 @@ void orc_star_gas_forces(Oracle *o, double *out_a, double *out_gpot)
 static int *ifield_ptr(Part &q, const char *name)
 {
 #define I(nm) if (!strcmp(name, #nm)) return &q.nm;
-  I(level) I(levelneib) I(nstep) I(nlast) I(flags)
+  I(level) I(levelneib) I(nstep) I(nlast) I(flags) I(sinkid) I(iorig)
 #undef I
   return nullptr;
 }
@@ -1887,6 +1950,231 @@ void orc_nbody_set(NbodyOracle *o, int field, const double *in)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sink particles: Sinks::SearchForNewSinkParticles / CreateNewSinkParticle / AccreteMassToSinks, Sinks.cpp:118-777
+// (one thread, no MPI).  Sinks are stars of the N-body oracle; the gas oracle holds the SinkParticle records.
+// ---------------------------------------------------------------------------------------------
+static void CreateNewSinkParticle(Oracle &g, NbodyOracle &nb, int isink, FLOAT t)      // Sinks.cpp:282-356
+{
+  const int nd = g.P.ndim;
+  Part &part = g.p[isink];
+  Sink sk;
+  memset(&sk, 0, sizeof(Sink));
+  Star st;
+  memset(&st, 0, sizeof(Star));
+  st.dt_internal = big_number;                                        // StarParticle constructor
+  if (g.P.sink_radius_mode == 0) sk.radius = g.P.sink_radius;
+  else if (g.P.sink_radius_mode == 1) sk.radius = g.P.sink_radius*part.h;
+  else sk.radius = g.kern.kernrange*part.h;
+  st.h = g.kern.invkernrange*sk.radius;
+  st.invh = (FLOAT) 1.0/part.h;
+  st.m = part.m; st.gpot = part.gpot;
+  st.dt = part.dt; st.tlast = t; st.nstep = part.nstep; st.nlast = part.nlast; st.level = part.level;
+  st.active = (part.flags & F_ACTIVE) != 0;
+  for (int k = 0; k < nd; k++) {
+    st.r[k] = part.r[k]; st.v[k] = part.v[k]; st.a[k] = part.a[k]; st.adot[k] = 0.0;
+    st.r0[k] = part.r0[k]; st.v0[k] = part.v0[k]; st.a0[k] = part.a0[k]; st.adot0[k] = 0.0;
+  }
+  sk.istar = nb.N;
+  part.m = 0.0;
+  part.flags &= ~F_ACTIVE;
+  part.flags |= F_DEAD;
+  nb.s.push_back(st);                                                  // nbody->Nstar++ / Nnbody++ (:269-270) below
+  g.sinks.push_back(sk);
+}
+
+static void SearchForNewSinkParticles(Oracle &g, NbodyOracle &nb, int n, FLOAT t)      // Sinks.cpp:118-273
+{
+  const int nd = g.P.ndim;
+  if ((int) g.sinks.size() >= g.P.Nsinkfixed && g.P.Nsinkfixed != -1) return;
+  int isink;
+  do {
+    isink = -1;
+    FLOAT rho_max = 0.0;
+    const int Nsink = (int) g.sinks.size();
+    for (int i = 0; i < g.Nhydro; i++) {
+      bool sink_flag = true;
+      const Part &part = g.p[i];
+      if (part.flags & F_DEAD) continue;
+      if (!(part.flags & F_POTMIN)) continue;
+      if (part.rho < g.P.rho_sink || part.rho < rho_max) continue;
+      if (n%part.nstep != 0) continue;
+      for (int s = 0; s < Nsink; s++) {
+        const Star &st = nb.s[g.sinks[s].istar];
+        FLOAT dr[3], da[3], dv[3];
+        for (int k = 0; k < nd; k++) dr[k] = part.r[k] - st.r[k];
+        for (int k = 0; k < nd; k++) da[k] = part.a[k] - st.a[k];
+        for (int k = 0; k < nd; k++) dv[k] = part.v[k] - st.v[k];
+        const FLOAT drsqd = Dot(dr, dr, nd), dadr = Dot(dr, da, nd), dvdr = Dot(dr, dv, nd);
+        const FLOAT tff = (FLOAT) 0.5/sqrt(part.rho);
+        if (tff > drsqd/dvdr && dvdr > 0) sink_flag = false;
+        if (part.rho < -dadr/drsqd) sink_flag = false;
+        if (drsqd < pow(g.P.sink_radius*part.h + g.sinks[s].radius, 2)) sink_flag = false;
+        if (!sink_flag) break;
+      }
+      if (sink_flag && part.rho > rho_max) { isink = i; rho_max = part.rho; }
+    }
+    if (isink >= 0) {
+      CreateNewSinkParticle(g, nb, isink, t);
+      // total gas mass inside the new sink (direct sum, :246-253)
+      Sink &sk = g.sinks.back();
+      const Star &st = nb.s[sk.istar];
+      sk.mmax = 0.0;
+      for (int i = 0; i < g.Nhydro; i++) {
+        const Part &part = g.p[i];
+        if (part.flags & F_DEAD) continue;
+        FLOAT dr[3];
+        for (int k = 0; k < nd; k++) dr[k] = st.r[k] - part.r[k];
+        if (Dot(dr, dr, nd) < pow(sk.radius, 2)) sk.mmax += part.m;
+      }
+      nb.N++;
+    }
+  } while (isink != -1);
+}
+
+static void AccreteMassToSinks(Oracle &g, NbodyOracle &nb, int n, FLOAT timestep)      // Sinks.cpp:365-770
+{
+  const int nd = g.P.ndim;
+  const int Nsink = (int) g.sinks.size();
+  for (int i = 0; i < g.Nhydro + g.Nghost; i++) g.p[i].sinkid = -1;
+  for (int s = 0; s < Nsink; s++) g.sinks[s].Ngas = 0;
+  std::vector<int> neiblist, ilist;
+  std::vector<FLOAT> rsqdlist;
+  FLOAT dr[3], dv[3], dvtang[3];
+  // which sink each particle accretes to (:427-468; the last sink in whose radius it lies)
+  for (int s = 0; s < Nsink; s++) {
+    Sink &sk = g.sinks[s];
+    const Star &st = nb.s[sk.istar];
+    neiblist.clear();
+    g.tree.GatherPoint(st.r, sk.radius, g.p, neiblist);
+    for (size_t j = 0; j < neiblist.size(); j++) {
+      Part &part = g.p[neiblist[j]];
+      if (part.flags & F_DEAD) continue;
+      for (int k = 0; k < nd; k++) dr[k] = part.r[k] - st.r[k];
+      if (Dot(dr, dr, nd) <= sk.radius*sk.radius) { part.sinkid = s; sk.Ngas++; }
+    }
+  }
+  for (int s = 0; s < Nsink; s++) {
+    Sink &sk = g.sinks[s];
+    Star &st = nb.s[sk.istar];
+    if (sk.Ngas == 0 || n%st.nstep != 0) continue;
+    FLOAT wnorm = 0.0;
+    sk.menc = 0.0; sk.trad = 0.0; sk.tvisc = 1.0; sk.ketot = 0.0; sk.rotketot = 0.0; sk.gpetot = 0.0;
+    neiblist.clear(); ilist.clear(); rsqdlist.clear();
+    g.tree.GatherPoint(st.r, sk.radius, g.p, neiblist);
+    for (size_t j = 0; j < neiblist.size(); j++) {
+      const int i = neiblist[j];
+      Part &part = g.p[i];
+      if (part.flags & F_DEAD) continue;
+      if (part.sinkid == s) {
+        for (int k = 0; k < nd; k++) dr[k] = part.r[k] - st.r[k];
+        const FLOAT drsqd = Dot(dr, dr, nd);
+        if (drsqd > sk.radius*sk.radius) continue;
+        ilist.push_back(i); rsqdlist.push_back(drsqd);
+        part.levelneib = std::max(part.levelneib, st.level);
+      }
+    }
+    const int Nneib = (int) ilist.size();
+    for (int j = 1; j < Nneib; j++) {                                  // InsertionSortIds, InlineFuncs.h:226-248
+      const FLOAT raux = rsqdlist[j]; const int iaux = ilist[j];
+      int i;
+      for (i = j - 1; i >= 0; i--) { if (rsqdlist[i] <= raux) break; rsqdlist[i + 1] = rsqdlist[i]; ilist[i + 1] = ilist[i]; }
+      rsqdlist[i + 1] = raux; ilist[i + 1] = iaux;
+    }
+    for (int j = 0; j < Nneib; j++) {                                  // :524-561
+      const Part &part = g.p[ilist[j]];
+      if (part.flags & F_DEAD) continue;
+      for (int k = 0; k < nd; k++) dr[k] = part.r[k] - st.r[k];
+      const FLOAT drsqd = Dot(dr, dr, nd);
+      const FLOAT drmag = sqrt(drsqd) + small_number;
+      for (int k = 0; k < nd; k++) dr[k] /= drmag;
+      sk.menc += part.m;
+      wnorm += part.m*g.kern.w0(drmag*st.invh)*pow(st.invh, nd)/part.rho;
+      sk.gpetot += (FLOAT) 0.5*part.m*(st.m + sk.menc)*st.invh*g.kern.wpot(drmag*st.invh);
+      for (int k = 0; k < nd; k++) dv[k] = part.v[k] - st.v[k];
+      for (int k = 0; k < nd; k++) dvtang[k] = dv[k] - Dot(dv, dr, nd)*dr[k];
+      sk.ketot += part.m*Dot(dv, dv, nd)*g.kern.w0(drmag*st.invh)*pow(st.invh, nd)/part.rho;
+      sk.rotketot += part.m*Dot(dvtang, dvtang, nd)*g.kern.w0(drmag*st.invh)*pow(st.invh, nd)/part.rho;
+      sk.tvisc *= pow(sqrt(drmag)/part.sound/part.sound, part.m);
+      sk.trad += fabs((FLOAT) 4.0*pi_const*drsqd*part.m*Dot(dv, dr, nd)*g.kern.w0(drmag*st.invh)*pow(st.invh, nd));
+    }
+    sk.ketot *= (FLOAT) 0.5*sk.menc/wnorm;
+    sk.rotketot *= (FLOAT) 0.5*sk.menc/wnorm;
+    FLOAT macc, dt;
+    if (g.P.smooth_accretion == 1) {                                   // :573-602
+      const FLOAT efrac = std::min((FLOAT) 2.0*sk.rotketot/sk.gpetot, (FLOAT) 1.0);
+      sk.tvisc = (sqrt(st.m + sk.menc)*pow(sk.tvisc, (FLOAT) 1.0/sk.menc))/g.P.alpha_ss;
+      sk.trad = sk.menc/sk.trad;
+      sk.trot = twopi*sqrt(pow(sk.radius, 3)/(sk.menc + st.m));
+      sk.taccrete = pow(sk.trad, (FLOAT) 1.0 - efrac)*pow(sk.tvisc, efrac);
+      if (sk.mmax > small_number && sk.menc > sk.mmax) sk.taccrete *= pow(sk.mmax/sk.menc, 2);
+      dt = (FLOAT) st.nstep*timestep;
+      macc = sk.menc*std::max((FLOAT) 1.0 - (FLOAT) exp(-dt/sk.taccrete), (FLOAT) 0.0);
+      sk.dmdt = macc/dt;
+    }
+    else { macc = sk.menc; sk.dmdt = macc/timestep; }
+    FLOAT macc_temp = macc, rold[3], vold[3];
+    for (int k = 0; k < nd; k++) { rold[k] = st.r[k]; vold[k] = st.v[k]; }
+    const FLOAT mold = st.m;
+    for (int k = 0; k < nd; k++) { st.r[k] *= st.m; st.v[k] *= st.m; st.a[k] *= st.m; }
+    for (int j = 0; j < Nneib; j++) {                                  // :626-654
+      const Part &part = g.p[ilist[j]];
+      if (part.flags & F_DEAD) continue;
+      FLOAT mtemp = std::min(part.m, macc_temp);
+      dt = part.dt;
+      if (g.P.smooth_accretion == 0 || part.m - mtemp < g.P.smooth_accrete_frac*g.mmean || dt < g.P.smooth_accrete_dt*sk.trot) mtemp = part.m;
+      macc_temp -= mtemp;
+      st.m += mtemp;
+      for (int k = 0; k < nd; k++) { st.r[k] += mtemp*part.r[k]; st.v[k] += mtemp*part.v[k]; st.a[k] += mtemp*part.a[k]; }
+      sk.utot += mtemp*part.u;
+      if (macc_temp < small_number) break;
+    }
+    for (int k = 0; k < nd; k++) { st.r[k] /= st.m; st.v[k] /= st.m; st.a[k] /= st.m; }
+    for (int k = 0; k < nd; k++) { st.r0[k] = st.r[k]; st.v0[k] = st.v[k]; st.a0[k] = st.a[k]; }
+    for (int k = 0; k < nd; k++) { dr[k] = rold[k] - st.r[k]; dv[k] = vold[k] - st.v[k]; }
+    if (nd == 3) {
+      sk.angmom[0] += mold*(dr[1]*dv[2] - dr[2]*dv[1]);
+      sk.angmom[1] += mold*(dr[2]*dv[0] - dr[0]*dv[2]);
+      sk.angmom[2] += mold*(dr[0]*dv[1] - dr[1]*dv[0]);
+    }
+    else if (nd == 2) sk.angmom[2] += mold*(dr[0]*dv[1] - dr[1]*dv[0]);
+    for (int j = 0; j < Nneib; j++) {                                  // :685-729
+      Part &part = g.p[ilist[j]];
+      if (part.flags & F_DEAD) continue;
+      FLOAT mtemp = std::min(part.m, macc);
+      dt = part.dt;
+      if (g.P.smooth_accretion == 0 || part.m - mtemp < g.P.smooth_accrete_frac*g.mmean || dt < g.P.smooth_accrete_dt*sk.trot) {
+        mtemp = part.m; part.m = 0.0; part.flags |= F_DEAD; part.flags &= ~F_ACTIVE;
+      }
+      else part.m -= mtemp;                                            // Sph::AccreteMassFromParticle, Sph.h:108
+      macc -= mtemp;
+      for (int k = 0; k < nd; k++) { dr[k] = part.r[k] - st.r[k]; dv[k] = part.v[k] - st.v[k]; }
+      if (nd == 3) {
+        sk.angmom[0] += mtemp*(dr[1]*dv[2] - dr[2]*dv[1]);
+        sk.angmom[1] += mtemp*(dr[2]*dv[0] - dr[0]*dv[2]);
+        sk.angmom[2] += mtemp*(dr[0]*dv[1] - dr[1]*dv[0]);
+      }
+      else if (nd == 2) sk.angmom[2] += mtemp*(dr[0]*dv[1] - dr[1]*dv[0]);
+      if (macc < small_number) break;
+    }
+    const FLOAT asqd = Dot(st.a, st.a, nd);
+    st.dt_internal = (FLOAT) 0.4*sqrt(sk.radius/(sqrt(asqd) + small_number));
+  }
+}
+
+// the sink part of MainLoop, SphSimulation.cpp:820-838 (ntreebuildstep = 1: the search runs on every step)
+static void SinkStep(Oracle &g, NbodyOracle &nb)
+{
+  if (g.P.sink_particles != 1) return;
+  if (g.P.create_sinks == 1) SearchForNewSinkParticles(g, nb, g.n, g.t);
+  if (!g.sinks.empty()) {
+    g.mmean = (FLOAT) 0.0;
+    for (int i = 0; i < g.Nhydro; i++) g.mmean += g.p[i].m;
+    g.mmean /= (FLOAT) g.Nhydro;
+    AccreteMassToSinks(g, nb, g.n, g.timestep);
+  }
+}
+
 // One SphSimulation::MainLoop call of a hybrid gas + stars run with a global timestep (SphSimulation.cpp:574-880, Npec = 1):
 // both species advance, the gas passes see the stars (zeta term, ComputeStarGravForces), the stars get the gas' tree
 // forces and their own direct sum, the timestep is the minimum over both (Simulation.cpp:1669-1754)
@@ -1907,6 +2195,7 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   for (int i = 0; i < nb.N; i++) if (nb.s[i].active) { for (int k = 0; k < 3; k++) nb.s[i].a[k] = g.stars[i].a[k]; nb.s[i].gpot = g.stars[i].gpot; }
   nb.Forces();                                                       // :794-799 (adds the star-star sums)
   nb.Correct(g.n);                                                   // :811
+  SinkStep(g, nb);                                                   // :820-838
   g.ComputeGlobalTimestep();                                         // minimum over gas and stars
   nb.GlobalTimestep();
   const double ts = std::min(g.timestep, (double) nb.timestep);
@@ -1943,6 +2232,38 @@ static void HybridSetup(Oracle &g, NbodyOracle &nb, int h_provided)
   for (int i = 0; i < nb.N; i++) nb.s[i].dt_next = ts;
   g.EndTimestep();
   nb.EndTimestep(0);
+}
+
+// sink parameters: v = {sink_particles, create_sinks, smooth_accretion, sink_radius_mode (0 fixed, 1 hmult, 2 other), Nsinkfixed,
+//                       rho_sink, sink_radius, alpha_ss, smooth_accrete_frac, smooth_accrete_dt}
+void orc_set_sink_params(Oracle *o, const double *v)
+{
+  o->P.sink_particles = (int) v[0]; o->P.create_sinks = (int) v[1]; o->P.smooth_accretion = (int) v[2];
+  o->P.sink_radius_mode = (int) v[3]; o->P.Nsinkfixed = (int) v[4];
+  o->P.rho_sink = v[5]; o->P.sink_radius = v[6]; o->P.alpha_ss = v[7]; o->P.smooth_accrete_frac = v[8]; o->P.smooth_accrete_dt = v[9];
+}
+int orc_num_particles(Oracle *o) { return o->Nhydro; }
+int orc_num_sinks(Oracle *o) { return (int) o->sinks.size(); }
+double orc_mmean(Oracle *o) { return o->mmean; }
+// per sink: {radius, mmax, menc, dmdt, ketot, gpetot, rotketot, utot, taccrete, trad, trot, tvisc, angmom[3]} (15 doubles), ints {istar, Ngas}
+void orc_get_sinks(Oracle *o, double *out, int *iout)
+{
+  for (size_t s = 0; s < o->sinks.size(); s++) {
+    const Sink &k = o->sinks[s];
+    const double v[15] = {k.radius, k.mmax, k.menc, k.dmdt, k.ketot, k.gpetot, k.rotketot, k.utot, k.taccrete, k.trad, k.trot, k.tvisc,
+                          k.angmom[0], k.angmom[1], k.angmom[2]};
+    for (int q = 0; q < 15; q++) out[15*s + q] = v[q];
+    iout[2*s] = k.istar; iout[2*s + 1] = k.Ngas;
+  }
+}
+int orc_nbody_count(NbodyOracle *o) { return o->N; }
+// scalar star fields: 0 m, 1 h, 2 dt_internal, 3 invh, 4 gpot, 5 dt, 6 tlast
+void orc_nbody_get_scalar(NbodyOracle *o, int field, double *out)
+{
+  for (int i = 0; i < o->N; i++) {
+    const Star &q = o->s[i];
+    out[i] = field == 0 ? q.m : field == 1 ? q.h : field == 2 ? q.dt_internal : field == 3 ? q.invh : field == 4 ? q.gpot : field == 5 ? q.dt : q.tlast;
+  }
 }
 void orc_hybrid_setup(Oracle *g, NbodyOracle *nb, int h_provided) { HybridSetup(*g, *nb, h_provided); }
 void orc_hybrid_step(Oracle *g, NbodyOracle *nb, int nsteps) { for (int s = 0; s < nsteps; s++) HybridMainLoop(*g, *nb); }

@@ -48,6 +48,8 @@ def lib():
         L.orc_nbody_get.argtypes = [C.c_void_p, C.c_int, _PD]
         L.orc_nbody_set.argtypes = [C.c_void_p, C.c_int, _PD]
         L.orc_hybrid_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_nbody_count.argtypes = [C.c_void_p]
+        L.orc_nbody_get_scalar.argtypes = [C.c_void_p, C.c_int, _PD]
         L.orc_hybrid_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_set_stars.argtypes = [C.c_void_p, C.c_int, _PD, _PD, _PD, C.c_int]
         L.orc_star_gas_forces.argtypes = [C.c_void_p, _PD, _PD]
@@ -99,6 +101,12 @@ class Oracle:
         q.sph_single_timestep = int(p.get("sph_single_timestep", 0))
         self.L, self.ndim, self.N = L, q.ndim, 0
         self.h = C.c_void_p(L.orc_create(C.byref(q)))
+        if int(p.get("sink_particles", 0)):
+            mode = {"fixed": 0, "hmult": 1}.get(p.get("sink_radius_mode", "hmult"), 2)
+            v = np.array([1, int(p.get("create_sinks", 0)), int(p.get("smooth_accretion", 0)), mode, int(p.get("Nsinkfixed", -1)),
+                          float(p.get("rho_sink", 1.0e-12)), float(p.get("sink_radius", 2.0)), float(p.get("alpha_ss", 0.01)),
+                          float(p.get("smooth_accrete_frac", 0.01)), float(p.get("smooth_accrete_dt", 0.01))])
+            L.orc_set_sink_params(self.h, v.ctypes.data_as(_PD))
 
     def __del__(self):
         try:
@@ -119,7 +127,26 @@ class Oracle:
         v, m, h, u = c(v), c(m), c(h), c(u)
         self.L.orc_set_particles(self.h, self.N, self._dp(r), self._dp(v), self._dp(m), self._dp(h), self._dp(u))
 
+    def num_particles(self):
+        """Nhydro now (sink runs delete accreted particles at every tree build)"""
+        self.N = int(self.L.orc_num_particles(self.h))
+        return self.N
+
+    def sinks(self):
+        """SinkParticle records: dict of arrays (radius, mmax, menc, ..., angmom[3], istar, Ngas)"""
+        n = int(self.L.orc_num_sinks(self.h))
+        d, i = np.zeros((max(n, 1), 15)), np.zeros((max(n, 1), 2), dtype=np.int32)
+        self.L.orc_get_sinks(self.h, self._dp(d), i.ctypes.data_as(C.c_void_p))
+        d, i = d[:n], i[:n]
+        names = ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc"]
+        out = {k: d[:, j].copy() for j, k in enumerate(names)}
+        out["angmom"] = d[:, 12:15].copy(); out["istar"] = i[:, 0].copy(); out["Ngas"] = i[:, 1].copy()
+        self.L.orc_mmean.restype = C.c_double
+        out["mmean"] = float(self.L.orc_mmean(self.h))
+        return out
+
     def get(self, name):
+        self.num_particles()
         out = np.empty((self.N, self.ndim) if name in VEC else (self.N,))
         rc = self.L.orc_get(self.h, name.encode(), self._dp(out))
         assert rc == 0, name
@@ -130,7 +157,8 @@ class Oracle:
         assert self.L.orc_set(self.h, name.encode(), self._dp(arr)) == 0, name
 
     def get_int(self, name):
-        """level / levelneib / nstep / nlast / flags (bit 1 active, bit 2 end_timestep)"""
+        """level / levelneib / nstep / nlast / flags (1 dead, 2 active, 4 end_timestep, 8 potmin) / sinkid / iorig"""
+        self.num_particles()
         out = np.empty(self.N, dtype=np.int32)
         assert self.L.orc_get_int(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)) == 0, name
         return out
@@ -243,6 +271,7 @@ class NbodyOracle:
     FIELDS = {"r": 0, "v": 1, "a": 2, "adot": 3, "gpot": 4, "r0": 5, "v0": 6, "a0": 7}
 
     def __init__(self, r, v, m, h, softening, nbody_mult=0.1):
+        """no stars (a sink run before its first sink): r = v = m = h = empty arrays"""
         self.L = lib()
         self.N = len(m)
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (r, v, m, h)]
@@ -282,7 +311,14 @@ class NbodyOracle:
         """n MainLoop calls of a hybrid run: `gas` is the Oracle holding the gas, self the stars"""
         self.L.orc_hybrid_step(gas.h, self.o, int(n))
 
+    SCALARS = {"m": 0, "h": 1, "dt_internal": 2, "invh": 3, "gpot": 4, "dt": 5, "tlast": 6}
+
     def get(self, name):
-        out = np.empty(self.N if name == "gpot" else (self.N, 3))
+        self.N = int(self.L.orc_nbody_count(self.o))          # sinks add stars
+        if name in self.SCALARS:
+            out = np.empty(self.N)
+            self.L.orc_nbody_get_scalar(self.o, self.SCALARS[name], out.ctypes.data_as(_PD))
+            return out
+        out = np.empty((self.N, 3))
         self.L.orc_nbody_get(self.o, self.FIELDS[name], out.ctypes.data_as(_PD))
         return out

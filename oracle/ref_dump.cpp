@@ -53,6 +53,7 @@
 #include "KDTree.h"
 #include "NeighbourSearch.h"
 #include "SphNeighbourSearch.h"
+#include "Sinks.h"
 
 using namespace std;
 
@@ -114,7 +115,24 @@ static void dump_particles(Dump &out, Simulation<ndim> *sim)
 #define SVEC(field) { vector<double> v((size_t)Ns*ndim); for (int i=0;i<Ns;i++) for (int k=0;k<ndim;k++) v[(size_t)i*ndim+k]=st[i].field[k]; out.d("star_" #field, v, ndim); }
 #define SSCAL(field) { vector<double> v(Ns); for (int i=0;i<Ns;i++) v[i]=st[i].field; out.d("star_" #field, v); }
     SVEC(r) SVEC(v) SVEC(a) SVEC(adot) SVEC(r0) SVEC(v0) SVEC(a0) SVEC(adot0)
-    SSCAL(m) SSCAL(h) SSCAL(gpot) SSCAL(dt) SSCAL(tlast)
+    SSCAL(m) SSCAL(h) SSCAL(gpot) SSCAL(dt) SSCAL(tlast) SSCAL(invh) SSCAL(radius) SSCAL(dt_internal)
+    { vector<int> v(Ns); for (int i=0;i<Ns;i++) v[i]=st[i].level; out.i("star_level", v); }
+    { vector<int> v(Ns); for (int i=0;i<Ns;i++) v[i]=st[i].nstep; out.i("star_nstep", v); }
+    { vector<int> v(Ns); for (int i=0;i<Ns;i++) v[i]=st[i].nlast; out.i("star_nlast", v); }
+  }
+  // sink particles (Sinks.h: SinkParticle): every sink is star number istar
+  PINT(sinkid)
+  { vector<double> v; v.push_back(sph->mmean); v.push_back(sph->hmin_sink); out.d("mmean_hminsink", v); }
+  if (sim->sinks && sim->sink_particles == 1) {
+    const int Nk = sim->sinks->Nsink;
+    SinkParticle<ndim> *sk = sim->sinks->sink;
+    { vector<int> v(1, Nk); out.i("Nsink", v); }
+#define KSCAL(field) { vector<double> v(Nk); for (int i=0;i<Nk;i++) v[i]=sk[i].field; out.d("sink_" #field, v); }
+    KSCAL(radius) KSCAL(mmax) KSCAL(menc) KSCAL(dmdt) KSCAL(ketot) KSCAL(gpetot) KSCAL(rotketot) KSCAL(utot)
+    KSCAL(taccrete) KSCAL(trad) KSCAL(trot) KSCAL(tvisc)
+    { vector<double> v((size_t)Nk*3); for (int i=0;i<Nk;i++) for (int k=0;k<3;k++) v[(size_t)i*3+k]=sk[i].angmom[k]; out.d("sink_angmom", v, 3); }
+    { vector<int> v(Nk); for (int i=0;i<Nk;i++) v[i]=sk[i].Ngas; out.i("sink_Ngas", v); }
+    { vector<int> v(Nk); for (int i=0;i<Nk;i++) v[i]=(int)(sk[i].star - sim->nbody->stardata); out.i("sink_istar", v); }
   }
   { vector<int> v; v.push_back(sim->n); v.push_back(sim->Nsteps); v.push_back(sim->nresync); out.i("n_Nsteps_nresync", v); }
   { vector<int> v; v.push_back(sim->level_max); v.push_back(sim->level_step); v.push_back(sim->Nlevels); v.push_back(sim->level_diff_max); out.i("levelmax_levelstep_Nlevels_diffmax", v); }

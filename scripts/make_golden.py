@@ -31,9 +31,11 @@ TREE = ["tree_Ncell_ltot_gtot_Ntot_Nleafmax", "cell_cnext", "cell_copen", "cell_
         "inext"]
 
 
-def run(args, cwd):
+def run(args, cwd, threads=None):
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "8")
+    if threads:
+        env["OMP_NUM_THREADS"] = str(threads)
     subprocess.run([REF] + args, cwd=cwd, check=True, stdout=subprocess.DEVNULL, env=env)
 
 
@@ -113,6 +115,35 @@ def levels(name, nsteps=40):
         np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
         print(name, "levels ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
+
+
+SINK_PART = ["flags", "sinkid", "m", "hrangesqd", "hfactor", "invomega", "zeta", "pressure", "sound", "tlast"]
+SINK_STAR = ["r", "v", "a", "adot", "r0", "v0", "a0", "adot0", "m", "h", "gpot", "dt", "tlast", "invh", "radius", "dt_internal", "level", "nstep", "nlast"]
+SINK_REC = ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc", "angmom", "Ngas", "istar"]
+
+
+def sinks(name, nsteps=12):
+    """sink particles (Sinks.cpp) on the Boss-Bodenheimer cloud: the IC the reference generated, its post-setup state and the
+    state after nsteps MainLoop calls (gas incl. dead / potmin flags and sinkid, the stars the sinks are, the SinkParticle records).
+    One OpenMP thread: AccreteMassToSinks assigns sinkid in a parallel loop over sinks (Sinks.cpp:427-468)."""
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["steps", par, os.path.join(tmp, "s"), str(nsteps)], tmp, threads=1)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"], "nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in STEP_OUT + SINK_PART:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        out["final_Nhydro"] = final["Nhydro"]
+        out["final_mmean_hminsink"] = final["mmean_hminsink"]
+        out["final_Nsink"] = final["Nsink"]
+        for k in SINK_STAR:
+            out["final_star_" + k] = final["star_" + k]
+        for k in SINK_REC:
+            out["final_sink_" + k] = final["sink_" + k]
+        np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
+        print(name, "sinks ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
 def treeerror(n=32768):
@@ -202,6 +233,8 @@ if __name__ == "__main__":
             levels(cfg)
         elif cfg == "treeerror":
             treeerror()
+        elif "_sinks" in cfg:
+            sinks(cfg)
         elif cfg == "nbody":
             nbody(256, 0)
             nbody(256, 1)

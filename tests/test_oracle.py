@@ -217,6 +217,62 @@ def test_restocked_tree_steps_bitwise(case):
         assert np.array_equal(o.get(k), g["final_" + k]), k
 
 
+def bb_initial_h(p, m):
+    """BossBodenheimerIc::Generate (BossBodenheimerIc.cpp:126, 56-62): h = h_fac (m / rho0)^(1/3), rho0 = 3 mcloud / (4 pi radius^3)"""
+    rho0 = 3.0*float(p["mcloud"])/(4.0*3.14159265358979*float(p["radius"])**3)
+    return np.array([float(p["h_fac"])*(x/rho0)**(1.0/3.0) for x in m])
+
+
+def run_sink_case(case, make_gas, make_stars):
+    """setup + nsteps of a sink run from the reference's own initial condition (gas r, v, m, u as the reference's
+    BossBodenheimerIc made them; no stars yet)"""
+    g = load_golden(case + "_steps")
+    p = read_params_file("%s/%s.dat" % (PARAMS, case))
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    gas = make_gas(p, s("r"), s("m"), bb_initial_h(p, s("m")), s("v"), s("u"))
+    stars = make_stars(p)
+    return g, p, gas, stars
+
+
+def test_sinks_bitwise():
+    """Boss-Bodenheimer cloud with sink creation and smooth accretion (Sinks.cpp:118-777; potmin flag with the reference's
+    stale-distance quirk and the rho_sink floor of h, GradhSph.cpp:163-169, 270-280; DeleteDeadParticles,
+    Hydrodynamics.h:158-202): setup + 12 MainLoop calls, in which two sinks form on the first step, each accretes on every
+    step and 24 dead particles are deleted - gas, stars and SinkParticle records bit for bit"""
+    from oracle.pyoracle import NbodyOracle
+
+    def make_gas(p, r, m, h, v, u):
+        o = Oracle(p, nthreads=4)
+        o.set_particles(r, m, h, v=v, u=u)
+        return o
+
+    def make_stars(p):
+        e = np.zeros(0)
+        return NbodyOracle(e.reshape(0, 3), e.reshape(0, 3), e, e, int(p["nbody_softening"]), float(p["nbody_mult"]))
+
+    g, p, o, nb = run_sink_case("bb_sinks_8k", make_gas, make_stars)
+    nb.hybrid_setup(o, h_provided=True)
+    assert o.timestep == g["setup_t_timestep"][1]
+    for k in ["h", "rho", "a", "gpot", "dt"]:
+        assert np.array_equal(o.get(k), g["setup_" + k]), k
+    assert np.array_equal(o.get_int("flags"), g["setup_flags"])
+    nb.hybrid_step(o, int(g["nsteps"][0]))
+    assert o.num_particles() == int(g["final_Nhydro"][0]) < int(g["Nhydro"][0])
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ["r", "v", "a", "h", "rho", "u", "m", "gpot", "dt", "invomega", "zeta"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
+    for k in ["flags", "sinkid", "iorig"]:
+        assert np.array_equal(o.get_int(k), g["final_" + k]), k
+    assert (g["final_flags"] & 1).sum() > 0 and (g["final_sinkid"] >= 0).sum() > 50      # the fixture has dead and in-sink particles
+    sk = o.sinks()
+    assert len(sk["radius"]) == int(g["final_Nsink"][0]) == 2
+    for k in ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc", "angmom", "Ngas", "istar"]:
+        assert np.array_equal(sk[k], g["final_sink_" + k].reshape(sk[k].shape)), k
+    assert sk["mmean"] == g["final_mmean_hminsink"][0]
+    for k in ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt_internal", "invh"]:
+        assert np.array_equal(nb.get(k), g["final_star_" + k]), "star " + k
+
+
 def initial_h_guess(r, h_fac=1.2, kernrange=2.0):
     """Sph::InitialSmoothingLengthGuess (Sph.cpp:76-119) in 3-D: one h for all particles from the bounding box; the
     reference calls powf (single precision), so call the same libm function"""
