@@ -13,7 +13,8 @@ FIELDS = {name: i for i, name in enumerate(
     ["r", "v", "a", "atree", "r0", "v0", "a0",
      "m", "h", "u", "u0", "dudt", "dudt0", "rho", "invomega", "zeta", "hfactor", "hrangesqd", "sound",
      "pressure", "div_v", "gpot", "gpot_hydro", "alpha", "dalphadt", "dt", "dt_next", "tlast",
-     "level", "levelneib", "nstep", "nlast", "flags"])}      # block timesteps: integers carried as doubles
+     "level", "levelneib", "nstep", "nlast", "flags",        # block timesteps: integers carried as doubles
+     "sinkid"])}                                             # sink runs (flags then: 1 active, 2 end_timestep, 4 dead, 8 potmin)
 VECTOR_FIELDS = {"r", "v", "a", "atree", "r0", "v0", "a0"}
 
 
@@ -38,6 +39,10 @@ class Config(C.Structure):
         ("mu_bar", C.c_double), ("rho_bary", C.c_double), ("thetamaxsqd", C.c_double),
         ("courant_mult", C.c_double), ("accel_mult", C.c_double), ("energy_mult", C.c_double),
         ("macerror", C.c_double), ("alpha_visc_min", C.c_double),
+        ("sink_particles", C.c_int32), ("create_sinks", C.c_int32), ("smooth_accretion", C.c_int32),
+        ("sink_radius_mode", C.c_int32), ("Nsinkfixed", C.c_int32), ("reserved2_", C.c_int32),
+        ("rho_sink", C.c_double), ("sink_radius", C.c_double), ("alpha_ss", C.c_double),
+        ("smooth_accrete_frac", C.c_double), ("smooth_accrete_dt", C.c_double),
     ]
 
 
@@ -103,6 +108,9 @@ SYMBOLS = {
     "gh_nbody_step": (C.c_int, [_CTX, C.c_int, _PD, _PD]),
     "gh_nbody_upload_field": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_hybrid_step": (C.c_int, [_CTX, _CTX, C.c_int, _PD, _PD]),
+    "gh_get_sinks": (C.c_int, [_CTX, _PI, _PD, _PI]),
+    "gh_nbody_num_stars": (C.c_int64, [_CTX]),
+    "gh_nbody_download_scalar": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_hybrid_setup": (C.c_int, [_CTX, _CTX, C.c_int, _PD]),
 }
 
@@ -190,6 +198,17 @@ def config_from_params(p, device=0):
     c.courant_mult = float(p.get("courant_mult", 0.15))
     c.accel_mult = float(p.get("accel_mult", 0.3))
     c.energy_mult = float(p.get("energy_mult", 0.4))
+    # sink particles (dimensionless = 1: rho_sink and sink_radius are in code units already, SphSimulation.cpp:128-136)
+    c.sink_particles = int(p.get("sink_particles", 0))
+    c.create_sinks = int(p.get("create_sinks", 0)) if c.sink_particles else 0
+    c.smooth_accretion = int(p.get("smooth_accretion", 0))
+    c.sink_radius_mode = {"fixed": 0, "hmult": 1}.get(p.get("sink_radius_mode", "hmult"), 2)
+    c.Nsinkfixed = int(p.get("Nsinkfixed", -1))
+    c.rho_sink = float(p.get("rho_sink", 1.0e-12))
+    c.sink_radius = float(p.get("sink_radius", 2.0))
+    c.alpha_ss = float(p.get("alpha_ss", 0.01))
+    c.smooth_accrete_frac = float(p.get("smooth_accrete_frac", 0.01))
+    c.smooth_accrete_dt = float(p.get("smooth_accrete_dt", 0.01))
     return c
 
 
@@ -263,6 +282,19 @@ class GandalfHip:
         shape = (n, self.ndim) if name in VECTOR_FIELDS else (n,)
         out = np.full(shape, np.nan, dtype=np.float64)      # multi-GPU: only this rank's own particles are written
         self._chk(self.lib.gh_download(self.ctx, FIELDS[name], _dp(out)))
+        return out
+
+    def sinks(self):
+        """SinkParticle records of a sink run: dict of arrays (radius, mmax, ..., angmom[3], invh, istar, Ngas) + mmean"""
+        n = C.c_int32()
+        self._chk(self.lib.gh_get_sinks(self.ctx, C.byref(n), None, None))
+        n = n.value
+        d, i = np.zeros((max(n, 1), 17)), np.zeros((max(n, 1), 2), dtype=np.int32)
+        self._chk(self.lib.gh_get_sinks(self.ctx, C.byref(C.c_int32()), _dp(d), i.ctypes.data_as(_PI)))
+        names = ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc"]
+        out = {k: d[:n, j].copy() for j, k in enumerate(names)}
+        out["angmom"] = d[:n, 12:15].copy(); out["invh"] = d[:n, 15].copy(); out["mmean"] = float(d[0, 16]) if n else 0.0
+        out["istar"] = i[:n, 0].copy(); out["Ngas"] = i[:n, 1].copy()
         return out
 
     def build_tree(self):
@@ -460,9 +492,20 @@ class NbodyHip:
         self.N = len(a[2])
         self._chk(self.lib.gh_nbody_upload(self.ctx, self.N, *[_dp(x) for x in a]))
 
+    def num_stars(self):
+        """sink runs create stars"""
+        self.N = int(self.lib.gh_nbody_num_stars(self.ctx))
+        return self.N
+
     def download(self, name):
+        self.num_stars()
+        if name in ("m", "h", "dt_internal"):
+            out = np.empty(self.N)
+            self._chk(self.lib.gh_nbody_download_scalar(self.ctx, {"m": 0, "h": 1, "dt_internal": 2}[name], _dp(out)))
+            return out
         out = np.empty(self.N if name in ("gpot", "tlast") else (self.N, self.ndim))
-        self._chk(self.lib.gh_nbody_download(self.ctx, self.FIELDS[name], _dp(out)))
+        if self.N:
+            self._chk(self.lib.gh_nbody_download(self.ctx, self.FIELDS[name], _dp(out)))
         return out
 
     def upload_field(self, name, arr):

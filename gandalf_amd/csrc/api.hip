@@ -25,7 +25,9 @@ static int field_comp(int field, int *first, int *ncomp, int ndim)
     case GH_F_A0: *first = D_A0X; *ncomp = ndim; return 0;
     default: break;
   }
-  if (field >= GH_F_M && field < GH_F_COUNT) { *first = D_M + (field - GH_F_M); *ncomp = 1; return 0; }
+  if (field >= GH_F_M && field <= GH_F_TLAST) { *first = D_M + (field - GH_F_M); *ncomp = 1; return 0; }
+  if (field >= GH_F_LEVEL && field <= GH_F_FLAGS) { *first = D_LEVEL + (field - GH_F_LEVEL); *ncomp = 1; return 0; }
+  if (field == GH_F_SINKID) { *first = D_SINKID; *ncomp = 1; return 0; }
   return -1;
 }
 
@@ -115,73 +117,8 @@ static int read_stats(gh_ctx *ctx, gh_stats *st, int phase)
 // ------------------------------------------------------------------------------------------------
 
 // ---- tabulated kernel: host-side construction of the tables (TabulatedKernel.cpp:57-100, SmoothingKernel.h:581-597)
+#include "host_kernels.hpp"
 namespace {
-struct HostM4 {            // M4Kernel functions as the reference writes them (SmoothingKernel.h:131-240)
-  int nd; double norm;
-  explicit HostM4(int nd_) : nd(nd_) { norm = nd == 1 ? GH_TWOTHIRDS : (nd == 2 ? GH_INVPI*(10.0/7.0) : GH_INVPI); }
-  double w0(double s) const { return s < 1.0 ? norm*(1.0 - 1.5*s*s + 0.75*s*s*s) : (s < 2.0 ? 0.25*norm*std::pow(2.0 - s, 3) : 0.0); }
-  double w1(double s) const { return s < 1.0 ? norm*(-3.0*s + 2.25*s*s) : (s < 2.0 ? -0.75*norm*(2.0 - s)*(2.0 - s) : 0.0); }
-  double womega(double s) const {
-    if (s < 1.0) return norm*(-nd + 1.5*(nd + 2.0)*s*s - 0.75*(nd + 3.0)*std::pow(s, 3));
-    if (s < 2.0) return norm*(-2.0*nd + 3.0*(nd + 1.0)*s - 1.50*(nd + 2.0)*s*s + 0.25*(nd + 3.0)*std::pow(s, 3));
-    return 0.0;
-  }
-  double wzeta(double s) const {
-    if (s < 1.0) return 1.4 - 2.0*s*s + 1.5*std::pow(s, 4) - 0.6*std::pow(s, 5);
-    if (s < 2.0) return 1.6 - 4.0*s*s + 4.0*std::pow(s, 3) - 1.5*std::pow(s, 4) + 0.2*std::pow(s, 5);
-    return 0.0;
-  }
-  double wgrav(double s) const {
-    if (s < 1.0) return 1.333333333333333333333*s - 1.2*std::pow(s, 3) + 0.5*std::pow(s, 4);
-    if (s < 2.0) return 2.6666666666666666667*s - 3.0*s*s + 1.2*std::pow(s, 3) - 0.166666666666666666667*std::pow(s, 4) - 0.06666666666666666667/(s*s);
-    return 1.0/(s*s);
-  }
-  double wpot(double s) const {
-    if (s < 1.0) return 1.4 - 0.666666666666666666666666*s*s + 0.3*std::pow(s, 4) - 0.1*std::pow(s, 5);
-    if (s < 2.0) return -1.0/(15.0*s) + 1.6 - 1.33333333333333333333333333*s*s + std::pow(s, 3) - 0.3*std::pow(s, 4) + (1.0/30.0)*std::pow(s, 5);
-    return 1.0/s;
-  }
-};
-struct HostQuintic {       // QuinticKernel functions as the reference writes them (SmoothingKernel.h:281-408)
-  int nd; double norm;
-  explicit HostQuintic(int nd_) : nd(nd_) { norm = nd == 1 ? (1.0/120.0) : (nd == 2 ? GH_INVPI*(7.0/478.0) : GH_INVPI*(1/120.)); }
-  double w0(double s) const {
-    if (s < 1.0) return norm*(66.0 - 60.0*s*s + 30.0*std::pow(s,4) - 10.0*std::pow(s,5));
-    if (s < 2.0) return norm*(51.0 + 75.0*s - 210.0*s*s + 150.0*std::pow(s,3) - 45.0*std::pow(s,4) + 5.0*std::pow(s,5));
-    if (s < 3.0) return norm*(243.0 - 405*s + 270.0*s*s - 90.0*std::pow(s,3) + 15.0*std::pow(s,4) - std::pow(s,5));
-    return 0.0;
-  }
-  double w1(double s) const {
-    if (s < 1.0) return norm*(-120.0*s + 120.0*std::pow(s,3) - 50.0*std::pow(s,4));
-    if (s < 2.0) return norm*(75.0 - 420.0*s + 450.0*s*s - 180.0*std::pow(s,3) + 25.0*std::pow(s,4));
-    if (s < 3.0) return norm*(-405.0 + 540.0*s - 270.0*s*s + 60.0*std::pow(s,3) - 5.0*std::pow(s,4));
-    return 0.0;
-  }
-  double womega(double s) const {
-    if (s < 1.0) return norm*(-66.0*nd + 60.0*(nd + 2.0)*s*s - 30.0*(nd + 4.0)*std::pow(s,4) + 10.0*(nd + 5.0)*std::pow(s,5));
-    if (s < 2.0) return norm*(-51.0*nd - 75.0*(nd + 1.0)*s + 210.0*(nd + 2.0)*s*s - 150.0*(nd + 3.0)*std::pow(s,3) + 45.0*(nd + 4.0)*std::pow(s,4) - 5.0*(nd + 5.0)*std::pow(s,5));
-    if (s < 3.0) return norm*(-243.0*nd + 405.0*(nd + 1.0)*s - 270.0*(nd + 2.0)*s*s + 90.0*(nd + 3.0)*std::pow(s,3) - 15.0*(nd + 4.0)*std::pow(s,4) + (nd + 5.0)*std::pow(s,5));
-    return 0.0;
-  }
-  double wzeta(double s) const {
-    if (s < 1.0) return 33.0*s*s - 15.0*std::pow(s,4) + 5.0*std::pow(s,6) - 1.42857142857*std::pow(s,7) - 34.14285714;
-    if (s < 2.0) return 25.5*s*s + 25.0*std::pow(s,3) - 52.5*std::pow(s,4) + 30.0*std::pow(s,5) - 7.5*std::pow(s,6) + 0.7142857143*std::pow(s,7) - 33.785714286;
-    if (s < 3.0) return 121.5*s*s - 135.0*std::pow(s,3) + 67.5*std::pow(s,4) - 18.0*std::pow(s,5) + 2.5*std::pow(s,6) - 0.142857143*std::pow(s,7) - 52.07142857;
-    return 0.0;
-  }
-  double wgrav(double s) const {
-    if (s < 1.0) return (12.0/359.0)*(22.0*s - 12.0*std::pow(s,3) + (30.0/7.0)*std::pow(s,5) - (5.0/4.0)*std::pow(s,6));
-    if (s < 2.0) return (12.0/359.0)*(17.0*s + (75.0/4.0)*s*s - 42.0*std::pow(s,3) + 25.0*std::pow(s,4) - (45.0/7.0)*std::pow(s,5) + (5.0/8.0)*std::pow(s,6) + (5.0/56.0)/(s*s));
-    if (s < 3.0) return (12.0/359.0)*(81.0*s - (405.0/4.0)*s*s + 54.0*std::pow(s,3) - 15.0*std::pow(s,4) + (15.0/7.0)*std::pow(s,5) - (1.0/8.0)*std::pow(s,6) - (507.0/56.0)/(s*s));
-    return 1.0/(s*s);
-  }
-  double wpot(double s) const {
-    if (s < 1.0) return (12.0/359.0)*(-11.0*s*s + 3.0*std::pow(s,4) - (5.0/7.0)*std::pow(s,6) + (5.0/28.0)*std::pow(s,7) + (478.0/14.0));
-    if (s < 2.0) return (12.0/359.0)*(-(17.0/2.0)*s*s - (25.0/4.0)*std::pow(s,3) + (21.0/2.0)*std::pow(s,4) - 5.0*std::pow(s,5) + (15.0/14.0)*std::pow(s,6) - (5.0/56.0)*std::pow(s,7) + (473.0/14.0) + (5.0/56.0)/s);
-    if (s < 3.0) return (12.0/359.0)*(-(81.0/2.0)*s*s + (135.0/4.0)*std::pow(s,3) - (27.0/2.0)*std::pow(s,4) + 3.0*std::pow(s,5) - (5.0/14.0)*std::pow(s,6) + (1.0/56.0)*std::pow(s,7) + (729.0/14.0) - (507.0/56.0)/s);
-    return 1.0/s;
-  }
-};
 template <class HK> static void fill_tables(const HK &k, double R, std::vector<double> &t)
 {
   const int res = GH_TAB_RES;
@@ -219,6 +156,9 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (cfg->kernel < GH_KERNEL_M4 || cfg->kernel > GH_KERNEL_QUINTIC_TAB)
     return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic, each with tabulated_kernel = 0 or 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
+  if (cfg->sink_particles && (cfg->Nlevels > 1 || cfg->ntreebuildstep > 1 || !cfg->self_gravity || cfg->ndim != 3))
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "sink runs: 3-D, self_gravity = 1, global timestep (Nlevels = 1), tree rebuilt every step (ntreebuildstep = 1)");
+  if (cfg->sink_particles && !(cfg->rho_sink > 0.0)) return gh_fail(ctx, GH_ERR_INVALID, "sink_particles = 1 needs rho_sink > 0");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");
@@ -254,9 +194,9 @@ static void free_particles(gh_ctx *ctx)
     if (ctx->W[k]) (void) hipFree(ctx->W[k]); ctx->W[k] = nullptr;
     if (ctx->Wpre[k]) (void) hipFree(ctx->Wpre[k]); ctx->Wpre[k] = nullptr;
   }
-  void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals, ctx->qs_ids, ctx->qs_keys};
+  void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals, ctx->qs_ids, ctx->qs_keys, ctx->pm_invhsqd, ctx->pm_cullsqd};
   for (void *p : ptrs) if (p) (void) hipFree(p);
-  ctx->qs_ids = nullptr; ctx->qs_keys = nullptr;
+  ctx->qs_ids = nullptr; ctx->qs_keys = nullptr; ctx->pm_invhsqd = nullptr; ctx->pm_cullsqd = nullptr;
   ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
   ctx->iota_N = -1;
   ctx->Ncap = 0; ctx->N = 0; ctx->tree_layout_N = -1; ctx->tree_valid = false;
@@ -267,6 +207,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   if (!ctx) return;
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
   gh_dd_free(ctx);
+  gh_sinks_free(ctx);
   free_particles(ctx);
   void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->leafact, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
@@ -304,6 +245,10 @@ int gh_alloc_particles(gh_ctx *ctx, int64_t N)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->posm, sizeof(double4)*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->hrec, sizeof(double4)*4*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->side, n));
+  if (ctx->cfg.sink_particles && ctx->cfg.create_sinks == 1) {
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->pm_invhsqd, sizeof(double)*n));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->pm_cullsqd, sizeof(double)*n));
+  }
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortkeys_out, sizeof(double)*3*n));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->sortvals, sizeof(int)*n));
   {
@@ -356,6 +301,8 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   // SphSimulation.cpp:252-257: alpha = alpha_visc, or alpha_visc_min with time-dependent viscosity
   if ((rc = put(D_ALPHA, nullptr, 1, 0, (ctx->cfg.avisc == GH_AVISC_MON97MM97 || ctx->cfg.avisc == GH_AVISC_MON97CD2010) ? ctx->cfg.alpha_visc_min : ctx->cfg.alpha_visc))) return rc;
   if ((rc = put(D_FLAGS, nullptr, 1, 0, 1.0))) return rc;              // every particle active until the first EndTimestep
+  if ((rc = put(D_SINKID, nullptr, 1, 0, -1.0))) return rc;            // Particle constructor, Particle.h:183
+  ctx->sinks.clear(); ctx->mmean = 0.0;
   std::vector<int> ids(n);
   for (size_t i = 0; i < n; i++) ids[i] = (int) i;
   GH_CHECK(ctx, hipMemcpy(ctx->iorig[0], ids.data(), sizeof(int)*n, hipMemcpyHostToDevice));
@@ -489,6 +436,7 @@ static int density_and_hmax(gh_ctx *ctx, bool count)
   if (rc) return rc;
   if ((rc = gh_density_impl(ctx, count))) return rc;
   gh_zeta_stars_impl(ctx);                              // hybrid runs: star term of zeta (GradhSph.cpp:288-307)
+  if ((rc = gh_sinks_potmin(ctx))) return rc;           // sink runs: potential-minimum flag at the end of ComputeH (GradhSph.cpp:270-280)
   if (ctx->cfg.avisc == GH_AVISC_MON97CD2010) {         // Cullen & Dehnen switch at the end of ComputeH (GradhSph.cpp:319-321)
     if ((rc = gh_cullen_dehnen_impl(ctx))) return rc;
   }
@@ -683,6 +631,8 @@ int gh_tree_build_checked(gh_ctx *ctx)
 static int step_tree_timed(gh_ctx *ctx)
 {
   const int ntb = ctx->cfg.ntreebuildstep;
+  // sink runs: accreted particles leave the arrays before the tree is rebuilt (HydroTree.cpp:334-335)
+  if (ctx->cfg.sink_particles) { const int rc = gh_sinks_delete_dead(ctx); if (rc) return rc; }
   if (ntb <= 1 || ctx->nranks > 1 || ctx->rebuild_tree || ctx->Nsteps%ntb == 0 || ctx->tree_layout_N != ctx->N) return build_tree_timed(ctx);
   gh_phase_begin(ctx, GH_T_BUILD_TREE);
   // re-stock every ntreestockstep steps, otherwise let the cells drift with their mean velocity (Tree.cpp:172-198)

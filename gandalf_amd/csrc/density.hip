@@ -24,6 +24,7 @@ struct DensityParams {
   Domain dom;
   EosParams eos;
   double h_fac, h_converge;
+  double rho_sink;    // sink runs: h >= h_fac (m / rho_sink)^(1/ndim) (GradhSph.cpp:163-169); 0 = no sinks
   const double *ktab; // kernel tables (tabulated_kernel = 1) or nullptr
   const int *only_if; // fused kernel as the fallback of the split path: per-group flags, process a group only if
   int only_val;       // only_if[group] == only_val (nullptr: all groups).  Flag values: 1 = list overflow / leaf retry,
@@ -41,7 +42,7 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 // normalise and store the converged sums of one particle (GradhSph.cpp:262-317)
 template <int ND, class K>
 __device__ __forceinline__ void density_store(const DevicePtrs &d, const DensityParams &P, int i, double mi, double ui,
-                                              double rho, double omg, double zet, double hlo)
+                                              double rho, double omg, double zet, double hlo, double invhsqd_last, double hmaxl)
 {
   const double invndim = 1.0/(double) ND;
   const double h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
@@ -50,7 +51,9 @@ __device__ __forceinline__ void density_store(const DevicePtrs &d, const Density
   const double deriv = -invndim*h/rho;                                     // h_rho_deriv, Sph.h:264
   double invomega = 1.0 - deriv*omg;
   invomega = 1.0/invomega;
-  const double zeta = deriv*zet*invomega;
+  double zeta = deriv*zet*invomega;
+  if (d.sinks && d.f[D_SINKID][i] != -1.0) { invomega = 1.0; zeta = 0.0; }   // inside a sink, GradhSph.cpp:309-312
+  if (d.pm_invhsqd) { d.pm_invhsqd[i] = invhsqd_last; d.pm_cullsqd[i] = K::kernrangesqd*hmaxl*hmaxl; }
   double sound, press;
   eos_eval(P.eos, rho, ui, sound, press);
   d.f[D_H][i] = h;
@@ -142,9 +145,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 
   // per-lane iteration state (GradhSph.cpp:148-158)
   const double h0 = d.f[D_H][i];
-  double h = h0, hlo = 0.0, hup = hmaxl;
+  // sink runs: lower bound of h; a cell whose hmax is below it leaves the particle as it is ("return -1", GradhSph.cpp:163-169)
+  const double hfloor = P.rho_sink > 0.0 ? P.h_fac*pow(mi/P.rho_sink, invndim) : 0.0;
+  double h = h0, hlo = hfloor, hup = hmaxl;
   int iter = 0;
-  bool done = !act;
+  bool done = !act || hmaxl < hfloor;
   double rho = 0.0, omg = 0.0, zet = 0.0;
   double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
   unsigned long long n_iter = 0, n_cand = 0, n_retry = 0, n_tested = 0;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     const unsigned long long fm = __ballot(failed);
     if (fm != 0ull && act && (leafmates & fm) != 0ull) {
       hmaxl = 1.05*hmaxl;
-      h = h0; hlo = 0.0; hup = hmaxl; iter = 0; done = false;
+      h = h0; hlo = hfloor; hup = hmaxl; iter = 0; done = hmaxl < hfloor;
       if (failed) n_retry++;
     }
   }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #endif
   if (P.only_if && lane == 0) P.fbout[q] = 0;
   // ---- normalise and store (GradhSph.cpp:262-317)
-  if (act) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo);
+  if (act && !(hmaxl < hfloor)) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo, invhsqd, hmaxl);
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0), c = wave_sum_u64(n_retry);
     const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
@@ -669,9 +674,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   while (leafn < d.gtot - 1) { const int c2 = 2*leafn + 2; leafn = (i >= d.cfirst[c2]) ? c2 : 2*leafn + 1; }
   const double hmaxl = 1.05*d.ch[leafn].hmax;
   const double h0 = d.f[D_H][i];
-  double h = h0, hlo = 0.0, hup = hmaxl;
+  const double hfloor = P.rho_sink > 0.0 ? P.h_fac*pow(mi/P.rho_sink, 1.0/(double) ND) : 0.0;   // sink runs, see k_density
+  double h = h0, hlo = hfloor, hup = hmaxl;
   int iter = 0;
-  bool done = !act;
+  bool done = !act || hmaxl < hfloor;
   double rho = 0.0, omg = 0.0, zet = 0.0;
   double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
   unsigned long long n_iter = 0, n_cand = 0, n_tested = 0;
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
   }
 
-  if (act) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo);
+  if (act && !(hmaxl < hfloor)) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo, invhsqd, hmaxl);
   if (COUNT) {
     const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0);
     const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
@@ -880,6 +886,7 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   fill_domain(ctx, P.dom);
   gh_fill_eos(ctx, P.eos);
   P.h_fac = ctx->cfg.h_fac; P.h_converge = ctx->cfg.h_converge; P.ktab = ctx->ktab;
+  P.rho_sink = ctx->cfg.sink_particles ? ctx->cfg.rho_sink : 0.0;
 #ifdef GH_DEBUG_BLOCKTIME
   static double *dbgbuf = nullptr;
   if (!dbgbuf) (void) hipMalloc((void**) &dbgbuf, sizeof(double)*8*(size_t) ctx->ngroups);

@@ -23,11 +23,16 @@ enum FieldD {
   D_M, D_H, D_U, D_U0, D_DUDT, D_DUDT0, D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD,
   D_SOUND, D_PRESSURE, D_DIV_V, D_GPOT, D_GPOT_HYDRO, D_ALPHA, D_DALPHADT, D_DT, D_DT_NEXT,
   D_TLAST,
+  D_SINKID,        // sink runs: Particle::sinkid as a double (-1 = none); sink runs permute every field (flags: dead, potmin)
   // block timesteps (Nlevels > 1): integers carried as doubles so that they travel with the particle through the
   // tree-order permutation; D_FLAGS bit 0 = active, bit 1 = end_timestep.  Untouched (and not permuted) for Nlevels = 1.
   D_LEVEL, D_LEVELNEIB, D_NSTEP, D_NLAST, D_FLAGS, D_COUNT
 };
-#define D_COUNT_BASE D_LEVEL      /* fields of a global-timestep run */
+#define D_COUNT_BASE D_SINKID     /* fields of a global-timestep run without sinks */
+#define GH_FLAG_ACTIVE 1
+#define GH_FLAG_END 2
+#define GH_FLAG_DEAD 4
+#define GH_FLAG_POTMIN 8
 
 // KD-tree cell records (heap order), split by consumer so that every walk touches one 64-byte line per
 // node.  Field meanings follow TreeCellBase (reference TreeCell.h:16-49).
@@ -75,8 +80,35 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
   const int *cfirst, *cN;          // static per-cell particle ranges (heap order)
   int N, ndim, ltot, gtot, lgroup, ngroups, leafocc;
   int levels;                      // Nlevels > 1: targets are the ACTIVE particles only (flags bit 0)
+  int sinks;                       // cfg.sink_particles: flags bit 2 = dead, D_SINKID valid
+  double *pm_invhsqd, *pm_cullsqd; // create_sinks: 1/h^2 of the last h iteration and the (kernrange*hmax)^2 of the successful ComputeH call
+                                   // per particle - what the potential-minimum test of GradhSph.cpp:270-280 runs on (else nullptr)
   const int *leafact;              // extrapolated tree + block timesteps: active-particle count of every leaf AS OF THE LAST STOCKING
                                    // (the reference does not refresh cell.Nactive on extrapolation steps, SphSimulation.cpp:663) or nullptr
+};
+
+// host mirror of the stars of a sink run ([n][3] vectors, [n] scalars): what Sinks.cpp reads and writes of StarParticle
+struct gh_host_stars {
+  size_t n = 0;
+  std::vector<double> r, v, a, adot, r0, v0, a0, m, h, gpot, tlast, dti;
+  void resize(size_t k) {
+    n = k;
+    std::vector<double> *v3[] = {&r, &v, &a, &adot, &r0, &v0, &a0};
+    for (auto *q : v3) q->resize(3*k, 0.0);
+    std::vector<double> *v1[] = {&m, &h, &gpot, &tlast, &dti};
+    for (auto *q : v1) q->resize(k, 0.0);
+  }
+  void append() { resize(n + 1); }
+};
+// SinkParticle (Sinks.h:48-100); the star is gh_nbody star number istar; invh = 1/h of the gas particle the sink was made from
+#ifndef GH_SINK_NREC
+#define GH_SINK_NREC 17
+#endif
+struct gh_sink_rec {
+  int istar = -1, Ngas = 0;
+  double radius = 0, mmax = 0, menc = 0, dmdt = 0, ketot = 0, gpetot = 0, rotketot = 0, utot = 0, taccrete = 0, trad = 0, trot = 0, tvisc = 0;
+  double angmom[3] = {0, 0, 0};
+  double invh = 0;
 };
 
 struct gh_ctx {
@@ -104,6 +136,10 @@ struct gh_ctx {
   CellGeo *cgeo = nullptr;
   CellCom *ccom = nullptr;
   CellQuad *cquad = nullptr;
+  double *pm_invhsqd = nullptr, *pm_cullsqd = nullptr;   // create_sinks only (DevicePtrs)
+  std::vector<gh_sink_rec> sinks;  // sink runs (sinks.hip)
+  double mmean = 0.0;              // Hydrodynamics::mmean
+  void *sink_scratch = nullptr;
   double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
   int *qs_ids = nullptr; double *qs_keys = nullptr;   // exact (quick-select order) build, tree.hip
   bool exact_armed = false;        // a build split equal coordinates: every later build runs the gated exact kernels
@@ -255,3 +291,8 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen);   // ... with t
 int gh_dd_any(gh_ctx *ctx, const unsigned int *count_dev, int *any);   // any rank's counter non-zero? (collective, synchronises)
 int gh_dd_min_dt(gh_ctx *ctx);                 // time[1] = min over ranks
 void gh_dd_free(gh_ctx *ctx);
+// sinks.hip
+int gh_sinks_potmin(gh_ctx *ctx);           // potential-minimum flag of the particles with rho >= rho_sink (after a density pass)
+int gh_sinks_delete_dead(gh_ctx *ctx);      // Hydrodynamics::DoDeleteDeadParticles before a tree build
+int gh_sinks_step(gh_ctx *ctx, gh_host_stars &S, double t, double timestep);   // search + create + accrete (SphSimulation.cpp:820-838)
+void gh_sinks_free(gh_ctx *ctx);

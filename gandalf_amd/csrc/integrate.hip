@@ -32,7 +32,7 @@ __global__ void k_kdk_advance(DevicePtrs d, Domain dom, const double *time, int 
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   int nact = 0;
-  if (i < d.N) {
+  if (i < d.N && !(d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD))) {      // dead particles stay where they are (SphLeapfrogKDK.cpp:99)
   const double t = time[0];
   const double dt = t - d.f[D_TLAST][i];
   for (int k = 0; k < d.ndim; k++) {
@@ -132,6 +132,7 @@ __global__ void k_kdk_end(DevicePtrs d, const double *time, int energy_integrati
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
+  if (d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD)) return;          // SphLeapfrogKDK.cpp:238
   if (d.levels) {                                          // only particles at the end of their step (SphLeapfrogKDK.cpp:241)
     if (!((int) d.f[D_FLAGS][i] & 2)) return;
     d.f[D_NLAST][i] = (double) blk[0];

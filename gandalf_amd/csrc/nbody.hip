@@ -27,6 +27,7 @@ struct gh_nbody {
   // SoA, component-major: r[k*N + i]
   double *r = nullptr, *v = nullptr, *a = nullptr, *adot = nullptr, *r0 = nullptr, *v0 = nullptr, *a0 = nullptr;
   double *m = nullptr, *h = nullptr, *gpot = nullptr, *tlast = nullptr;
+  double *dti = nullptr;            // dt_internal (Sinks.cpp:735: an accreting sink limits its own timestep), else big_number
   double *tdt = nullptr;            // device {t, timestep, scratch min}
   double *red = nullptr;            // block minima
   double *stage = nullptr;          // host<->device transposition buffer
@@ -35,11 +36,11 @@ struct gh_nbody {
 
 #define NB_CHECK(nb, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (nb)->err = std::string(#call) + ": " + hipGetErrorString(e__); return GH_ERR_HIP; } } while (0)
 
-struct NbPtrs { double *r, *v, *a, *adot, *r0, *v0, *a0, *m, *h, *gpot, *tlast, *tdt; int N, ndim; };
+struct NbPtrs { double *r, *v, *a, *adot, *r0, *v0, *a0, *m, *h, *gpot, *tlast, *tdt, *dti; int N, ndim; };
 
 static NbPtrs nb_ptrs(gh_nbody *nb)
 {
-  NbPtrs p = {nb->r, nb->v, nb->a, nb->adot, nb->r0, nb->v0, nb->a0, nb->m, nb->h, nb->gpot, nb->tlast, nb->tdt, (int) nb->N, nb->ndim};
+  NbPtrs p = {nb->r, nb->v, nb->a, nb->adot, nb->r0, nb->v0, nb->a0, nb->m, nb->h, nb->gpot, nb->tlast, nb->tdt, nb->dti, (int) nb->N, nb->ndim};
   return p;
 }
 
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_nbody_correct_dt(NbPtrs p, double nbody
     }
     const double amag = sqrt(amag2);
     ts = nbody_mult*sqrt(p.h[i]/(amag + NB_SMALL_DP));
-    ts = fmin(ts, NB_BIG);                                  // dt_internal = big_number without sub-systems
+    ts = fmin(ts, p.dti[i]);                                // dt_internal: big_number, or what the sink accretion set
   }
   s_min[threadIdx.x] = ts;
   __syncthreads();
@@ -193,9 +194,25 @@ __global__ void k_nbody_publish(NbPtrs p) { p.tdt[1] = p.tdt[2]; }
 
 static void nb_free(gh_nbody *nb)
 {
-  double **ptrs[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->red, &nb->stage};
+  double **ptrs[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->dti, &nb->red, &nb->stage};
   for (double **q : ptrs) { if (*q) (void) hipFree(*q); *q = nullptr; }
   nb->Ncap = 0;
+}
+
+// arrays for up to N stars (component-major: the stride is the CURRENT star count, not the capacity)
+static int nb_reserve(gh_nbody *nb, int64_t N)
+{
+  if (N <= nb->Ncap) return GH_OK;
+  const int64_t cap = N + 16;
+  nb_free(nb);
+  double **vec[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0};
+  for (double **q : vec) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*3*cap));
+  NB_CHECK(nb, hipMalloc((void**) &nb->stage, sizeof(double)*4*cap));          // 3N transposition buffer / hybrid: gas a + gpot
+  double **sca[] = {&nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->dti};
+  for (double **q : sca) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*cap));
+  NB_CHECK(nb, hipMalloc((void**) &nb->red, sizeof(double)*((cap + 255)/256 + 1)));
+  nb->Ncap = cap;
+  return GH_OK;
 }
 
 extern "C" int gh_nbody_create(int ndim, int softening, double nbody_mult, int device, gh_nbody **out)
@@ -234,17 +251,10 @@ extern "C" int gh_nbody_upload(gh_nbody *nb, int64_t N, const double *r, const d
 {
   if (!nb || N <= 0 || !r || !v || !m || !h) return GH_ERR_INVALID;
   const int nd = nb->ndim;
-  if (N > nb->Ncap) {
-    nb_free(nb);
-    double **vec[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0};
-    for (double **q : vec) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*3*N));
-    NB_CHECK(nb, hipMalloc((void**) &nb->stage, sizeof(double)*4*N));          // 3N transposition buffer / hybrid: gas a + gpot
-    double **sca[] = {&nb->m, &nb->h, &nb->gpot, &nb->tlast};
-    for (double **q : sca) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*N));
-    NB_CHECK(nb, hipMalloc((void**) &nb->red, sizeof(double)*((N + 255)/256 + 1)));
-    nb->Ncap = N;
-  }
+  int rca = nb_reserve(nb, N);
+  if (rca) return rca;
   nb->N = N;
+  { std::vector<double> big((size_t) N, NB_BIG); NB_CHECK(nb, hipMemcpy(nb->dti, big.data(), sizeof(double)*N, hipMemcpyHostToDevice)); }
   std::string tmp;
   std::vector<double> t((size_t) 3*N, 0.0);
   auto up = [&](double *dst, const double *src) -> hipError_t {
@@ -383,8 +393,18 @@ __global__ void k_nbody_add_gas(NbPtrs p, const double *ga, const double *gg)
   p.gpot[i] += gg[i];
 }
 
+static int sink_hybrid_step(gh_ctx *gas, gh_nbody *nb);
+static int sink_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided);
+
 extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_out, double *timestep_out)
 {
+  if (gas && nb && gas->cfg.sink_particles) {                // sink runs: the star list may be empty and grows
+    if (gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
+    for (int s = 0; s < nsteps; s++) { const int rc = sink_hybrid_step(gas, nb); if (rc) return rc; }
+    if (t_out) *t_out = gas->t;
+    if (timestep_out) *timestep_out = gas->timestep;
+    return GH_OK;
+  }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
   if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
@@ -442,6 +462,13 @@ int gh_setup_passes(gh_ctx *ctx, int initial_h_provided);    // api.hip
 // (gas tree part + direct sum, :500-514), first timestep = minimum over both species (:538), EndTimestep of both (:551-553)
 extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided, double *timestep_out)
 {
+  if (gas && nb && gas->cfg.sink_particles) {
+    if (gas->N <= 0) return GH_ERR_INVALID;
+    const int rc = sink_hybrid_setup(gas, nb, initial_h_provided);
+    if (rc) return rc;
+    if (timestep_out) *timestep_out = gas->timestep;
+    return GH_OK;
+  }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0) return GH_ERR_INVALID;
   if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
@@ -481,5 +508,171 @@ extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided
   td[0] = gas->t; td[1] = gas->timestep;
   NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
   if (timestep_out) *timestep_out = gas->timestep;
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sink runs: the stars are the sinks; their number grows, and the sink routines work on a host mirror
+// ------------------------------------------------------------------------------------------------
+static int nb_pull(gh_nbody *nb, gh_host_stars &S)
+{
+  const size_t N = (size_t) nb->N;
+  S.resize(N);
+  if (N == 0) return GH_OK;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  std::vector<double> t(3*N);
+  struct { const double *src; std::vector<double> *dst; } v3[] = {{nb->r, &S.r}, {nb->v, &S.v}, {nb->a, &S.a}, {nb->adot, &S.adot}, {nb->r0, &S.r0}, {nb->v0, &S.v0}, {nb->a0, &S.a0}};
+  for (auto &q : v3) {
+    NB_CHECK(nb, hipMemcpy(t.data(), q.src, sizeof(double)*3*N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) (*q.dst)[3*i + k] = t[(size_t) k*N + i];
+  }
+  struct { const double *src; std::vector<double> *dst; } v1[] = {{nb->m, &S.m}, {nb->h, &S.h}, {nb->gpot, &S.gpot}, {nb->tlast, &S.tlast}, {nb->dti, &S.dti}};
+  for (auto &q : v1) NB_CHECK(nb, hipMemcpy(q.dst->data(), q.src, sizeof(double)*N, hipMemcpyDeviceToHost));
+  return GH_OK;
+}
+
+static int nb_push(gh_nbody *nb, const gh_host_stars &S)
+{
+  const size_t N = S.n;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  int rc = nb_reserve(nb, (int64_t) N);
+  if (rc) return rc;
+  nb->N = (int64_t) N;
+  if (N == 0) return GH_OK;
+  std::vector<double> t(3*N);
+  struct { double *dst; const std::vector<double> *src; } v3[] = {{nb->r, &S.r}, {nb->v, &S.v}, {nb->a, &S.a}, {nb->adot, &S.adot}, {nb->r0, &S.r0}, {nb->v0, &S.v0}, {nb->a0, &S.a0}};
+  for (auto &q : v3) {
+    for (size_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) t[(size_t) k*N + i] = (*q.src)[3*i + k];
+    NB_CHECK(nb, hipMemcpy(q.dst, t.data(), sizeof(double)*3*N, hipMemcpyHostToDevice));
+  }
+  struct { double *dst; const std::vector<double> *src; } v1[] = {{nb->m, &S.m}, {nb->h, &S.h}, {nb->gpot, &S.gpot}, {nb->tlast, &S.tlast}, {nb->dti, &S.dti}};
+  for (auto &q : v1) NB_CHECK(nb, hipMemcpy(q.dst, q.src->data(), sizeof(double)*N, hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
+// star positions, masses and softening lengths as the gas passes see them
+static int sink_stars_to_gas(gh_ctx *gas, gh_nbody *nb)
+{
+  const int64_t Ns = nb->N;
+  if (Ns == 0) return gh_set_stars(gas, 0, nullptr, nullptr, nullptr, nb->softening);
+  const int nd = nb->ndim;
+  std::vector<double> sr((size_t) Ns*nd), sm((size_t) Ns), shh((size_t) Ns);
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  NB_CHECK(nb, hipMemcpy(sm.data(), nb->m, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  NB_CHECK(nb, hipMemcpy(shh.data(), nb->h, sizeof(double)*Ns, hipMemcpyDeviceToHost));
+  int rc = gh_nbody_download(nb, GH_NB_R, sr.data());
+  if (rc) return rc;
+  return gh_set_stars(gas, Ns, sr.data(), sm.data(), shh.data(), nb->softening);
+}
+
+// forces on the stars: gas tree part + star-star direct sum (SphSimulation.cpp:771-800)
+static int sink_star_forces(gh_ctx *gas, gh_nbody *nb)
+{
+  const int64_t Ns = nb->N;
+  if (Ns == 0) return GH_OK;
+  const int nd = nb->ndim;
+  std::vector<double> ga((size_t) Ns*nd), gg((size_t) Ns);
+  int rc;
+  if ((rc = gh_star_gas_forces(gas, ga.data(), gg.data()))) return rc;
+  if ((rc = nb_launch_forces(nb))) return rc;
+  NB_CHECK(nb, hipMemcpyAsync(nb->stage, ga.data(), sizeof(double)*Ns*nd, hipMemcpyHostToDevice, nb->stream));
+  NB_CHECK(nb, hipMemcpyAsync(nb->stage + (size_t) Ns*nd, gg.data(), sizeof(double)*Ns, hipMemcpyHostToDevice, nb->stream));
+  hipLaunchKernelGGL(k_nbody_add_gas, dim3((unsigned) ((Ns + 255)/256)), dim3(256), 0, nb->stream, nb_ptrs(nb), nb->stage, nb->stage + (size_t) Ns*nd);
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));         // ga / gg are on this function's stack
+  return GH_OK;
+}
+
+// the stars' timestep minimum and EndTimestep; returns the minimum (big when there are no stars)
+static int sink_star_end(gh_nbody *nb, double *star_min)
+{
+  *star_min = 9.9e50;
+  const int64_t Ns = nb->N;
+  if (Ns == 0) return GH_OK;
+  NbPtrs p = nb_ptrs(nb);
+  const int nblk = (int) ((Ns + 255)/256);
+  hipLaunchKernelGGL(k_nbody_correct_dt, dim3(nblk), dim3(256), 0, nb->stream, p, nb->nbody_mult, nb->red, 0);
+  hipLaunchKernelGGL(k_nbody_end, dim3(std::min(nblk, 256)), dim3(256), 0, nb->stream, p, nb->red, nblk);
+  NB_CHECK(nb, hipMemcpyAsync(star_min, nb->tdt + 2, sizeof(double), hipMemcpyDeviceToHost, nb->stream));
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  return GH_OK;
+}
+
+static int sink_finish_step(gh_ctx *gas, gh_nbody *nb, double star_min, const char *where)
+{
+  int rc;
+  GH_CHECK(gas, hipMemcpyAsync(gas->redbuf + 256, &star_min, sizeof(double), hipMemcpyHostToDevice, gas->stream));
+  gh_timestep_impl_extra(gas, 1);                            // ComputeGlobalTimestep over gas (dead particles included) and stars
+  gh_kdk_end_impl(gas, 0, 0.0, 0.0);
+  gas->n = 0;
+  if ((rc = gh_sync_collect(gas, where))) return rc;
+  double tt[2];
+  GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+  gas->t = tt[0]; gas->timestep = tt[1];
+  NB_CHECK(nb, hipMemcpy(nb->tdt, tt, sizeof(tt), hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
+// one MainLoop call of a sink run (SphSimulation.cpp:574-880, global timestep)
+static int sink_hybrid_step(gh_ctx *gas, gh_nbody *nb)
+{
+  int rc;
+  double td[2] = {gas->t, gas->timestep};
+  NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  gas->n++; gas->Nsteps++;
+  gh_advance_time_impl(gas);
+  gh_kdk_advance_impl(gas, gas->n, 0.0, 0.0);
+  if (nb->N > 0) hipLaunchKernelGGL(k_nbody_advance, dim3((unsigned) ((nb->N + 255)/256)), dim3(256), 0, nb->stream, nb_ptrs(nb), 0);
+  hipLaunchKernelGGL(k_nbody_clock, dim3(1), dim3(1), 0, nb->stream, nb_ptrs(nb));
+  if ((rc = sink_stars_to_gas(gas, nb))) return rc;
+  if ((rc = gh_hybrid_gas_passes(gas))) return rc;          // dead particles out, tree, density (+ zeta, potmin), forces (+ gas <- stars)
+  if ((rc = sink_star_forces(gas, nb))) return rc;
+  if (nb->N > 0)                                             // CorrectionTerms (its timestep output is redone below)
+    hipLaunchKernelGGL(k_nbody_correct_dt, dim3((unsigned) ((nb->N + 255)/256)), dim3(256), 0, nb->stream, nb_ptrs(nb), nb->nbody_mult, nb->red, 1);
+  if ((rc = gh_sync_collect(gas, "gh_hybrid_step/sinks"))) return rc;
+  double tt[2];
+  GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+  // search for new sinks, accrete (SphSimulation.cpp:820-838)
+  gh_host_stars S;
+  if ((rc = nb_pull(nb, S))) return rc;
+  if ((rc = gh_sinks_step(gas, S, tt[0], tt[1]))) return rc;
+  if ((rc = nb_push(nb, S))) return rc;
+  double star_min;
+  if ((rc = sink_star_end(nb, &star_min))) return rc;
+  return sink_finish_step(gas, nb, star_min, "gh_hybrid_step/sinks");
+}
+
+static int sink_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided)
+{
+  int rc;
+  // SphSimulation.cpp:229-237: stars present at the start are sinks of radius kernrange*h
+  gas->sinks.clear();
+  if (nb->N > 0) {
+    gh_host_stars S;
+    if ((rc = nb_pull(nb, S))) return rc;
+    const double kr = (gas->cfg.kernel == GH_KERNEL_QUINTIC || gas->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
+    for (size_t i = 0; i < S.n; i++) { gh_sink_rec k; k.istar = (int) i; k.radius = kr*S.h[i]; k.invh = 1.0/S.h[i]; gas->sinks.push_back(k); }
+  }
+  if ((rc = sink_stars_to_gas(gas, nb))) return rc;
+  if ((rc = gh_setup_passes(gas, initial_h_provided))) return rc;
+  double td[2] = {gas->t, 0.0};
+  NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  if ((rc = sink_star_forces(gas, nb))) return rc;
+  double star_min;
+  if ((rc = sink_star_end(nb, &star_min))) return rc;
+  gas->timestep = 0.0; gas->n = 0;
+  double tt0[2] = {gas->t, 0.0};
+  GH_CHECK(gas, hipMemcpyAsync(gh_time_dev(gas), tt0, sizeof(tt0), hipMemcpyHostToDevice, gas->stream));
+  return sink_finish_step(gas, nb, star_min, "gh_hybrid_setup/sinks");
+}
+
+extern "C" int64_t gh_nbody_num_stars(const gh_nbody *nb) { return nb ? nb->N : 0; }
+
+// scalar star fields of sink runs: 0 m, 1 h, 2 dt_internal
+extern "C" int gh_nbody_download_scalar(gh_nbody *nb, int which, double *out)
+{
+  if (!nb || !out || which < 0 || which > 2) return GH_ERR_INVALID;
+  if (nb->N == 0) return GH_OK;
+  NB_CHECK(nb, hipStreamSynchronize(nb->stream));
+  NB_CHECK(nb, hipMemcpy(out, which == 0 ? nb->m : which == 1 ? nb->h : nb->dti, sizeof(double)*nb->N, hipMemcpyDeviceToHost));
   return GH_OK;
 }

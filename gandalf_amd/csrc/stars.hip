@@ -51,7 +51,7 @@ __global__ void k_zeta_stars(DevicePtrs d, StarTab S, const double *ktab)
       sum += p.w*ih2*K::t_wzetas2(dr2*ih2, ktab);
     }
   }
-  if (act) {
+  if (act && !(d.sinks && d.f[D_SINKID][i] != -1.0)) {                         // (zeta = 0 inside a sink, GradhSph.cpp:309-312)
     const double deriv = -(1.0/(double) ND)*h/d.f[D_RHO][i];                  // h_rho_deriv, Sph.h:264
     d.f[D_ZETA][i] += deriv*sum*d.f[D_INVOMEGA][i];
   }

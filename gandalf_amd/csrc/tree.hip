@@ -779,6 +779,8 @@ DevicePtrs gh_dev(gh_ctx *ctx)
   d.lgroup = ctx->lgroup; d.ngroups = ctx->ngroups; d.leafocc = ctx->leafocc;
   d.levels = ctx->cfg.Nlevels > 1 ? 1 : 0;
   d.leafact = (d.levels && ctx->tree_stale) ? ctx->leafact : nullptr;
+  d.sinks = ctx->cfg.sink_particles ? 1 : 0;
+  d.pm_invhsqd = ctx->pm_invhsqd; d.pm_cullsqd = ctx->pm_cullsqd;
   return d;
 }
 
@@ -790,6 +792,7 @@ DevicePtrs gh_dev_own(gh_ctx *ctx)
   const size_t o = (size_t) ctx->own_first;
   for (int f = 0; f < D_COUNT; f++) d.f[f] += o;
   d.iorig += o; d.posm += o; d.hrec += 4*o;
+  if (d.pm_invhsqd) { d.pm_invhsqd += o; d.pm_cullsqd += o; }
   d.N = (int) ctx->own_count;
   return d;
 }
@@ -1001,9 +1004,12 @@ int gh_tree_build_impl(gh_ctx *ctx)
   // gather every particle array into tree order (perm[new] = old position).  The two pointer tables
   // (buffer 0 -> 1 and 1 -> 0) live in device memory since allocation: no host synchronisation here.
   // equal coordinates at a median: the reference's own quick-select order decides (exact mode, armed once a tie was seen)
-  if (ctx->exact_armed && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], ctx->d_blk + 13))) return rc; }
+  // (sink runs: always - the potential-minimum flag and the accretion order depend on the reference's order of the
+  // particles inside a leaf cell, which only its own quick-select produces)
+  if (ctx->cfg.sink_particles && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], nullptr))) return rc; }
+  else if (ctx->exact_armed && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], ctx->d_blk + 13))) return rc; }
   const int *perm = ctx->P[pb][0];
-  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn);
+  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), (ctx->cfg.Nlevels > 1 || ctx->cfg.sink_particles) ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn);
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, p0, pn);
   ctx->cur ^= 1;
   ctx->tree_valid = true;

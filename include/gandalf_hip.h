@@ -92,6 +92,19 @@ typedef struct gh_config {
   double  energy_mult;     /* energy_mult */
   double  macerror;        /* macerror (gravity_mac = gadget2 / eigenmac) */
   double  alpha_visc_min;  /* alpha_visc_min (time_dependent_avisc = mm97) */
+  /* sink particles (SphSimulation.cpp:116-136; all zero = no sinks).  Sink runs go through gh_hybrid_setup / gh_hybrid_step
+   * with a gh_nbody context that holds the sinks' stars (it may start empty); global timestep, tree rebuilt every step. */
+  int32_t sink_particles;  /* sink_particles */
+  int32_t create_sinks;    /* create_sinks */
+  int32_t smooth_accretion;/* smooth_accretion */
+  int32_t sink_radius_mode;/* sink_radius_mode: 0 fixed, 1 hmult, 2 anything else (radius = kernrange*h) */
+  int32_t Nsinkfixed;      /* Nsinkfixed (-1: no limit) */
+  int32_t reserved2_;
+  double  rho_sink;        /* rho_sink, in code units (SphSimulation.cpp:128-129) */
+  double  sink_radius;     /* sink_radius (code units for mode fixed, multiples of h for hmult) */
+  double  alpha_ss;        /* alpha_ss */
+  double  smooth_accrete_frac; /* smooth_accrete_frac */
+  double  smooth_accrete_dt;   /* smooth_accrete_dt */
 } gh_config;
 
 /* field ids for gh_download / gh_upload_field (values are per particle; vectors are [N][ndim]) */
@@ -103,6 +116,10 @@ enum {
   /* block timesteps (Particle.h:137-142), integers carried as doubles: level, levelneib, nstep, nlast and the flag
    * word (bit 0 active, bit 1 end_timestep) */
   GH_F_LEVEL, GH_F_LEVELNEIB, GH_F_NSTEP, GH_F_NLAST, GH_F_FLAGS,
+  /* sink runs: Particle::sinkid (-1 = not inside a sink); GH_F_FLAGS then also carries bit 2 = dead (accreted; gone after the
+   * next tree build, Hydrodynamics.h:158-202) and bit 3 = potmin (GradhSph.cpp:270-280; maintained only where rho >= rho_sink,
+   * which is where Sinks::SearchForNewSinkParticles reads it) */
+  GH_F_SINKID,
   GH_F_COUNT
 };
 
@@ -313,6 +330,18 @@ int gh_nbody_upload_field(gh_nbody *nb, int field, const double *src);
  * get the gas' tree forces (gh_star_gas_forces) on top of their direct sum, the timestep is the minimum over both
  * (Simulation::ComputeGlobalTimestep, Simulation.cpp:1669-1754).  gas must hold the post-setup state (gh_set_time). */
 int gh_hybrid_step(gh_ctx *gas, gh_nbody *stars, int nsteps, double *t, double *timestep);
+/* sink runs (cfg.sink_particles = 1): gh_hybrid_setup / gh_hybrid_step do the whole of MainLoop including
+ * Sinks::SearchForNewSinkParticles / CreateNewSinkParticle / AccreteMassToSinks (Sinks.cpp:118-777) and the removal of accreted
+ * particles before every tree build (Hydrodynamics::DoDeleteDeadParticles, Hydrodynamics.h:158-202): gh_num_particles and
+ * gh_nbody_num_stars change between calls, and gh_download returns the arrays in the reference's compacted particle order.
+ * gh_get_sinks: the SinkParticle records (Sinks.h:48-100).  rec [n][GH_SINK_NREC] = radius, mmax, menc, dmdt, ketot, gpetot,
+ * rotketot, utot, taccrete, trad, trot, tvisc, angmom[3], 1/h of the parent gas particle, Hydrodynamics::mmean;
+ * irec [n][2] = star number, Ngas.  Either array may be NULL. */
+#define GH_SINK_NREC 17
+int gh_get_sinks(gh_ctx *ctx, int *nsinks, double *rec, int *irec);
+int64_t gh_nbody_num_stars(const gh_nbody *nb);
+/* which: 0 m, 1 h, 2 dt_internal (NbodyParticle.h) */
+int gh_nbody_download_scalar(gh_nbody *nb, int which, double *out);
 /* ... and its PostInitialConditionsSetup (SphSimulation.cpp:204-565): gas after gh_upload_particles, stars after
  * gh_nbody_upload; leaves both contexts in the post-setup state and returns the first timestep */
 int gh_hybrid_setup(gh_ctx *gas, gh_nbody *stars, int initial_h_provided, double *timestep);

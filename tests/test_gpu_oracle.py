@@ -239,3 +239,40 @@ def test_restocked_tree_runs_match_reference(case):
     assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-9
     a, ar = dev.download("a"), g["final_a"]
     assert np.max(np.linalg.norm(a - ar, axis=1)/np.maximum(np.linalg.norm(ar, axis=1), np.linalg.norm(ar, axis=1).mean())) < 1e-8
+
+
+def test_potmin_flags_vs_oracle():
+    """the potential-minimum flag (GradhSph.cpp:270-280, with its stale-distance quirk) for EVERY particle the sink search could
+    read it from: the Boss-Bodenheimer cloud with rho_sink lowered so that thousands of particles qualify and Nsinkfixed = 0 so that no
+    sink forms; after two steps (real potentials) the flags of all particles with rho >= rho_sink equal the CPU restatement's,
+    and they are a non-trivial pattern (neither all set nor all clear)"""
+    import gandalf_amd
+    from gandalf_amd.capi import NbodyHip
+    from oracle.pyoracle import Oracle, NbodyOracle
+    from conftest import load_golden
+    from test_oracle import bb_initial_h
+    g = load_golden("bb_sinks_8k_steps")
+    p = read_params_file("%s/bb_sinks_8k.dat" % PARAMS)
+    p["rho_sink"] = "0.28"; p["Nsinkfixed"] = "0"      # (h floor 0.092 < the initial h 0.0965: below that every ComputeH call returns -1)
+    r, v, m, u = g["setup_r"], g["setup_v"], g["setup_m"], g["setup_u"]
+    h0 = bb_initial_h(p, m)
+    sim = gandalf_amd.GandalfHip(p)
+    sim.upload(r, m, h0, v=v, u=u)
+    nb = NbodyHip(ndim=3, softening=1, nbody_mult=float(p["nbody_mult"]))
+    nb.hybrid_setup(sim, initial_h_provided=True)
+    nb.hybrid_step(sim, 2)
+    o = Oracle(p, nthreads=8)
+    o.set_particles(r, m, h0, v=v, u=u)
+    e = np.zeros(0)
+    no = NbodyOracle(e.reshape(0, 3), e.reshape(0, 3), e, e, 1, float(p["nbody_mult"]))
+    no.hybrid_setup(o, h_provided=True)
+    no.hybrid_step(o, 2)
+    assert sim.N == o.num_particles() == len(m) and nb.num_stars() == 0
+    rho = o.get("rho")
+    assert np.max(np.abs(sim.download("rho") - rho)/rho) < 1e-11
+    assert np.max(np.abs(sim.download("h") - o.get("h"))/o.get("h")) < 1e-11
+    dense = rho >= 0.28*(1.0 + 1e-9)
+    pm_gpu = (sim.download("flags").astype(np.int64)[dense] & 8) != 0
+    pm_ref = (o.get_int("flags")[dense] & 8) != 0
+    assert dense.sum() > 1500 and 0 < pm_ref.sum() < dense.sum()
+    assert np.array_equal(pm_gpu, pm_ref), (int((pm_gpu != pm_ref).sum()), int(pm_ref.sum()))

@@ -308,6 +308,54 @@ def test_hybrid_run_from_ic_matches_reference():
     assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9
 
 
+def test_sinks_match_reference():
+    """Boss-Bodenheimer cloud with sink creation + smooth accretion (Sinks.cpp:118-777, the potmin flag and
+    rho_sink floor of GradhSph::ComputeH, DeleteDeadParticles): gh_hybrid_setup + 12 gh_hybrid_step calls from the
+    reference's own initial condition, no stars at the start.  Discrete results - which particles become sinks and when, the
+    sinkid of every particle, which particles die, the compacted particle order, Ngas - are exact; sums to the step
+    tolerances.  (potmin is maintained where rho >= rho_sink only, which is where the sink search reads it.)"""
+    from gandalf_amd.capi import NbodyHip
+    from test_oracle import bb_initial_h
+    case = "bb_sinks_8k"
+    g = load_golden(case + "_steps")
+    sim, p = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    sim.upload(s("r"), s("m"), bb_initial_h(p, s("m")), v=s("v"), u=s("u"))
+    nb = NbodyHip(ndim=3, softening=int(p["nbody_softening"]), nbody_mult=float(p["nbody_mult"]))
+    dt = nb.hybrid_setup(sim, initial_h_provided=True)
+    assert abs(dt - g["setup_t_timestep"][1]) <= 1e-10*dt
+    assert relerr(sim.download("h"), s("h")) < 1e-11 and relerr(sim.download("rho"), s("rho")) < 1e-11
+    assert vec_err(sim.download("a"), s("a")) < 1e-10
+    t, dt = nb.hybrid_step(sim, int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert sim.N == int(g["final_Nhydro"][0]) and nb.num_stars() == int(g["final_Nsink"][0]) == 2
+    assert abs(t - tf) <= 1e-11*abs(tf) and abs(dt - dtf) <= 1e-8*abs(dtf)
+    # discrete state: exact
+    fl = sim.download("flags").astype(np.int64)
+    assert np.array_equal((fl & 4) != 0, (g["final_flags"] & 1) != 0)                       # dead
+    assert np.array_equal(sim.download("sinkid").astype(np.int64), g["final_sinkid"])
+    dense = (g["final_rho"] >= float(p["rho_sink"])) & ((g["final_flags"] & 1) == 0)
+    assert dense.sum() > 100 and np.array_equal((fl[dense] & 8) != 0, (g["final_flags"][dense] & 8) != 0)     # potmin
+    assert np.array_equal(sim.download("m") == 0.0, g["final_m"] == 0.0)
+    # gas: the particle order is the reference's compacted order, so arrays compare element for element
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    assert relerr(sim.download("m"), g["final_m"], floor=g["final_m"].max()) < 1e-10
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-9 and relerr(sim.download("h"), g["final_h"]) < 1e-9
+    assert vec_err(sim.download("a"), g["final_a"]) < 1e-8
+    # sinks and their stars
+    sk = sim.sinks()
+    assert np.array_equal(sk["istar"], g["final_sink_istar"]) and np.array_equal(sk["Ngas"], g["final_sink_Ngas"])
+    for k in ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc"]:
+        assert relerr(sk[k], g["final_sink_" + k]) < 1e-8, k
+    assert np.max(np.abs(sk["angmom"] - g["final_sink_angmom"])) < 1e-8*np.abs(g["final_sink_angmom"]).max()
+    assert abs(sk["mmean"] - g["final_mmean_hminsink"][0]) <= 1e-14*sk["mmean"]
+    assert relerr(nb.download("m"), g["final_star_m"]) < 1e-10 and relerr(nb.download("h"), g["final_star_h"]) < 1e-12
+    assert np.max(np.abs(nb.download("r") - g["final_star_r"])) < 1e-10*np.abs(g["final_star_r"]).max()
+    assert np.max(np.abs(nb.download("v") - g["final_star_v"])) < 1e-9*np.abs(g["final_star_v"]).max()
+    assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-8
+    assert relerr(nb.download("dt_internal"), g["final_star_dt_internal"]) < 1e-8
+
+
 def test_point_gather_query_matches_brute_force():
     """gh_gather_neighbours_at (NeighbourSearch::GetGatherNeighbourList(rp, rsearch, ...), Tree.cpp:208-280): the set
     of particles within rsearch of arbitrary points, against a brute-force distance test; overflow answer -1"""

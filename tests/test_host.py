@@ -21,7 +21,7 @@ def test_capi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libgandalf_hip.so does not export " + name
         assert name in capi.SYMBOLS, "ctypes binding misses " + name
-    assert ctypes.sizeof(capi.Config) == 12*4 + 6*4 + 6*4 + 6*8 + 14*8
+    assert ctypes.sizeof(capi.Config) == 12*4 + 6*4 + 6*4 + 6*8 + 14*8 + 6*4 + 5*8      # ... + the sink block
 
 
 def test_no_cpu_fallback_without_gpu():
