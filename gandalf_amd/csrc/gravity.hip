@@ -49,6 +49,8 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
   __shared__ unsigned short s_smask[GH_SCAP];
+  __shared__ int s_qnode[128];                     // nodes waiting for the per-leaf tests, with their leaf masks
+  __shared__ unsigned short s_qmask[128];
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF], s_lamin[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
@@ -109,39 +111,86 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
   for (int l = 0; l < GH_MAXLEAF; l++) { len_c[l] = 0; len_d[l] = 0; len_h[l] = 0; }
   if (lane == 0) { s_stack[0] = 0; s_smask[0] = (unsigned short) allmask; }
   __syncthreads();
-  int top = 1, len_g = 0;
+  int top = 1, len_g = 0, qn = 0;
   bool overflow = false;
-  while (top > 0) {
-    const int p = pop_width(top);
-    const int newtop = top - p;
+  // Two phases per round.  A: pop up to 64 nodes and classify each against the WHOLE group - every leaf accepts it
+  // (-> the group's shared list), every leaf opens it (-> children pushed), or undecided (-> queued).  B: once 64
+  // undecided nodes are queued (or the stack is empty) one full wave takes them through the per-leaf tests.  Most
+  // nodes are decided in A (1 test instead of 16), and the per-leaf loop - the cost of this kernel - only ever runs
+  // with all lanes busy.
+  while (top > 0 || qn > 0) {
+    if (top > 0 && qn <= 64) {
+      const int p = pop_width(top);
+      const int newtop = top - p;
 #ifdef GH_DEBUG_BLOCKTIME
-    dbg_steps++;
+      dbg_steps++;
 #endif
-    unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
-    int n = 0; bool isleaf = false;
-    CellGeo g;
-    g.first = 0; g.N = 0;
-    if (lane < p) {
-      n = s_stack[top - 1 - lane];
-      const unsigned int fm = s_smask[top - 1 - lane];
-      g = d.cgeo[n];
-      if (g.N < 0) { atomicOr(flags, FLAG_LET_MISS); g.N = 0; }     // multi-GPU: a remote cell the halo exchange did not import
-      isleaf = n >= leaf0;
-      const double khr = K::kernrange*g.hmax;
-      // quick classification against the whole group (see k_grav_forces): lower bound D - Rg on every
-      // leaf's distance; if it clears the overlap and opening distances, every leaf says "cell"
-      double D2 = 0.0;
-      for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; D2 += dx*dx; }
-      const double Dm = (sqrt(D2) - Rg)*(1.0 - 1e-12);
-      const double Tn = g.rmax + fmax(Lm, Lr + khr);
-      // gadget2: open if drsqd^2*amin*macerror < rmax^2*m; rm2 is that right-hand side (0 disables the test)
-      const double rm2 = gadget ? g.rmax*g.rmax*d.ccom[n].m : 0.0;
-      // eigenmac: open if drsqd < cell.mac*macfactor(leaf); the group bound uses the largest factor
-      if (g.N > 0 && Dm > Tn && Dm*Dm > g.cdistsqd && !(gadget && (Dm*Dm)*(Dm*Dm)*Amin*P.macerror*(1.0 - 1e-12) < rm2) &&
-          !(eigen && !((Dm*Dm)*(1.0 - 1e-12) >= g.mac*Amax))) {
-        if (isleaf && g.N == 1) dirm = fm; else cellm = fm;
+      int n = 0; unsigned int fm = 0;
+      bool acc = false, opn = false, slow = false;
+      if (lane < p) {
+        n = s_stack[top - 1 - lane];
+        fm = s_smask[top - 1 - lane];
+        const CellGeo g = d.cgeo[n];
+        if (g.N < 0) atomicOr(flags, FLAG_LET_MISS);            // multi-GPU: a remote cell the halo exchange did not import
+        const bool isleaf = n >= leaf0;
+        const double khr = K::kernrange*g.hmax;
+        // lower / upper bound D -/+ Rg on every leaf's distance to the node
+        double D2 = 0.0;
+        for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - gg.rcell[k]; D2 += dx*dx; }
+        const double Ds = sqrt(D2);
+        const double Dm = (Ds - Rg)*(1.0 - 1e-12), Dp = (Ds + Rg)*(1.0 + 1e-12);
+        const double Tn = g.rmax + fmax(Lm, Lr + khr);
+        // gadget2: open if drsqd^2*amin*macerror < rmax^2*m; rm2 is that right-hand side (0 disables the test)
+        const double rm2 = gadget ? g.rmax*g.rmax*d.ccom[n].m : 0.0;
+        // eigenmac: open if drsqd < cell.mac*macfactor(leaf); the group bound uses the largest factor
+        if (g.N <= 0) { }                                       // empty cell (or a remote one that was not imported): nothing below it
+        else if (Dm > Tn && Dm*Dm > g.cdistsqd && !(gadget && (Dm*Dm)*(Dm*Dm)*Amin*P.macerror*(1.0 - 1e-12) < rm2) &&
+                 !(eigen && !((Dm*Dm)*(1.0 - 1e-12) >= g.mac*Amax))) {
+          // every leaf clears the overlap and opening distances: "cell" for all.  Only the complete group goes to the
+          // shared list from here; partial masks and single-particle leaves take the per-leaf path
+          if (fm == allmask && !(isleaf && g.N == 1)) acc = true; else slow = true;
+        }
+        // every leaf opens it: the node is inside every leaf's opening distance (geometric MAC: drsqd < cdistsqd, whether
+        // through the overlap branch or the MAC branch) and too large to lie inside any leaf's overlap range
+        else if (!isleaf && !gadget && !eigen && g.rmax > Lm && Dp*Dp < g.cdistsqd) opn = true;
+        else slow = true;
       }
-      else {
+      const unsigned long long gm = __ballot(acc), om = __ballot(opn), qm = __ballot(slow);
+      if (gm) {
+        const int pos = len_g + __popcll(gm & lt);
+        if (acc) { if (pos < G.cap_g) G.gcells[(size_t) q*G.cap_g + pos] = n; else overflow = true; }
+        len_g += __popcll(gm);
+      }
+      __syncthreads();
+      if (opn) {
+        const int pos = newtop + 2*__popcll(om & lt);
+        if (pos + 1 < GH_SCAP) {
+          s_stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) fm;
+          s_stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) fm;
+        }
+      }
+      top = newtop + 2*__popcll(om);
+      if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
+      if (slow) { const int pos = qn + __popcll(qm & lt); s_qnode[pos] = n; s_qmask[pos] = (unsigned short) fm; }
+      qn += __popcll(qm);
+      __syncthreads();
+    }
+    if (qn > 0 && (qn >= 64 || top == 0)) {
+      // (a batch pushes two entries per lane at most: sized to the room left on the stack, never less than 4 lanes)
+      const int room = (GH_SCAP - top) >> 1;
+      const int b = min(min(qn, 64), max(room, 4));
+      unsigned int openm = 0, cellm = 0, hydm = 0, dirm = 0;
+      int n = 0; bool isleaf = false;
+      CellGeo g;
+      g.first = 0; g.N = 0;
+      if (lane < b) {
+        n = s_qnode[qn - 1 - lane];
+        const unsigned int fm = s_qmask[qn - 1 - lane];
+        g = d.cgeo[n];
+        if (g.N < 0) g.N = 0;
+        isleaf = n >= leaf0;
+        const double khr = K::kernrange*g.hmax;
+        const double rm2 = gadget ? g.rmax*g.rmax*d.ccom[n].m : 0.0;
         for (int l = 0; l < nl; l++) {
           if (!((fm >> l) & 1)) continue;
           double drsqd = 0.0;
@@ -173,61 +222,62 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
           }
         }
       }
-    }
-    // cells that every (non-empty) leaf of the group accepts go once into the group's shared list
-    const bool gfull = cellm != 0 && cellm == allmask;
-    const unsigned long long gm = __ballot(gfull);
-    if (gm) {
-      const int pos = len_g + __popcll(gm & lt);
-      if (gfull) { if (pos < G.cap_g) G.gcells[(size_t) q*G.cap_g + pos] = n; else overflow = true; }
-      len_g += __popcll(gm);
-    }
-    if (gfull) cellm = 0;
-    const unsigned long long om = __ballot(openm != 0);
-    const bool anycell = __any(cellm != 0), anynear = __any((hydm | dirm) != 0);
-    __syncthreads();
-    if (openm) {
-      const int pos = newtop + 2*__popcll(om & lt);
-      if (pos + 1 < GH_SCAP) {
-        s_stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
-        s_stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
+      qn -= b;
+      // cells that every (non-empty) leaf of the group accepts go once into the group's shared list
+      const bool gfull = cellm != 0 && cellm == allmask;
+      const unsigned long long gm = __ballot(gfull);
+      if (gm) {
+        const int pos = len_g + __popcll(gm & lt);
+        if (gfull) { if (pos < G.cap_g) G.gcells[(size_t) q*G.cap_g + pos] = n; else overflow = true; }
+        len_g += __popcll(gm);
       }
-    }
-    top = newtop + 2*__popcll(om);
-    if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
-    if (anycell | anynear) {
-      const int nent = g.first | (g.N << 27);
+      if (gfull) cellm = 0;
+      const unsigned long long om = __ballot(openm != 0);
+      const bool anycell = __any(cellm != 0), anynear = __any((hydm | dirm) != 0);
+      __syncthreads();
+      if (openm) {
+        const int pos = top + 2*__popcll(om & lt);
+        if (pos + 1 < GH_SCAP) {
+          s_stack[pos] = 2*n + 1; s_smask[pos] = (unsigned short) openm;
+          s_stack[pos + 1] = 2*n + 2; s_smask[pos + 1] = (unsigned short) openm;
+        }
+      }
+      top = top + 2*__popcll(om);
+      if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
+      if (anycell | anynear) {
+        const int nent = g.first | (g.N << 27);
 #pragma unroll
-      for (int l = 0; l < GH_MAXLEAF; l++) {
-        if (l < nl) {
-          const size_t leaf = (size_t) (q*nl + l);
-          if (anycell) {
-            const bool bc = (cellm >> l) & 1;
-            const unsigned long long m_ = __ballot(bc);
-            if (m_) {
-              const int pos = len_c[l] + __popcll(m_ & lt);
-              if (bc) { if (pos < G.cap_c) G.cells[leaf*G.cap_c + pos] = n; else overflow = true; }
-              len_c[l] += __popcll(m_);
+        for (int l = 0; l < GH_MAXLEAF; l++) {
+          if (l < nl) {
+            const size_t leaf = (size_t) (q*nl + l);
+            if (anycell) {
+              const bool bc = (cellm >> l) & 1;
+              const unsigned long long m_ = __ballot(bc);
+              if (m_) {
+                const int pos = len_c[l] + __popcll(m_ & lt);
+                if (bc) { if (pos < G.cap_c) G.cells[leaf*G.cap_c + pos] = n; else overflow = true; }
+                len_c[l] += __popcll(m_);
+              }
             }
-          }
-          if (anynear) {
-            const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
-            const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
-            if (mh_) {
-              const int pos = len_h[l] + __popcll(mh_ & lt);
-              if (bh) { if (pos < G.cap_h) G.hydl[leaf*G.cap_h + pos] = make_int2(g.first, g.N); else overflow = true; }
-              len_h[l] += __popcll(mh_);
-            }
-            if (md_) {
-              const int pos = len_d[l] + __popcll(md_ & lt);
-              if (bd) { if (pos < G.cap_d) G.dirl[leaf*G.cap_d + pos] = nent; else overflow = true; }
-              len_d[l] += __popcll(md_);
+            if (anynear) {
+              const bool bh = (hydm >> l) & 1, bd = (dirm >> l) & 1;
+              const unsigned long long mh_ = __ballot(bh), md_ = __ballot(bd);
+              if (mh_) {
+                const int pos = len_h[l] + __popcll(mh_ & lt);
+                if (bh) { if (pos < G.cap_h) G.hydl[leaf*G.cap_h + pos] = make_int2(g.first, g.N); else overflow = true; }
+                len_h[l] += __popcll(mh_);
+              }
+              if (md_) {
+                const int pos = len_d[l] + __popcll(md_ & lt);
+                if (bd) { if (pos < G.cap_d) G.dirl[leaf*G.cap_d + pos] = nent; else overflow = true; }
+                len_d[l] += __popcll(md_);
+              }
             }
           }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 #ifdef GH_DEBUG_BLOCKTIME
   if (lane == 0 && G.dbgw) {

@@ -925,6 +925,43 @@ void gh_rootbox_local(gh_ctx *ctx, int node0)
   hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, ctx->stream, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
 }
 
+// 32-bit sort keys: the coordinate's position in the build's box, truncated - monotone (not strictly) in x
+__global__ void k_sortkeys(DevicePtrs d, const double *bmin, const double *bmax, unsigned int *keys, int p0, int pn, int N)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= pn) return;
+  const double lo = bmin[k], ext = bmax[k] - lo;
+  const double scale = ext > 0.0 ? 4294967295.0/ext : 0.0;
+  double u = (d.f[D_RX + k][p0 + i] - lo)*scale;
+  u = u < 0.0 ? 0.0 : (u > 4294967295.0 ? 4294967295.0 : u);
+  keys[(size_t) k*N + i] = (unsigned int) u;
+}
+// runs of equal 32-bit keys -> (coordinate, position) order: the first element of every run sorts it (insertion sort;
+// runs are one or two elements long unless coordinates coincide, and then they are already in order)
+__global__ void k_sortfix(const double *x, const unsigned int *keys, int *ids, int n)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= n || i + 1 >= n) return;
+  const unsigned int u = keys[i];
+  if ((i > 0 && keys[i - 1] == u) || keys[i + 1] != u) return;
+  int e = i + 2;
+  while (e < n && keys[e] == u) e++;
+  for (int j = i + 1; j < e; j++) {
+    const int idj = ids[j];
+    const double xj = x[idj];
+    int q = j - 1;
+    while (q >= i) {
+      const int idq = ids[q];
+      const double xq = x[idq];
+      if (xq < xj || (xq == xj && idq < idj)) break;
+      ids[q + 1] = idq;
+      q--;
+    }
+    ids[q + 1] = idj;
+  }
+}
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0> SortCfg;
+
 int gh_tree_build_impl(gh_ctx *ctx)
 {
   int rc = gh_alloc_tree(ctx);
@@ -942,15 +979,20 @@ int gh_tree_build_impl(gh_ctx *ctx)
   DevicePtrs d = gh_dev(ctx);
   hipStream_t s = ctx->stream;
 
-  // one argsort per axis, on three streams (each sort is ~30 small launches: they overlap)
+  // One argsort per axis, on three streams.  The keys are 32-bit fixed-point coordinates relative to the build's box
+  // (monotone in x), sorted with rocPRIM's onesweep radix sort (4 passes; its merge sort, which it would pick for <= 2^20
+  // fp64 keys, needs 10 merge passes of two launches each); particles whose 32-bit keys collide are then put into
+  // (x, position) order by k_sortfix - the result is the stable fp64 sort's, element for element.
   if (ctx->iota_N != N || ctx->iota_p0 != p0) {             // identity values for the argsorts: never modified
     hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, s, ctx->sortvals, pn, p0);
     ctx->iota_N = N; ctx->iota_p0 = p0;
   }
   {
+    unsigned int *kin = (unsigned int*) ctx->sortkeys_out, *kout = kin + (size_t) 3*N;      // 2 x 3N x 4 B = the 24N bytes allocated
+    const int node0 = (1 << L) - 1 + ctx->rank;
+    hipLaunchKernelGGL(k_sortkeys, dim3(nb, ctx->ndim), dim3(256), 0, s, d, ctx->dbbmin + 3*node0, ctx->dbbmax + 3*node0, kin, p0, pn, N);
     size_t need = 0;
-    GH_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, need, d.f[D_RX] + p0, ctx->sortkeys_out, ctx->sortvals,
-                                            ctx->P[0][0] + p0, (size_t) pn, 0, 64, s));
+    GH_CHECK(ctx, rocprim::radix_sort_pairs<SortCfg>(nullptr, need, kin, kout, ctx->sortvals, ctx->P[0][0] + p0, (size_t) pn, 0, 32, s));
     need = (need + 255) & ~(size_t) 255;
     if (3*need > ctx->sorttemp_bytes) {
       GH_CHECK(ctx, hipStreamSynchronize(s));
@@ -962,8 +1004,9 @@ int gh_tree_build_impl(gh_ctx *ctx)
     for (int k = 0; k < ctx->ndim; k++) {
       hipStream_t sk = k == 0 ? s : ctx->aux[k - 1];
       if (k > 0) GH_CHECK(ctx, hipStreamWaitEvent(sk, ctx->ev_fork, 0));
-      GH_CHECK(ctx, rocprim::radix_sort_pairs((char*) ctx->sorttemp + k*need, need, d.f[D_RX + k] + p0,
-                                              ctx->sortkeys_out + (size_t) k*N, ctx->sortvals, ctx->P[0][k] + p0, (size_t) pn, 0, 64, sk));
+      GH_CHECK(ctx, rocprim::radix_sort_pairs<SortCfg>((char*) ctx->sorttemp + k*need, need, kin + (size_t) k*N, kout + (size_t) k*N, ctx->sortvals,
+                                                       ctx->P[0][k] + p0, (size_t) pn, 0, 32, sk));
+      hipLaunchKernelGGL(k_sortfix, dim3(nb), dim3(256), 0, sk, d.f[D_RX + k], kout + (size_t) k*N, ctx->P[0][k] + p0, pn);
       if (k > 0) GH_CHECK(ctx, hipEventRecord(ctx->ev_join[k - 1], sk));
     }
     for (int k = 1; k < ctx->ndim; k++) GH_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
