@@ -209,7 +209,7 @@ extern "C" void gh_destroy(gh_ctx *ctx)
   gh_dd_free(ctx);
   gh_sinks_free(ctx);
   free_particles(ctx);
-  void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->leafact, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
+  void *ptrs[] = {ctx->dl_rl, ctx->dl_rlen, ctx->d_blk, ctx->gl_cells, ctx->gl_dirl, ctx->gl_hydl, ctx->gl_len, ctx->gl_gcells, ctx->gl_glen, ctx->cfirst, ctx->cN, ctx->cleft, ctx->cbox, ctx->ch, ctx->cgeo, ctx->ccom, ctx->cquad, ctx->cvel, ctx->leafact, ctx->star_posm, ctx->star_h, ctx->star_out, ctx->ktab, ctx->leaf_amin, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->sorttemp,
                   ctx->redbuf, ctx->d_stats, ctx->d_flags, ctx->d_ptrtab};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (int ph = 0; ph < GH_T_COUNT; ph++) for (auto &p : ctx->ev_used[ph]) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }

@@ -129,8 +129,8 @@ struct gh_ctx {
   // tree
   int ltot = 0, gtot = 0, Ncell = 0, lgroup = 0, ngroups = 0, leafocc = 0;
   int64_t tree_layout_N = -1;
-  std::vector<int> h_cfirst, h_cN;
-  int *cfirst = nullptr, *cN = nullptr;
+  std::vector<int> h_cfirst, h_cN, h_cleft;
+  int *cfirst = nullptr, *cN = nullptr, *cleft = nullptr;
   CellBox *cbox = nullptr;
   CellH *ch = nullptr;
   CellGeo *cgeo = nullptr;

@@ -96,114 +96,103 @@ struct LevelArgs {
   int level, nwords;
   int p0, pn;            // particle range [p0, p0 + pn) the build works on: everything on one rank, the rank's own cell otherwise
   int jbase;             // k_build_subtree: first level-L0 cell of the range
+  const int *cleft;      // per cell: lefts (floor(N/2) each) of the cells before it on its level
+  int cleft0;            // ... of the first cell of this rank's range on the level being split
 };
 
-// level steps 1+2: split axis + median + children's inherited boxes (KDTree.cpp:490-533) and the left (0) /
-// right (1) mark of every particle, taken from its cell's split-axis list
-__global__ void k_mark_side(DevicePtrs d, LevelArgs a)
+// One level of the build above the LDS-resident subtrees, two kernels.
+//
+// k_level_flags: per cell, split axis + median + children's inherited boxes (KDTree.cpp:490-533); per position of each
+// of the three presorted lists, whether its particle goes left.  A cell's segment of every list is sorted by
+// (coordinate, position in the argsort's input) - the argsort is stable and the partitions below keep the order - so
+// "left" is "(x_kd, id) < (x_kd, id) of the median element", read straight from the coordinates: no scatter of side
+// marks through particle ids.  Output: one 64-bit word of left-flags per wavefront and list, and per 1024-position block
+// and list the number of lefts.
+// k_level_scatter: stable partition of every cell segment of every list.  The rank of a left-going element among the
+// lefts of its cell = (lefts before it in the whole list) - (lefts before the cell's first position); the second term
+// is static - every cell sends exactly floor(N/2) left - and precomputed per cell (`cleft`); the first is the block's
+// prefix (each block sums the counts of the blocks before it: at most 1024 values) + words + bits.
+#define GH_LB 1024
+__global__ __launch_bounds__(GH_LB) void k_level_flags(DevicePtrs d, LevelArgs a)
 {
-  const int pl = blockIdx.x*blockDim.x + threadIdx.x;
-  if (pl >= a.pn) return;
-  const int p = a.p0 + pl;
+  __shared__ unsigned int s_cnt[3][GH_LB/64];
+  const int pl = blockIdx.x*GH_LB + threadIdx.x;
+  const bool in = pl < a.pn;
+  const int p = a.p0 + (in ? pl : 0);
   const int n = a.cellnode[p];
   const int first = d.cfirst[n], cnt = d.cN[n], half = cnt/2;
-  // split axis = longest side of the inherited box (every particle of the cell recomputes it: 6 cached loads)
-  double bmin[3], bmax[3];
-  double rkmax = 0.0;
+  double bmin[3], bmax[3], rkmax = 0.0;
   int kd = 0;
   for (int k = 0; k < 3; k++) { bmin[k] = a.dbbmin[n*3 + k]; bmax[k] = a.dbbmax[n*3 + k]; }
   _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     const double ext = bmax[k] - bmin[k];
     if (ext > rkmax) { rkmax = ext; kd = k; }
   }
-  const int right = (p - first >= half) ? 1 : 0;
-  a.side[a.P[kd][p]] = (unsigned char) right;
-  a.cellnode_next[p] = 2*n + 1 + right;
-  if (p == first) {
-    // the cell's first particle also writes the children's inherited boxes (median = first of the right half)
-    const double rdiv = d.f[D_RX + kd][a.P[kd][first + half]];
-    if (half > 0 && d.f[D_RX + kd][a.P[kd][first + half - 1]] == rdiv) *a.tie = 1;
-    const int c1 = 2*n + 1, c2 = 2*n + 2;
-    for (int k = 0; k < 3; k++) {
-      a.dbbmin[c1*3 + k] = bmin[k]; a.dbbmax[c1*3 + k] = (k == kd) ? rdiv : bmax[k];
-      a.dbbmin[c2*3 + k] = (k == kd) ? rdiv : bmin[k]; a.dbbmax[c2*3 + k] = bmax[k];
-    }
-    a.kdiv[n] = kd;
-  }
-}
-
-// level step 3: one 64-bit word of "is left" flags per wave per axis, plus the count of left flags of
-// every 256-particle block (what the prefix scan runs over: 16x less data than the words)
-__global__ __launch_bounds__(256) void k_ballot_words(DevicePtrs d, LevelArgs a)
-{
-  __shared__ unsigned int s_cnt[3][4];
-  const int pl = blockIdx.x*blockDim.x + threadIdx.x;      // word / block indices are local to the range
-  const int p = a.p0 + pl;
+  const double *xk = d.f[D_RX + kd];
+  const int idm = a.P[kd][first + half];
+  const double xm = xk[idm];
   _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
-    const int flag = (pl < a.pn) ? (a.side[a.P[k][p]] == 0) : 0;
-    const unsigned long long w = __ballot(flag);
+    const int id = a.P[k][p];
+    const double x = xk[id];
+    const bool left = in && (x < xm || (x == xm && id < idm));
+    const unsigned long long w = __ballot(left);
     if ((threadIdx.x & 63) == 0) {
       if ((pl >> 6) < a.nwords) a.W[k][pl >> 6] = w;
       s_cnt[k][threadIdx.x >> 6] = __popcll(w);
     }
   }
+  if (in) {
+    a.cellnode_next[p] = 2*n + 1 + ((p - first >= half) ? 1 : 0);
+    if (p == first) {
+      // the cell's first position also writes the children's inherited boxes (median = first of the right half)
+      if (half > 0 && xk[a.P[kd][first + half - 1]] == xm) *a.tie = 1;
+      const int c1 = 2*n + 1, c2 = 2*n + 2;
+      for (int k = 0; k < 3; k++) {
+        a.dbbmin[c1*3 + k] = bmin[k]; a.dbbmax[c1*3 + k] = (k == kd) ? xm : bmax[k];
+        a.dbbmin[c2*3 + k] = (k == kd) ? xm : bmin[k]; a.dbbmax[c2*3 + k] = bmax[k];
+      }
+      a.kdiv[n] = kd;
+    }
+  }
   __syncthreads();
   if ((int) threadIdx.x < d.ndim) {
-    const int k = threadIdx.x;
-    a.Wpre[k][blockIdx.x] = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+    unsigned int c = 0;
+    for (int w = 0; w < GH_LB/64; w++) c += s_cnt[threadIdx.x][w];
+    a.Wpre[threadIdx.x][blockIdx.x] = c;
   }
 }
 
-// level step 4: in-place exclusive prefix sum of the block counts (one workgroup per axis): per-thread run,
-// wave shuffle scan, 16 wave totals through LDS - two barriers in all
-__global__ __launch_bounds__(1024) void k_scan_words(LevelArgs a)
+__global__ __launch_bounds__(GH_LB) void k_level_scatter(DevicePtrs d, LevelArgs a)
 {
-  const int k = blockIdx.x;
-  unsigned int *pre = a.Wpre[k];
-  const int nblk = (a.nwords + 3)/4;
-  __shared__ unsigned int s_wave[16];
-  const int per = (nblk + 1023)/1024;
-  const int lo = threadIdx.x*per, hi = min(lo + per, nblk);
-  unsigned int sum = 0;
-  for (int i = lo; i < hi; i++) sum += pre[i];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned int inc = sum;
-  for (int off = 1; off < 64; off <<= 1) { const unsigned int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
-  if (lane == 63) s_wave[wave] = inc;
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    unsigned int v = s_wave[threadIdx.x], w = v;
-    for (int off = 1; off < 16; off <<= 1) { const unsigned int t = __shfl_up(w, off, 64); if ((int) threadIdx.x >= off) w += t; }
-    s_wave[threadIdx.x] = w - v;
+  __shared__ unsigned int s_base[3];
+  __shared__ unsigned int s_wpre[3][GH_LB/64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < d.ndim) {
+    // lefts in all blocks before this one (wave k sums list k) and the running count of this block's words
+    unsigned int sum = 0;
+    for (int b = lane; b < (int) blockIdx.x; b += 64) sum += a.Wpre[wave][b];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const int w0 = blockIdx.x*(GH_LB/64);
+    unsigned int c = (lane < GH_LB/64 && w0 + lane < a.nwords) ? (unsigned int) __popcll(a.W[wave][w0 + lane]) : 0u;
+    unsigned int inc = c;
+    for (int off = 1; off < GH_LB/64; off <<= 1) { const unsigned int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+    if (lane < GH_LB/64) s_wpre[wave][lane] = inc - c;
+    if (lane == 0) s_base[wave] = sum;
   }
   __syncthreads();
-  unsigned int run = s_wave[wave] + inc - sum;
-  for (int i = lo; i < hi; i++) { const unsigned int c = pre[i]; pre[i] = run; run += c; }
-}
-
-// number of left flags in [0, p): block prefix + whole words of the block before p + bits of p's word
-__device__ __forceinline__ unsigned int rank_left(const unsigned long long *W, const unsigned int *pre, int p)
-{
-  const int w = p >> 6, b = p & 63;
-  unsigned int r = pre[p >> 8];
-  for (int i = (w & ~3); i < w; i++) r += __popcll(W[i]);
-  const unsigned long long m = b ? (W[w] & ((1ull << b) - 1ull)) : 0ull;
-  return r + __popcll(m);
-}
-
-// level step 5: stable partition of every cell segment of every axis list
-__global__ void k_partition(DevicePtrs d, LevelArgs a)
-{
-  const int pl = blockIdx.x*blockDim.x + threadIdx.x;
+  const int pl = blockIdx.x*GH_LB + threadIdx.x;
   if (pl >= a.pn) return;
   const int p = a.p0 + pl;
   const int n = a.cellnode[p];
   const int first = d.cfirst[n], half = d.cN[n]/2;
+  const unsigned int lbase = (unsigned int) (a.cleft[n] - a.cleft0);        // lefts before the cell's first position
   _Pragma("unroll") for (int k = 0; k < 3; k++) if (k < d.ndim) {
     const int id = a.P[k][p];
-    const int right = a.side[id];
-    const int nleft_before = (int) (rank_left(a.W[k], a.Wpre[k], pl) - rank_left(a.W[k], a.Wpre[k], first - a.p0));
-    const int np = right ? first + half + ((p - first) - nleft_before) : first + nleft_before;
+    const unsigned long long w = a.W[k][pl >> 6];
+    const bool left = (w >> lane) & 1ull;
+    const unsigned int rl = s_base[k] + s_wpre[k][wave] + (unsigned int) __popcll(lane ? (w & ((1ull << lane) - 1ull)) : 0ull);
+    const int nleft_before = (int) (rl - lbase);
+    const int np = left ? first + nleft_before : first + half + ((p - first) - nleft_before);
     a.Pn[k][np] = id;
   }
 }
@@ -813,6 +802,11 @@ int gh_alloc_tree(gh_ctx *ctx)
     ctx->h_cfirst[2*n + 1] = ctx->h_cfirst[n];        ctx->h_cN[2*n + 1] = half;
     ctx->h_cfirst[2*n + 2] = ctx->h_cfirst[n] + half; ctx->h_cN[2*n + 2] = ctx->h_cN[n] - half;
   }
+  ctx->h_cleft.assign(Ncell, 0);
+  for (int l = 0; l <= ltot; l++) {
+    int run = 0;
+    for (int j = 0; j < (1 << l); j++) { const int n = (1 << l) - 1 + j; ctx->h_cleft[n] = run; run += ctx->h_cN[n]/2; }
+  }
   int occ = 0;
   for (int g = 0; g < gtot; g++) occ = std::max(occ, ctx->h_cN[gtot - 1 + g]);
   ctx->leafocc = occ;
@@ -843,6 +837,7 @@ int gh_alloc_tree(gh_ctx *ctx)
   auto re = [&](void **p, size_t bytes) -> hipError_t { if (*p) (void) hipFree(*p); *p = nullptr; return hipMalloc(p, bytes); };
   GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cN, sizeof(int)*Ncell));
+  GH_CHECK(ctx, re((void**) &ctx->cleft, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cbox, sizeof(CellBox)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->ch, sizeof(CellH)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cgeo, sizeof(CellGeo)*Ncell));
@@ -862,6 +857,7 @@ int gh_alloc_tree(gh_ctx *ctx)
   GH_CHECK(ctx, re((void**) &ctx->kdiv, sizeof(int)*Ncell));
   GH_CHECK(ctx, hipMemcpyAsync(ctx->cfirst, ctx->h_cfirst.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
   GH_CHECK(ctx, hipMemcpyAsync(ctx->cN, ctx->h_cN.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
+  GH_CHECK(ctx, hipMemcpyAsync(ctx->cleft, ctx->h_cleft.data(), sizeof(int)*Ncell, hipMemcpyHostToDevice, ctx->stream));
   GH_CHECK(ctx, hipMemsetAsync(ctx->cbox, 0, sizeof(CellBox)*Ncell, ctx->stream));
   GH_CHECK(ctx, hipMemsetAsync(ctx->ch, 0, sizeof(CellH)*Ncell, ctx->stream));
   GH_CHECK(ctx, hipMemsetAsync(ctx->cgeo, 0, sizeof(CellGeo)*Ncell, ctx->stream));
@@ -1024,15 +1020,15 @@ int gh_tree_build_impl(gh_ctx *ctx)
     a.tie = ctx->d_blk + 13;
     a.level = l; a.nwords = nwords;
     a.p0 = p0; a.pn = pn; a.jbase = 0;
+    a.cleft = ctx->cleft; a.cleft0 = 0;
     return a;
   };
   const int lsub = ctx->lsub;
   for (int l = L; l < lsub; l++) {
     LevelArgs a = level_args(l);
-    hipLaunchKernelGGL(k_mark_side, dim3(nb), dim3(256), 0, s, d, a);
-    hipLaunchKernelGGL(k_ballot_words, dim3(nb), dim3(256), 0, s, d, a);
-    hipLaunchKernelGGL(k_scan_words, dim3(ctx->ndim), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(k_partition, dim3(nb), dim3(256), 0, s, d, a);
+    a.cleft0 = ctx->h_cleft[(1 << l) - 1 + (ctx->rank << (l - L))];
+    hipLaunchKernelGGL(k_level_flags, dim3(cdiv(pn, GH_LB)), dim3(GH_LB), 0, s, d, a);
+    hipLaunchKernelGGL(k_level_scatter, dim3(cdiv(pn, GH_LB)), dim3(GH_LB), 0, s, d, a);
     pb ^= 1;
   }
   {

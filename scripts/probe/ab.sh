@@ -1,5 +1,9 @@
-for v in A B C A B C; do
-  GANDALF_HIP_LIB=$GRAFT_REPO_ROOT/variants/lib$v.so timeout -k 10 300 python bench.py --workload plummer1m --steps 20 --warmup 3 --no-cpu > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err || exit 1
+# A/B timing of library builds on the GPU box: bash scripts/probe/ab.sh <workload> <variant> ...   (variants/lib<variant>.so)
+# The variant replaces the in-tree library of the box's scratch copy, because the host shell resolves libgandalf_hip.so by rpath.
+w=$1; shift
+for v in "$@"; do
+  cp variants/lib$v.so gandalf_amd/csrc/libgandalf_hip.so
+  timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu > gpurun_out/ab_$v.json 2>gpurun_out/ab_$v.err || { tail -3 gpurun_out/ab_$v.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
