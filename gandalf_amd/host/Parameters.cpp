@@ -85,6 +85,22 @@ void Parameters::SetDefaultValues()
   floatparams["gasfrac"] = 0.0;
   floatparams["starfrac"] = 0.0;
   intparams["com_frame"] = 0;
+  // Boss-Bodenheimer cloud (ic = bb) and sink particles (Parameters.cpp of the reference: same keys and defaults)
+  floatparams["mcloud"] = 1.0;
+  floatparams["angvel"] = 0.0;
+  floatparams["amp"] = 0.1;
+  intparams["sink_particles"] = 0;
+  intparams["create_sinks"] = 0;
+  intparams["smooth_accretion"] = 0;
+  intparams["Nsinkfixed"] = -1;
+  intparams["nbody_softening"] = 1;
+  floatparams["nbody_mult"] = 0.1;
+  floatparams["rho_sink"] = 1.0e-12;
+  floatparams["sink_radius"] = 2.0;
+  floatparams["alpha_ss"] = 0.01;
+  floatparams["smooth_accrete_frac"] = 0.01;
+  floatparams["smooth_accrete_dt"] = 0.01;
+  stringparams["sink_radius_mode"] = "hmult";
   stringparams["rand_algorithm"] = "xorshift";
   intparams["randseed"] = 1;
   intparams["device"] = 0;               // (ours) HIP device ordinal of this process

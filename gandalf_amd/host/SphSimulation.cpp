@@ -71,6 +71,7 @@ SphSimulation::SphSimulation(int ndim, Parameters *params) : ndim(ndim), simpara
 
 SphSimulation::~SphSimulation()
 {
+  if (nbody) gh_nbody_destroy(nbody);
   if (ctx) gh_destroy(ctx);
   delete sph; delete sphneib; delete randnumb;
 }
@@ -123,6 +124,13 @@ void SphSimulation::ProcessParameters()
   cfg.gamma_eos = fp["gamma_eos"]; cfg.temp0 = fp["temp0"]; cfg.mu_bar = fp["mu_bar"]; cfg.rho_bary = fp["rho_bary"];
   cfg.thetamaxsqd = fp["thetamaxsqd"];
   cfg.courant_mult = fp["courant_mult"]; cfg.accel_mult = fp["accel_mult"]; cfg.energy_mult = fp["energy_mult"];
+  // sink particles (SphSimulation.cpp:116-136; dimensionless runs: rho_sink and sink_radius need no unit scaling)
+  cfg.sink_particles = ip["sink_particles"]; cfg.create_sinks = cfg.sink_particles ? ip["create_sinks"] : 0;
+  cfg.smooth_accretion = ip["smooth_accretion"]; cfg.Nsinkfixed = ip["Nsinkfixed"];
+  cfg.sink_radius_mode = sp["sink_radius_mode"] == "fixed" ? 0 : (sp["sink_radius_mode"] == "hmult" ? 1 : 2);
+  cfg.rho_sink = fp["rho_sink"]; cfg.sink_radius = fp["sink_radius"]; cfg.alpha_ss = fp["alpha_ss"];
+  cfg.smooth_accrete_frac = fp["smooth_accrete_frac"]; cfg.smooth_accrete_dt = fp["smooth_accrete_dt"];
+  if (cfg.sink_particles && ip["dimensionless"] == 0) throw GandalfError("sink runs: dimensionless units required");
   tend = fp["tend"]; Nstepsmax = ip["Nstepsmax"];
   delete sph; delete randnumb;
   sph = new Sph(ndim, cfg.h_fac, (cfg.kernel == GH_KERNEL_QUINTIC || cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0);
@@ -261,6 +269,128 @@ void SphSimulation::GenerateIC()
     }
     initial_h_provided = true;
   }
+  else if (ic == "bb") {
+    // BossBodenheimerIc::Generate (BossBodenheimerIc.cpp:71-150): a sphere cut out of a lattice (Ic::AddLatticeSphere,
+    // Ic.cpp:505-566: lattice in [-2,2]^3, Ic::CutSphere bisection, random Euler rotation), an m = 2 azimuthal density
+    // perturbation (Ic::AddAzimuthalDensityPerturbation, Ic.cpp:850-915) and solid-body rotation about z
+    // (Ic::AddRotationalVelocityField, Ic.cpp:974-1021)
+    if (ndim != 3) throw GandalfError("Boss-Bodenheimer test only runs in 3D");
+    if (ip["dimensionless"] == 0) throw GandalfError("dimensionless units required");
+    const std::string dist = sp["particle_distribution"];
+    if (dist != "cubic_lattice" && dist != "hexagonal_lattice") throw GandalfError("Invalid particle distribution option");
+    const double pi = 3.14159265358979, twopi = 6.28318530717959, small_number = 1.0e-20;
+    const double amp = fp["amp"], angvel = fp["angvel"], mcloud = fp["mcloud"], radius = fp["radius"], temp0 = fp["temp0"];
+    const double gammaone = fp["gamma_eos"] - 1.0, mu_bar = fp["mu_bar"];
+    const double u0 = temp0/gammaone/mu_bar;
+    const double rho0 = 3.0*mcloud/(4.0*pi*pow(radius, 3));
+    const double mp = mcloud/(double) N;
+    int Nl[3];
+    for (int k = 0; k < 3; k++) Nl[k] = (int) (3.0*powf((double) N, (double) 1/3));
+    const int Naux0 = Nl[0]*Nl[1]*Nl[2];
+    std::vector<double> raux((size_t) 3*Naux0);
+    const double bmin = -2.0, bmax = 2.0;
+    if (dist == "cubic_lattice") {                       // Ic::AddCubicLattice, normalise = true (Ic.cpp:641-693)
+      const double spacing = (bmax - bmin)/(double) Nl[0];
+      for (int kk = 0; kk < Nl[2]; kk++) for (int jj = 0; jj < Nl[1]; jj++) for (int ii = 0; ii < Nl[0]; ii++) {
+        const size_t i = (size_t) kk*Nl[0]*Nl[1] + (size_t) jj*Nl[0] + ii;
+        raux[3*i] = bmin + ((double) ii + 0.5)*spacing; raux[3*i + 1] = bmin + ((double) jj + 0.5)*spacing; raux[3*i + 2] = bmin + ((double) kk + 0.5)*spacing;
+      }
+    }
+    else {                                               // Ic::AddHexagonalLattice, normalise = true (Ic.cpp:701-768)
+      const double rad = 0.5*(bmax - bmin)/(double) Nl[0];
+      for (int kk = 0; kk < Nl[2]; kk++) for (int jj = 0; jj < Nl[1]; jj++) for (int ii = 0; ii < Nl[0]; ii++) {
+        const size_t i = (size_t) kk*Nl[0]*Nl[1] + (size_t) jj*Nl[0] + ii;
+        raux[3*i] = bmin + 0.5*rad + (2.0*(double) ii + (double) (jj%2) + (double) ((kk + 1)%2))*rad;
+        raux[3*i + 1] = bmin + 0.5*sqrt(3.0)*rad + (double) jj*sqrt(3.0)*rad + (double) (kk%2)*rad/sqrt(3.0);
+        raux[3*i + 2] = bmin + sqrt(6.0)*rad/3.0 + (double) kk*2.0*sqrt(6.0)*rad/3.0;
+      }
+    }
+    // Ic::CutSphere (Ic.cpp:775-842): bisection on the radius that holds N lattice points
+    int Nsphere = 0;
+    {
+      double r_low = 0.0, r_high = 9.9e20, rad = 0.0;
+      for (int k = 0; k < 3; k++) r_high = std::min(r_high, 0.5*(bmax - bmin));
+      int Ninterior;
+      do {
+        rad = 0.5*(r_low + r_high);
+        Ninterior = 0;
+        for (int i = 0; i < Naux0; i++) {
+          const double drsqd = raux[3*(size_t) i]*raux[3*(size_t) i] + raux[3*(size_t) i + 1]*raux[3*(size_t) i + 1] + raux[3*(size_t) i + 2]*raux[3*(size_t) i + 2];
+          if (drsqd <= rad*rad) Ninterior++;
+        }
+        if (Ninterior < N && fabs(r_high - r_low)/rad < 1.e-8) break;
+        if (Ninterior > N) r_high = rad;
+        if (Ninterior < N) r_low = rad;
+      } while (Ninterior != N);
+      for (int i = 0; i < Naux0; i++) {
+        const double *q = &raux[3*(size_t) i];
+        const double drsqd = q[0]*q[0] + q[1]*q[1] + q[2]*q[2];
+        if (drsqd <= rad*rad) { for (int k = 0; k < 3; k++) raux[3*(size_t) Nsphere + k] = q[k]/rad; Nsphere++; }
+      }
+    }
+    // random Euler rotation (Ic.cpp:550-555, InlineFuncs.h:257-339)
+    {
+      const double theta = (double) acosf(sqrtf((float) randnumb->floatrand()));     // acos(float) -> the float overload, as the reference's <math.h> + using namespace std resolves it
+      const double phi = twopi*randnumb->floatrand();
+      const double psi = twopi*randnumb->floatrand();
+      double A[3][3];
+      A[0][0] = cos(theta)*cos(psi);
+      A[1][0] = cos(phi)*sin(psi) + sin(phi)*sin(theta)*cos(psi);
+      A[2][0] = sin(phi)*sin(psi) - cos(phi)*sin(theta)*cos(psi);
+      A[0][1] = -cos(theta)*sin(psi);
+      A[1][1] = cos(phi)*cos(psi) - sin(phi)*sin(theta)*sin(psi);
+      A[2][1] = sin(phi)*cos(psi) + cos(phi)*sin(theta)*sin(psi);
+      A[0][2] = sin(theta);
+      A[1][2] = -sin(phi)*cos(theta);
+      A[2][2] = cos(phi)*cos(theta);
+      for (int i = 0; i < Nsphere; i++) {
+        double va[3];
+        for (int k = 0; k < 3; k++) va[k] = raux[3*(size_t) i + k];
+        for (int k = 0; k < 3; k++) raux[3*(size_t) i + k] = A[0][k]*va[0] + A[1][k]*va[1] + A[2][k]*va[2];
+      }
+    }
+    sph->AllocateMemory(std::max(Nsphere, 1));
+    HydroParticles &q = sph->part;
+    for (int i = 0; i < Nsphere; i++) for (int k = 0; k < 3; k++) q.r[(size_t) i*3 + k] = 0.0 + radius*raux[3*(size_t) i + k];
+    // azimuthal perturbation, mode 2
+    {
+      const int mpert = 2, tabtot = 2048;
+      const double invmpert = 1.0/(double) mpert, spacing = twopi/(double) (tabtot - 1);
+      for (int i = 0; i < Nsphere; i++) {
+        const double rp0 = q.r[(size_t) i*3], rp1 = q.r[(size_t) i*3 + 1];
+        const double Rsqd = rp0*rp0 + rp1*rp1, Rmag = sqrt(Rsqd);
+        double phi = Rmag > small_number ? asin(fabs(rp1)/Rmag) : 0.0;
+        if (rp0 < 0.0 && rp1 > 0.0) phi = pi - phi;
+        else if (rp0 < 0.0 && rp1 < 0.0) phi = pi + phi;
+        else if (rp0 > 0.0 && rp1 < 0.0) phi = twopi - phi;
+        if (phi < amp*invmpert) phi = phi + twopi;
+        for (int j = 1; j < tabtot; j++) {
+          double phi1 = spacing*(double) (j - 1), phi2 = spacing*(double) j;
+          phi1 = phi1 + amp*cos((double) mpert*phi1)*invmpert;
+          phi2 = phi2 + amp*cos((double) mpert*phi2)*invmpert;
+          if (phi2 >= phi && phi1 < phi) {
+            const double phiprime = spacing*(double) (j - 1) + spacing*(phi - phi1)/(phi2 - phi1);
+            q.r[(size_t) i*3] = 0.0 + Rmag*cos(phiprime);
+            q.r[(size_t) i*3 + 1] = 0.0 + Rmag*sin(phiprime);
+            break;
+          }
+        }
+      }
+    }
+    // solid-body rotation
+    for (int i = 0; i < Nsphere; i++) {
+      double dr0 = q.r[(size_t) i*3], dr1 = q.r[(size_t) i*3 + 1];
+      for (int k = 0; k < 3; k++) q.v[(size_t) i*3 + k] = 0.0;
+      const double Rsqd = dr0*dr0 + dr1*dr1 + small_number, Rmag = sqrt(Rsqd);
+      if (Rmag > small_number) {
+        dr0 = dr0/Rmag; dr1 = dr1/Rmag;
+        q.v[(size_t) i*3] = -angvel*Rmag*dr1;
+        q.v[(size_t) i*3 + 1] = angvel*Rmag*dr0;
+      }
+    }
+    for (int i = 0; i < Nsphere; i++) { q.m[i] = mp; q.h[i] = cfg.h_fac*pow(q.m[i]/rho0, 1.0/3.0); q.u[i] = u0; }
+    initial_h_provided = true;
+  }
   else throw GandalfError("Unrecognised parameter : ic = " + ic);
 }
 
@@ -286,7 +416,13 @@ void SphSimulation::PostInitialConditionsSetup()
   // a run that starts from a snapshot keeps the snapshot's time (ReadColumnSnapshotFile / ReadSerenUnformSnapshotFile set
   // Simulation::t and nothing in the setup resets it); generated ICs start at t = 0
   if (t != 0.0) check(ctx, gh_set_time(ctx, t, 0.0), "set_time");
-  check(ctx, gh_setup(ctx, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
+  if (cfg.sink_particles) {
+    // sink runs: the (initially empty) star context holds the sinks; the library does the sink part of MainLoop
+    if (!nbody && gh_nbody_create(ndim, simparams->intparams["nbody_softening"], simparams->floatparams["nbody_mult"], cfg.device, &nbody))
+      throw GandalfError(std::string("Nbody: ") + gh_nbody_last_error(nbody));
+    check(ctx, gh_hybrid_setup(ctx, nbody, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
+  }
+  else check(ctx, gh_setup(ctx, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
   Nsteps = 0;
   setup = true;
 }
@@ -302,7 +438,11 @@ void SphSimulation::SetupSimulation()
 
 void SphSimulation::MainLoop(int nsteps)
 {
-  check(ctx, gh_step(ctx, nsteps, &t, &timestep), "MainLoop");
+  if (cfg.sink_particles) {
+    check(ctx, gh_hybrid_step(ctx, nbody, nsteps, &t, &timestep), "MainLoop");
+    sph->part.N = (int) gh_num_particles(ctx);                 // accreted particles leave the arrays
+  }
+  else check(ctx, gh_step(ctx, nsteps, &t, &timestep), "MainLoop");
   Nsteps += nsteps;
 }
 

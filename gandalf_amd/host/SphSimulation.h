@@ -77,6 +77,7 @@ class SphSimulation {
   Parameters *simparams;
   gh_config cfg;
   gh_ctx *ctx = nullptr;
+  gh_nbody *nbody = nullptr;               // sink runs: the stars the sinks are (Nbody, Sinks; SphSimulation.cpp:116-136)
   Sph *sph = nullptr;
   SphNeighbourSearch *sphneib = nullptr;
   XorshiftRand *randnumb = nullptr;

@@ -276,3 +276,23 @@ def test_potmin_flags_vs_oracle():
     pm_ref = (o.get_int("flags")[dense] & 8) != 0
     assert dense.sum() > 1500 and 0 < pm_ref.sum() < dense.sum()
     assert np.array_equal(pm_gpu, pm_ref), (int((pm_gpu != pm_ref).sum()), int(pm_ref.sum()))
+
+
+def test_sink_run_from_parameter_file():
+    """the host shell runs the Boss-Bodenheimer sink case from its parameter file alone (ic = bb generated on the host,
+    sink_particles = 1 -> star context + gh_hybrid_setup / gh_hybrid_step inside SphSimulation): same particle count, sinks
+    and positions as the reference after 12 steps"""
+    from conftest import load_golden
+    from gandalf_amd.host import Simulation
+    g = load_golden("bb_sinks_8k_steps")
+    sim = Simulation("%s/bb_sinks_8k.dat" % PARAMS)
+    sim.setup()
+    assert abs(sim.timestep - g["setup_t_timestep"][1]) <= 1e-10*sim.timestep
+    sim.main_loop(int(g["nsteps"][0]))
+    dev = sim.device()
+    assert dev.N == int(g["final_Nhydro"][0])
+    assert abs(sim.t - g["final_t_timestep"][0]) <= 1e-11*sim.t
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    sk = dev.sinks()
+    assert np.array_equal(sk["Ngas"], g["final_sink_Ngas"])
+    assert np.max(np.abs(sk["menc"] - g["final_sink_menc"])/g["final_sink_menc"]) < 1e-9

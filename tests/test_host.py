@@ -57,6 +57,16 @@ def test_params_grammar_and_defaults():
     assert sim2.get_param("Nhydro") == "128" and sim2.get_param("boundary_lhs[0]") == "periodic"
 
 
+def test_boss_bodenheimer_ic_bitwise():
+    """ic = bb (BossBodenheimerIc.cpp:71-150): hexagonal lattice cut to a sphere, random Euler rotation (with the reference's
+    single-precision acos), m = 2 azimuthal perturbation, solid-body rotation - the particles the reference generated"""
+    from gandalf_amd.host import Simulation
+    g = load_golden("bb_sinks_8k_steps")
+    ic = Simulation(os.path.join(PARAMS, "bb_sinks_8k.dat")).generate_ic()
+    assert np.array_equal(ic["r"], g["setup_r"]) and np.array_equal(ic["v"], g["setup_v"]) and np.array_equal(ic["m"], g["setup_m"])
+    assert ic["initial_h_provided"]
+
+
 @pytest.mark.parametrize("case", ["box3d_4k", "plummer_4k", "adsod_1d"])
 def test_ic_generators_bitwise(case):
     from gandalf_amd.host import Simulation
