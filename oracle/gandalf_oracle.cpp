@@ -1523,6 +1523,7 @@ struct Oracle {
     int activecount = 0;
     for (int i = 0; i < Nhydro; i++) {
       Part &q = p[i];
+      if (q.flags & F_DEAD) continue;                                  // SphLeapfrogKDK.cpp:307
       const int dn = n - q.nlast;
       if (dn == q.nstep) continue;
       if (q.levelneib - q.level > P.level_diff_max) {
@@ -1545,7 +1546,7 @@ struct Oracle {
       if (x.level != tree.ltot) continue;
       int i = x.ifirst;
       while (i != -1) {
-        if (i < Nhydro && (p[i].flags & F_ACTIVE)) x.Nactive++;
+        if (i < Nhydro && (p[i].flags & F_ACTIVE) && !(p[i].flags & F_DEAD)) x.Nactive++;
         if (i == x.ilast) break;
         i = tree.inext[i];
       }
@@ -2162,6 +2163,134 @@ static void AccreteMassToSinks(Oracle &g, NbodyOracle &nb, int n, FLOAT timestep
   }
 }
 
+// Simulation::ComputeBlockTimesteps (Simulation.cpp:1764-2200) for gas + stars: the gas part as Oracle::ComputeBlockTimesteps,
+// with the dead-particle skips and the star branches (stars sit on levels >= the highest gas level)
+static double StarTimestep(const NbodyOracle &nb, const Star &s)       // NbodyLeapfrogKDK::Timestep, :387-400
+{
+  const double amag = sqrt(Dot(s.a, s.a, 3));
+  double ts = nb.nbody_mult*sqrt(s.h/(amag + small_number_dp));
+  return std::min(ts, (double) s.dt_internal);
+}
+static void ComputeBlockTimestepsHybrid(Oracle &g, NbodyOracle &nb)
+{
+  const Params &P = g.P;
+  auto ipow2 = [](int e) { return (int) pow(2.0, e); };
+  auto lvl = [](double dt, double dt_max) { return std::max((int) (invlogetwo*log(dt_max/dt)) + 1, 0); };
+  if (g.n == g.nresync) {
+    g.n = 0; g.timestep = big_number_dp;
+    double dt_min_hydro = big_number_dp, dt_min_nbody = big_number_dp;
+    for (int i = 0; i < g.Nhydro; i++) {
+      Part &q = g.p[i];
+      if (q.flags & F_DEAD) continue;
+      const double dt = g.Timestep(q);
+      g.timestep = std::min(g.timestep, dt); dt_min_hydro = std::min(dt_min_hydro, dt);
+      q.dt_next = dt;
+    }
+    for (int i = 0; i < nb.N; i++) {
+      const double dt = StarTimestep(nb, nb.s[i]);
+      g.timestep = std::min(g.timestep, dt); dt_min_nbody = std::min(dt_min_nbody, dt);
+      nb.s[i].dt_next = dt;
+    }
+    g.level_max = P.Nlevels - 1;
+    g.level_step = g.level_max + g.integration_step - 1;
+    g.dt_max = g.timestep*pow(2.0, g.level_max);
+    int level_max_hydro = std::min(lvl(dt_min_hydro, g.dt_max), g.level_max);
+    for (int i = 0; i < nb.N; i++) {                                   // :1862-1873
+      Star &s = nb.s[i];
+      const int level = std::min(lvl(s.dt_next, g.dt_max), g.level_max);
+      s.level = std::max(level, level_max_hydro);
+      s.nlast = g.n; s.nstep = ipow2(g.level_step - s.level); s.tlast = g.t;
+      s.dt_next = s.nstep*g.timestep; s.end_timestep = true;
+    }
+    for (int i = 0; i < g.Nhydro; i++) {                               // sink neighbours, :1876-1887
+      Part &q = g.p[i];
+      if (q.sinkid != -1) {
+        const int sl = nb.s[g.sinks[q.sinkid].istar].level;
+        if (sl - q.level > P.level_diff_max) { q.level = sl - P.level_diff_max; q.levelneib = sl; level_max_hydro = std::max(level_max_hydro, q.level); }
+      }
+    }
+    for (int i = 0; i < g.Nhydro; i++) {
+      Part &q = g.p[i];
+      if (q.flags & F_DEAD) continue;
+      const int level = P.sph_single_timestep ? level_max_hydro : std::min(lvl(q.dt_next, g.dt_max), g.level_max);
+      q.level = level; q.levelneib = level;
+      q.nstep = ipow2(g.level_step - q.level);
+      q.nlast = g.n;
+      q.dt_next = q.nstep*g.timestep;
+      q.flags |= F_END;
+    }
+    g.nresync = ipow2(g.level_step);
+    g.timestep = g.dt_max/(double) g.nresync;
+    nb.timestep = g.timestep;
+    return;
+  }
+  const int level_max_old = g.level_max;
+  g.level_max = 0;
+  int level_max_hydro = 0;
+  const int n = g.n;
+  for (int i = 0; i < g.Nhydro; i++) {
+    Part &q = g.p[i];
+    if (q.flags & F_DEAD) continue;
+    if (n - q.nlast == q.nstep && q.nstep != ipow2(g.level_step - q.level)) {
+      const double dt = g.Timestep(q);
+      const int level = std::max(lvl(dt, g.dt_max), q.levelneib - P.level_diff_max);
+      q.level = std::max(q.level, level);
+      q.levelneib = q.level;
+      q.nlast = n; q.nstep = ipow2(g.level_step - q.level);
+      q.dt_next = q.nstep*g.timestep; q.flags |= F_END;
+    }
+    else if (n - q.nlast == q.nstep) {
+      const int nstep = q.nstep, last_level = q.level;
+      const double dt = g.Timestep(q);
+      const int level = std::max(lvl(dt, g.dt_max), q.levelneib - P.level_diff_max);
+      if (level < last_level && last_level > 1 && n%(2*nstep) == 0) q.level = last_level - 1;
+      else if (level > last_level) q.level = level;
+      else q.level = last_level;
+      q.levelneib = level;
+      q.nlast = n; q.nstep = ipow2(g.level_step - q.level);
+      q.dt_next = q.nstep*g.timestep; q.flags |= F_END;
+    }
+    level_max_hydro = std::max(level_max_hydro, q.level);
+    g.level_max = std::max(g.level_max, q.level);
+  }
+  for (int i = 0; i < nb.N; i++) {                                     // :2024-2060
+    Star &s = nb.s[i];
+    if (n - s.nlast == s.nstep) {
+      const int nstep = s.nstep, last_level = s.level;
+      const double dt = StarTimestep(nb, s);
+      const int level = std::max(lvl(dt, g.dt_max), level_max_hydro);
+      if (level < last_level && level > level_max_hydro && last_level > 1 && n%(2*nstep) == 0) s.level = last_level - 1;
+      else if (level > last_level) s.level = level;
+      else s.level = last_level;
+      s.nlast = n; s.nstep = ipow2(g.level_step - s.level); s.tlast = g.t;
+      s.dt_next = s.nstep*g.timestep; s.end_timestep = true;
+    }
+    g.level_max = std::max(g.level_max, s.level);
+  }
+  if (P.sph_single_timestep) for (int i = 0; i < g.Nhydro; i++) if (!(g.p[i].flags & F_DEAD) && g.p[i].nlast == g.n) g.p[i].level = level_max_hydro;
+  const int istep = ipow2(g.level_step - level_max_old + 1);
+  if (g.level_max > level_max_old) {
+    const int nfactor = ipow2(g.level_max - level_max_old);
+    g.n *= nfactor;
+    for (int i = 0; i < g.Nhydro; i++) { if (g.p[i].flags & F_DEAD) continue; g.p[i].nstep *= nfactor; g.p[i].nlast *= nfactor; }
+    for (int i = 0; i < nb.N; i++) { nb.s[i].nstep *= nfactor; nb.s[i].nlast *= nfactor; }
+  }
+  else if (g.level_max <= level_max_old - 1 && level_max_old > 1 && g.n%istep == 0) {
+    g.level_max = level_max_old - 1;
+    const int nfactor = ipow2(level_max_old - g.level_max);
+    g.n /= nfactor;
+    for (int i = 0; i < g.Nhydro; i++) { if (g.p[i].flags & F_DEAD) continue; g.p[i].nlast /= nfactor; g.p[i].nstep /= nfactor; }
+    for (int i = 0; i < nb.N; i++) { nb.s[i].nlast /= nfactor; nb.s[i].nstep /= nfactor; }
+  }
+  else g.level_max = level_max_old;
+  g.level_step = g.level_max + g.integration_step - 1;
+  g.nresync = ipow2(g.level_step);
+  g.timestep = g.dt_max/(double) g.nresync;
+  nb.timestep = g.timestep;
+  for (int i = 0; i < g.Nhydro; i++) if (!(g.p[i].flags & F_DEAD) && g.p[i].nlast == g.n) g.p[i].nstep = ipow2(g.level_step - g.p[i].level);
+  for (int i = 0; i < nb.N; i++) if (nb.s[i].nlast == g.n) nb.s[i].nstep = ipow2(g.level_step - nb.s[i].level);
+}
+
 // the sink part of MainLoop, SphSimulation.cpp:820-838 (ntreebuildstep = 1: the search runs on every step)
 static void SinkStep(Oracle &g, NbodyOracle &nb)
 {
@@ -2187,8 +2316,23 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   g.stars.resize(nb.N);
   g.star_softening = nb.softening;
   for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].r[k] = nb.s[i].r[k]; g.stars[i].m = nb.s[i].m; g.stars[i].h = nb.s[i].h; }
-  g.StepTree(); g.DensityPass();
-  g.ZeroAccelerations(); g.Forces();
+  if (g.P.Nlevels > 1) {                                             // block timesteps: SphSimulation.cpp:654-755
+    g.StepTree(); g.SearchBoundaryGhostParticles(); g.BuildGhostTree();
+    int activecount = 0;
+    do {
+      if (activecount > 0) g.UpdateActiveParticleCounters();
+      g.UpdateAllSphProperties();
+      g.ZeroAccelerations();
+      for (int i = 0; i < g.Nhydro; i++) g.Thermal(g.p[i]);
+      g.Forces();
+      for (int i = 0; i < g.Nhydro; i++) g.p[i].flags &= ~F_ACTIVE;
+      activecount = g.CheckTimesteps();
+    } while (activecount > 0);
+  }
+  else {
+    g.StepTree(); g.DensityPass();
+    g.ZeroAccelerations(); g.Forces();
+  }
   nb.Zero();                                                         // :773-784
   for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) g.stars[i].a[k] = 0.0; g.stars[i].gpot = 0.0; }
   g.UpdateAllStarGasForces();                                        // :787
@@ -2196,6 +2340,13 @@ static void HybridMainLoop(Oracle &g, NbodyOracle &nb)
   nb.Forces();                                                       // :794-799 (adds the star-star sums)
   nb.Correct(g.n);                                                   // :811
   SinkStep(g, nb);                                                   // :820-838
+  if (g.P.Nlevels > 1) {
+    ComputeBlockTimestepsHybrid(g, nb);
+    g.EndTimestep();
+    nb.EndTimestep(g.n);
+    g.rebuild_tree = false;
+    return;
+  }
   g.ComputeGlobalTimestep();                                         // minimum over gas and stars
   nb.GlobalTimestep();
   const double ts = std::min(g.timestep, (double) nb.timestep);
@@ -2224,6 +2375,12 @@ static void HybridSetup(Oracle &g, NbodyOracle &nb, int h_provided)
   g.UpdateAllStarGasForces();
   for (int i = 0; i < nb.N; i++) { for (int k = 0; k < 3; k++) nb.s[i].a[k] = g.stars[i].a[k]; nb.s[i].gpot = g.stars[i].gpot; }
   nb.Forces();
+  if (g.P.Nlevels > 1) {
+    ComputeBlockTimestepsHybrid(g, nb);
+    g.EndTimestep();
+    nb.EndTimestep(g.n);
+    return;
+  }
   g.ComputeGlobalTimestep();
   nb.GlobalTimestep();
   const double ts = std::min(g.timestep, (double) nb.timestep);

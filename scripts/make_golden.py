@@ -132,7 +132,7 @@ def sinks(name, nsteps=12):
         setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
         final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
         out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"], "nsteps": np.array([nsteps], dtype=np.int32)}
-        for k in STEP_OUT + SINK_PART:
+        for k in STEP_OUT + SINK_PART + ["level", "levelneib", "nstep", "nlast", "levelmax_levelstep_Nlevels_diffmax", "dt_max"]:
             out["setup_" + k] = setup[k]
             out["final_" + k] = final[k]
         out["final_Nhydro"] = final["Nhydro"]
@@ -229,12 +229,13 @@ if __name__ == "__main__":
             long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
         elif cfg.endswith("_fromfile"):
             fromfile(cfg)
+        elif "_sinks" in cfg:
+            sinks(cfg, 40 if cfg.endswith("_levels") else 12)
         elif cfg.endswith("_levels") or cfg.endswith("_levels_single"):
             levels(cfg)
         elif cfg == "treeerror":
             treeerror()
-        elif "_sinks" in cfg:
-            sinks(cfg)
+
         elif cfg == "nbody":
             nbody(256, 0)
             nbody(256, 1)

@@ -234,11 +234,14 @@ def run_sink_case(case, make_gas, make_stars):
     return g, p, gas, stars
 
 
-def test_sinks_bitwise():
+@pytest.mark.parametrize("case", ["bb_sinks_8k", "bb_sinks_8k_levels"])
+def test_sinks_bitwise(case):
     """Boss-Bodenheimer cloud with sink creation and smooth accretion (Sinks.cpp:118-777; potmin flag with the reference's
     stale-distance quirk and the rho_sink floor of h, GradhSph.cpp:163-169, 270-280; DeleteDeadParticles,
     Hydrodynamics.h:158-202): setup + 12 MainLoop calls, in which two sinks form on the first step, each accretes on every
-    step and 24 dead particles are deleted - gas, stars and SinkParticle records bit for bit"""
+    step and 24 dead particles are deleted - gas, stars and SinkParticle records bit for bit.  `_levels`: the same cloud on the
+    block-timestep ladder (Nlevels = 5 as in the reference's bossbodenheimer.dat; the star branches of
+    Simulation::ComputeBlockTimesteps, Simulation.cpp:1820-1873, 2024-2060): 40 steps, a sixth level opens, 80 deletions"""
     from oracle.pyoracle import NbodyOracle
 
     def make_gas(p, r, m, h, v, u):
@@ -250,7 +253,7 @@ def test_sinks_bitwise():
         e = np.zeros(0)
         return NbodyOracle(e.reshape(0, 3), e.reshape(0, 3), e, e, int(p["nbody_softening"]), float(p["nbody_mult"]))
 
-    g, p, o, nb = run_sink_case("bb_sinks_8k", make_gas, make_stars)
+    g, p, o, nb = run_sink_case(case, make_gas, make_stars)
     nb.hybrid_setup(o, h_provided=True)
     assert o.timestep == g["setup_t_timestep"][1]
     for k in ["h", "rho", "a", "gpot", "dt"]:
@@ -261,9 +264,13 @@ def test_sinks_bitwise():
     assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
     for k in ["r", "v", "a", "h", "rho", "u", "m", "gpot", "dt", "invomega", "zeta"]:
         assert np.array_equal(o.get(k), g["final_" + k]), k
-    for k in ["flags", "sinkid", "iorig"]:
+    for k in ["flags", "sinkid", "iorig"] + (["level", "levelneib", "nstep", "nlast"] if case.endswith("_levels") else []):
         assert np.array_equal(o.get_int(k), g["final_" + k]), k
-    assert (g["final_flags"] & 1).sum() > 0 and (g["final_sinkid"] >= 0).sum() > 50      # the fixture has dead and in-sink particles
+    if case.endswith("_levels"):
+        clock, dt_max = o.get_block()
+        assert clock[0] == g["final_n_Nsteps_nresync"][0] and clock[1] == g["final_n_Nsteps_nresync"][2]
+        assert clock[2:] == list(g["final_levelmax_levelstep_Nlevels_diffmax"][:2]) and dt_max == g["final_dt_max"][0]
+    assert (g["final_sinkid"] >= 0).sum() > 50      # the fixture has dead and in-sink particles
     sk = o.sinks()
     assert len(sk["radius"]) == int(g["final_Nsink"][0]) == 2
     for k in ["radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc", "angmom", "Ngas", "istar"]:
