@@ -156,8 +156,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (cfg->kernel < GH_KERNEL_M4 || cfg->kernel > GH_KERNEL_QUINTIC_TAB)
     return gh_fail(ctx, GH_ERR_UNSUPPORTED, "kernels built: m4, quintic, each with tabulated_kernel = 0 or 1");
   if (cfg->Nleafmax < 1 || cfg->Nleafmax > 32) return gh_fail(ctx, GH_ERR_INVALID, "Nleafmax out of range");
-  if (cfg->sink_particles && (cfg->Nlevels > 1 || cfg->ntreebuildstep > 1 || !cfg->self_gravity || cfg->ndim != 3))
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "sink runs: 3-D, self_gravity = 1, global timestep (Nlevels = 1), tree rebuilt every step (ntreebuildstep = 1)");
+  if (cfg->sink_particles && (cfg->ntreebuildstep > 1 || !cfg->self_gravity || cfg->ndim != 3 || (cfg->Nlevels > 1 && cfg->sph_single_timestep)))
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "sink runs: 3-D, self_gravity = 1, tree rebuilt every step (ntreebuildstep = 1), no sph_single_timestep");
   if (cfg->sink_particles && !(cfg->rho_sink > 0.0)) return gh_fail(ctx, GH_ERR_INVALID, "sink_particles = 1 needs rho_sink > 0");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -715,15 +715,11 @@ extern "C" int gh_set_time(gh_ctx *ctx, double t, double timestep)
 // one MainLoop call with hierarchical block timesteps (SphSimulation.cpp:574-880, Nlevels > 1): only the particles at
 // the end of their own step are active (density, forces, kick); neighbours on longer steps are drifted (r, v, u) and
 // their pressure / sound refreshed; CheckTimesteps may wake neighbours of fast particles, which repeats the passes
-static int block_step(gh_ctx *ctx)
+// the tree and the density / force passes of a block-timestep step, repeated while CheckTimesteps wakes particles
+// (SphSimulation.cpp:634-755); synchronises
+int gh_block_gas_passes(gh_ctx *ctx)
 {
   int rc;
-  hipLaunchKernelGGL(k_block_tick, dim3(1), dim3(1), 0, ctx->stream, ctx->d_blk);   // n = n + 1 (:585)
-  ctx->n++; ctx->Nsteps++;
-  gh_advance_time_impl(ctx);
-  gh_phase_begin(ctx, GH_T_KDK);
-  gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // all particles drift; active = end of own step
-  gh_phase_end(ctx, GH_T_KDK);
   if ((rc = step_tree_timed(ctx))) return rc;
   for (int pass = 0; ; pass++) {
     if (pass > 0) gh_leaf_active_counters(ctx);          // "if (activecount > 0) UpdateActiveParticleCounters" (:663)
@@ -738,6 +734,29 @@ static int block_step(gh_ctx *ctx)
     if (blk[5] == 0) break;
     GH_CHECK(ctx, hipMemsetAsync(ctx->d_blk + 5, 0, sizeof(int), ctx->stream));
   }
+  return GH_OK;
+}
+// n = n + 1, t = t + timestep, drift (the start of MainLoop, :585-600)
+int gh_block_begin_step(gh_ctx *ctx)
+{
+  hipLaunchKernelGGL(k_block_tick, dim3(1), dim3(1), 0, ctx->stream, ctx->d_blk);   // n = n + 1 (:585)
+  ctx->n++; ctx->Nsteps++;
+  gh_advance_time_impl(ctx);
+  gh_phase_begin(ctx, GH_T_KDK);
+  gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // all particles drift; active = end of own step
+  gh_phase_end(ctx, GH_T_KDK);
+  return GH_OK;
+}
+int gh_block_pull(gh_ctx *ctx) { return pull_block(ctx); }
+
+// one MainLoop call with hierarchical block timesteps (SphSimulation.cpp:574-880, Nlevels > 1): only the particles at
+// the end of their own step are active (density, forces, kick); neighbours on longer steps are drifted (r, v, u) and
+// their pressure / sound refreshed; CheckTimesteps may wake neighbours of fast particles, which repeats the passes
+static int block_step(gh_ctx *ctx)
+{
+  int rc;
+  gh_block_begin_step(ctx);
+  if ((rc = gh_block_gas_passes(ctx))) return rc;
   gh_phase_begin(ctx, GH_T_KDK);
   gh_block_timesteps_impl(ctx);                          // ComputeBlockTimesteps (:842)
   gh_kdk_end_impl(ctx, 0, 0.0, 0.0);                     // EndTimestep of the particles that finished their step

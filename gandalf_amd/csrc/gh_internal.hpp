@@ -91,8 +91,10 @@ struct DevicePtrs {                // everything a kernel needs, passed by value
 struct gh_host_stars {
   size_t n = 0;
   std::vector<double> r, v, a, adot, r0, v0, a0, m, h, gpot, tlast, dti;
+  std::vector<int> level, nstep, nlast, endflag;      // block-timestep ladder (global timestep: 0, 1, 0)
   void resize(size_t k) {
     n = k;
+    level.resize(k, 0); nstep.resize(k, 1); nlast.resize(k, 0); endflag.resize(k, 0);
     std::vector<double> *v3[] = {&r, &v, &a, &adot, &r0, &v0, &a0};
     for (auto *q : v3) q->resize(3*k, 0.0);
     std::vector<double> *v1[] = {&m, &h, &gpot, &tlast, &dti};
@@ -276,6 +278,10 @@ int gh_cullen_dehnen_impl(gh_ctx *ctx);               // cd2010.hip: alpha, dalp
 int gh_thermal_all_impl(gh_ctx *ctx);
 int gh_block_timesteps_impl(gh_ctx *ctx);
 int gh_check_timesteps_impl(gh_ctx *ctx);
+int gh_block_gas_passes(gh_ctx *ctx);       // api.hip: tree + density / force passes of a block-timestep step
+int gh_block_begin_step(gh_ctx *ctx);       // api.hip: n++, t += timestep, drift
+int gh_block_pull(gh_ctx *ctx);             // api.hip: device block clock -> ctx->n, nresync, level_max, level_step, dt_max
+int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult);   // ComputeBlockTimesteps with the stars of a sink run
 // phase timing with HIP events on ctx->stream; read back by gh_sync_collect
 int gh_phase_begin(gh_ctx *ctx, int phase);
 int gh_phase_end(gh_ctx *ctx, int phase);

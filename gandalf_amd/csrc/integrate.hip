@@ -95,6 +95,7 @@ __global__ void k_timestep_partial(DevicePtrs d, TimestepParams tp, double *part
   __shared__ double s[256];
   double dtmin = 9.9e50;                                   // big_number_dp
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
+    if (d.levels && d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD)) continue;      // Simulation.cpp:1811 (the global-timestep loop, :1696, has no such skip)
     const double ts = particle_timestep(d, tp, i);
     if (d.levels) d.f[D_DT_NEXT][i] = ts;                  // resynchronisation of the block structure, Simulation.cpp:1816
     dtmin = fmin(dtmin, ts);
@@ -219,7 +220,7 @@ int gh_kdk_end_impl(gh_ctx *ctx, int, double, double)
 // nstep = 0 and therefore dt_next = 0 until the next pass refreshes nstep, Simulation.cpp:1989-1990 with :2141-2146)
 __device__ __forceinline__ int ipow2(int e) { return e >= 0 ? (1 << e) : 0; }
 
-enum { B_N = 0, B_NRESYNC, B_LMAX, B_LSTEP, B_LMAXNEW, B_ACTIVE, B_MUL, B_DIV, B_CNT0, B_CNT1, B_LMH };   // B_CNT*: 64-bit active counter
+enum { B_N = 0, B_NRESYNC, B_LMAX, B_LSTEP, B_LMAXNEW, B_ACTIVE, B_MUL, B_DIV, B_CNT0, B_CNT1, B_LMH, B_LMSTAR /* highest star level (sink runs) */ };   // B_CNT*: 64-bit active counter
 
 // ComputeTimestepLevel, InlineFuncs.h:550-558
 __device__ __forceinline__ int timestep_level(double dt, double dt_max)
@@ -251,6 +252,7 @@ __global__ void k_block_resync_assign(DevicePtrs d, const int *blk, const double
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
+  if (d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD)) return;
   const int level_max = blk[B_LMAX], level_step = blk[B_LSTEP];
   int level = timestep_level(d.f[D_DT_NEXT][i], time[2]);
   level = level < level_max ? level : level_max;
@@ -272,7 +274,7 @@ __global__ void k_block_levels(DevicePtrs d, TimestepParams tp, int *blk, const 
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   int mylevel = 0;
-  if (i < d.N) {
+  if (i < d.N && !(d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD))) {
     const int n = blk[B_N], level_step = blk[B_LSTEP];
     const int nlast = (int) d.f[D_NLAST][i], nstep = (int) d.f[D_NSTEP][i];
     int level_i = (int) d.f[D_LEVEL][i];
@@ -308,7 +310,8 @@ __global__ void k_block_levels(DevicePtrs d, TimestepParams tp, int *blk, const 
 __global__ void k_block_clock(int *blk, double *time)
 {
   const int level_max_old = blk[B_LMAX], level_step_old = blk[B_LSTEP];
-  int level_max = blk[B_LMAXNEW], n = blk[B_N];
+  int level_max = max(blk[B_LMAXNEW], blk[B_LMSTAR]), n = blk[B_N];      // over gas and stars (:2058, 2068)
+  blk[B_LMSTAR] = 0;
   const int istep = 1 << (level_step_old - level_max_old + 1);
   int mul = 1, div = 1;
   if (level_max > level_max_old) { mul = 1 << (level_max - level_max_old); n *= mul; }
@@ -324,6 +327,7 @@ __global__ void k_block_rescale(DevicePtrs d, const int *blk, int single)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   if (i >= d.N) return;
+  if (d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD)) return;
   const int mul = blk[B_MUL], div = blk[B_DIV];
   int nstep = (int) d.f[D_NSTEP][i], nlast = (int) d.f[D_NLAST][i];
   nstep = nstep*mul/div; nlast = nlast*mul/div;
@@ -339,7 +343,7 @@ __global__ void k_check_timesteps(DevicePtrs d, int *blk, int level_diff_max)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
   int woke = 0;
-  if (i < d.N) {
+  if (i < d.N && !(d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD))) {      // SphLeapfrogKDK.cpp:307
     int fl = (int) d.f[D_FLAGS][i] & ~1;
     const int dn = blk[B_N] - (int) d.f[D_NLAST][i];
     const int level = (int) d.f[D_LEVEL][i], levelneib = (int) d.f[D_LEVELNEIB][i];
@@ -393,6 +397,79 @@ int gh_block_timesteps_impl(gh_ctx *ctx)
     hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
     hipLaunchKernelGGL(k_block_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
     hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, ctx->cfg.sph_single_timestep);
+  }
+  return GH_OK;
+}
+
+// Simulation::ComputeBlockTimesteps of a sink run: the gas as above, the stars (a handful, host mirror S) with the star
+// branches of the reference (Simulation.cpp:1820-1873, 2024-2060, 2111-2150) - they sit on levels >= the highest gas level
+static inline int host_timestep_level(double dt, double dt_max) { const int l = (int) (1.44269504088896*log(dt_max/dt)) + 1; return l > 0 ? l : 0; }
+static inline int host_ipow2(int e) { return (int) pow(2.0, e); }
+int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult)
+{
+  hipStream_t s = ctx->stream;
+  const int nb = cdiv(ctx->own_count, 256);
+  DevicePtrs d = gh_dev_own(ctx);
+  double *time = gh_time_dev(ctx);
+  const int ns = (int) S.n;
+  auto star_dt = [&](int i) {                               // NbodyLeapfrogKDK::Timestep, :387-400
+    const double amag = sqrt(S.a[3*i]*S.a[3*i] + S.a[3*i + 1]*S.a[3*i + 1] + S.a[3*i + 2]*S.a[3*i + 2]);
+    return std::min(nbody_mult*sqrt(S.h[i]/(amag + GH_SMALL_DP)), S.dti[i]);
+  };
+  double tt[3];
+  int blk[12];
+  if (ctx->n == ctx->nresync) {
+    const int nblk = 256;
+    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, s, d, fill_tp(ctx), ctx->redbuf);
+    hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
+    GH_CHECK(ctx, hipMemcpyAsync(tt, time, sizeof(tt), hipMemcpyDeviceToHost, s));
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    const double dt_min_hydro = tt[1];
+    double timestep = dt_min_hydro;
+    std::vector<double> sdt((size_t) ns);
+    for (int i = 0; i < ns; i++) { sdt[i] = star_dt(i); timestep = std::min(timestep, sdt[i]); }
+    GH_CHECK(ctx, hipMemcpyAsync(time + 1, &timestep, sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_block_resync_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time, ctx->cfg.Nlevels);
+    const int level_max = ctx->cfg.Nlevels - 1, level_step = level_max;
+    const double dt_max = timestep*pow(2.0, level_max);
+    const int lmh = std::min(host_timestep_level(dt_min_hydro, dt_max), level_max);
+    GH_CHECK(ctx, hipMemcpyAsync(ctx->d_blk + B_LMH, &lmh, sizeof(int), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < ns; i++) {
+      const int level = std::min(host_timestep_level(sdt[i], dt_max), level_max);
+      S.level[i] = std::max(level, lmh);
+      S.nlast[i] = 0; S.nstep[i] = host_ipow2(level_step - S.level[i]); S.tlast[i] = tt[0]; S.endflag[i] = 1;
+    }
+    hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time, ctx->cfg.sph_single_timestep);
+    hipLaunchKernelGGL(k_block_resync_finish, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
+    GH_CHECK(ctx, hipStreamSynchronize(s));                  // timestep / lmh live on this stack
+    return GH_OK;
+  }
+  hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
+  GH_CHECK(ctx, hipMemcpyAsync(blk, ctx->d_blk, sizeof(blk), hipMemcpyDeviceToHost, s));
+  GH_CHECK(ctx, hipMemcpyAsync(tt, time, sizeof(tt), hipMemcpyDeviceToHost, s));
+  GH_CHECK(ctx, hipStreamSynchronize(s));
+  const int n = blk[B_N], level_step_old = blk[B_LSTEP], lmh = blk[B_LMAXNEW];
+  const double dt_max = tt[2];
+  int lmstar = 0;
+  for (int i = 0; i < ns; i++) {
+    if (n - S.nlast[i] == S.nstep[i]) {
+      const int nstep = S.nstep[i], last_level = S.level[i];
+      const int level = std::max(host_timestep_level(star_dt(i), dt_max), lmh);
+      if (level < last_level && level > lmh && last_level > 1 && n%(2*nstep) == 0) S.level[i] = last_level - 1;
+      else if (level > last_level) S.level[i] = level;
+      S.nlast[i] = n; S.nstep[i] = host_ipow2(level_step_old - S.level[i]); S.tlast[i] = tt[0]; S.endflag[i] = 1;
+    }
+    lmstar = std::max(lmstar, S.level[i]);
+  }
+  GH_CHECK(ctx, hipMemcpyAsync(ctx->d_blk + B_LMSTAR, &lmstar, sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_block_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
+  hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, ctx->cfg.sph_single_timestep);
+  GH_CHECK(ctx, hipMemcpyAsync(blk, ctx->d_blk, sizeof(blk), hipMemcpyDeviceToHost, s));
+  GH_CHECK(ctx, hipStreamSynchronize(s));
+  const int mul = blk[B_MUL], div = blk[B_DIV];
+  for (int i = 0; i < ns; i++) {
+    S.nstep[i] = S.nstep[i]*mul/div; S.nlast[i] = S.nlast[i]*mul/div;
+    if (S.nlast[i] == blk[B_N]) S.nstep[i] = host_ipow2(blk[B_LSTEP] - S.level[i]);
   }
   return GH_OK;
 }

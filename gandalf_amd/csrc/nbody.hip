@@ -27,6 +27,9 @@ struct gh_nbody {
   // SoA, component-major: r[k*N + i]
   double *r = nullptr, *v = nullptr, *a = nullptr, *adot = nullptr, *r0 = nullptr, *v0 = nullptr, *a0 = nullptr;
   double *m = nullptr, *h = nullptr, *gpot = nullptr, *tlast = nullptr;
+  bool act_on = false;
+  int *act = nullptr;               // sink runs on the block-timestep ladder: 1 = the star ends its step now (NbodyParticle active flag); nullptr = all
+  std::vector<int> h_level, h_nstep, h_nlast;   // ... and the stars' level / nstep / nlast (host: a handful of stars)
   double *dti = nullptr;            // dt_internal (Sinks.cpp:735: an accreting sink limits its own timestep), else big_number
   double *tdt = nullptr;            // device {t, timestep, scratch min}
   double *red = nullptr;            // block minima
@@ -36,11 +39,11 @@ struct gh_nbody {
 
 #define NB_CHECK(nb, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (nb)->err = std::string(#call) + ": " + hipGetErrorString(e__); return GH_ERR_HIP; } } while (0)
 
-struct NbPtrs { double *r, *v, *a, *adot, *r0, *v0, *a0, *m, *h, *gpot, *tlast, *tdt, *dti; int N, ndim; };
+struct NbPtrs { double *r, *v, *a, *adot, *r0, *v0, *a0, *m, *h, *gpot, *tlast, *tdt, *dti; const int *act; int N, ndim; };
 
 static NbPtrs nb_ptrs(gh_nbody *nb)
 {
-  NbPtrs p = {nb->r, nb->v, nb->a, nb->adot, nb->r0, nb->v0, nb->a0, nb->m, nb->h, nb->gpot, nb->tlast, nb->tdt, nb->dti, (int) nb->N, nb->ndim};
+  NbPtrs p = {nb->r, nb->v, nb->a, nb->adot, nb->r0, nb->v0, nb->a0, nb->m, nb->h, nb->gpot, nb->tlast, nb->tdt, nb->dti, nb->act_on ? nb->act : nullptr, (int) nb->N, nb->ndim};
   return p;
 }
 
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void k_nbody_forces(NbPtrs p)
   for (int k = 0; k < 3; k++) { s_acc[wave][k][lane] = a[k]; s_acc[wave][3 + k][lane] = ad[k]; }
   s_acc[wave][6][lane] = gp;
   __syncthreads();
-  if (wave == 0 && live) {
+  if (wave == 0 && live && (!p.act || p.act[i])) {
     for (int k = 0; k < ND; k++) {
       p.a[(size_t) k*p.N + i] = ((s_acc[0][k][lane] + s_acc[1][k][lane]) + s_acc[2][k][lane]) + s_acc[3][k][lane];
       p.adot[(size_t) k*p.N + i] = ((s_acc[0][3 + k][lane] + s_acc[1][3 + k][lane]) + s_acc[2][3 + k][lane]) + s_acc[3][3 + k][lane];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_nbody_correct_dt(NbPtrs p, double nbody
     for (int k = 0; k < p.ndim; k++) {
       const size_t o = (size_t) k*p.N + i;
       const double ak = p.a[o];
-      if (correct) p.v[o] += 0.5*(ak - p.a0[o])*(p.tdt[0] - p.tlast[i]);
+      if (correct && (!p.act || p.act[i])) p.v[o] += 0.5*(ak - p.a0[o])*(p.tdt[0] - p.tlast[i]);
       amag2 += ak*ak;
     }
     const double amag = sqrt(amag2);
@@ -196,6 +199,8 @@ static void nb_free(gh_nbody *nb)
 {
   double **ptrs[] = {&nb->r, &nb->v, &nb->a, &nb->adot, &nb->r0, &nb->v0, &nb->a0, &nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->dti, &nb->red, &nb->stage};
   for (double **q : ptrs) { if (*q) (void) hipFree(*q); *q = nullptr; }
+  if (nb->act) (void) hipFree(nb->act);
+  nb->act = nullptr;
   nb->Ncap = 0;
 }
 
@@ -211,6 +216,7 @@ static int nb_reserve(gh_nbody *nb, int64_t N)
   double **sca[] = {&nb->m, &nb->h, &nb->gpot, &nb->tlast, &nb->dti};
   for (double **q : sca) NB_CHECK(nb, hipMalloc((void**) q, sizeof(double)*cap));
   NB_CHECK(nb, hipMalloc((void**) &nb->red, sizeof(double)*((cap + 255)/256 + 1)));
+  NB_CHECK(nb, hipMalloc((void**) &nb->act, sizeof(int)*cap));
   nb->Ncap = cap;
   return GH_OK;
 }
@@ -388,7 +394,7 @@ int gh_timestep_impl_extra(gh_ctx *ctx, int nextra);         // integrate.hip: g
 __global__ void k_nbody_add_gas(NbPtrs p, const double *ga, const double *gg)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= p.N) return;
+  if (i >= p.N || (p.act && !p.act[i])) return;
   for (int k = 0; k < p.ndim; k++) p.a[(size_t) k*p.N + i] += ga[(size_t) i*p.ndim + k];
   p.gpot[i] += gg[i];
 }
@@ -518,6 +524,8 @@ static int nb_pull(gh_nbody *nb, gh_host_stars &S)
 {
   const size_t N = (size_t) nb->N;
   S.resize(N);
+  nb->h_level.resize(N, 0); nb->h_nstep.resize(N, 1); nb->h_nlast.resize(N, 0);
+  S.level = nb->h_level; S.nstep = nb->h_nstep; S.nlast = nb->h_nlast;
   if (N == 0) return GH_OK;
   NB_CHECK(nb, hipStreamSynchronize(nb->stream));
   std::vector<double> t(3*N);
@@ -538,6 +546,7 @@ static int nb_push(gh_nbody *nb, const gh_host_stars &S)
   int rc = nb_reserve(nb, (int64_t) N);
   if (rc) return rc;
   nb->N = (int64_t) N;
+  nb->h_level = S.level; nb->h_nstep = S.nstep; nb->h_nlast = S.nlast;
   if (N == 0) return GH_OK;
   std::vector<double> t(3*N);
   struct { double *dst; const std::vector<double> *src; } v3[] = {{nb->r, &S.r}, {nb->v, &S.v}, {nb->a, &S.a}, {nb->adot, &S.adot}, {nb->r0, &S.r0}, {nb->v0, &S.v0}, {nb->a0, &S.a0}};
@@ -612,19 +621,48 @@ static int sink_finish_step(gh_ctx *gas, gh_nbody *nb, double star_min, const ch
   return GH_OK;
 }
 
-// one MainLoop call of a sink run (SphSimulation.cpp:574-880, global timestep)
+// EndTimestep of the stars that ended their step (NbodyLeapfrogKDK.cpp:341-377), on the host mirror
+static void sink_star_end_host(gh_host_stars &S, int n, double t)
+{
+  for (size_t i = 0; i < S.n; i++) {
+    if (!S.endflag[i]) continue;
+    for (int k = 0; k < 3; k++) { S.r0[3*i + k] = S.r[3*i + k]; S.v0[3*i + k] = S.v[3*i + k]; S.a0[3*i + k] = S.a[3*i + k]; }
+    S.nlast[i] = n; S.tlast[i] = t; S.endflag[i] = 0;
+  }
+}
+
+// which stars end their step now (NbodyLeapfrogKDK::AdvanceParticles, :284: active if n - nlast == nstep)
+static int sink_star_active(gh_ctx *gas, gh_nbody *nb)
+{
+  const size_t Ns = (size_t) nb->N;
+  nb->act_on = gas->cfg.Nlevels > 1;
+  if (!nb->act_on || Ns == 0) return GH_OK;
+  std::vector<int> act(Ns);
+  for (size_t i = 0; i < Ns; i++) act[i] = (gas->n - nb->h_nlast[i] == nb->h_nstep[i]) ? 1 : 0;
+  NB_CHECK(nb, hipMemcpy(nb->act, act.data(), sizeof(int)*Ns, hipMemcpyHostToDevice));
+  return GH_OK;
+}
+
+// one MainLoop call of a sink run (SphSimulation.cpp:574-880)
 static int sink_hybrid_step(gh_ctx *gas, gh_nbody *nb)
 {
   int rc;
+  const bool levels = gas->cfg.Nlevels > 1;
   double td[2] = {gas->t, gas->timestep};
   NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
-  gas->n++; gas->Nsteps++;
-  gh_advance_time_impl(gas);
-  gh_kdk_advance_impl(gas, gas->n, 0.0, 0.0);
+  if (levels) gh_block_begin_step(gas);
+  else {
+    gas->n++; gas->Nsteps++;
+    gh_advance_time_impl(gas);
+    gh_kdk_advance_impl(gas, gas->n, 0.0, 0.0);
+  }
+  if ((rc = sink_star_active(gas, nb))) return rc;
   if (nb->N > 0) hipLaunchKernelGGL(k_nbody_advance, dim3((unsigned) ((nb->N + 255)/256)), dim3(256), 0, nb->stream, nb_ptrs(nb), 0);
   hipLaunchKernelGGL(k_nbody_clock, dim3(1), dim3(1), 0, nb->stream, nb_ptrs(nb));
   if ((rc = sink_stars_to_gas(gas, nb))) return rc;
-  if ((rc = gh_hybrid_gas_passes(gas))) return rc;          // dead particles out, tree, density (+ zeta, potmin), forces (+ gas <- stars)
+  // dead particles out, tree, density (+ zeta, potmin), forces (+ gas <- stars); block timesteps: repeated while CheckTimesteps wakes particles
+  if (levels) { if ((rc = gh_block_gas_passes(gas))) return rc; }
+  else if ((rc = gh_hybrid_gas_passes(gas))) return rc;
   if ((rc = sink_star_forces(gas, nb))) return rc;
   if (nb->N > 0)                                             // CorrectionTerms (its timestep output is redone below)
     hipLaunchKernelGGL(k_nbody_correct_dt, dim3((unsigned) ((nb->N + 255)/256)), dim3(256), 0, nb->stream, nb_ptrs(nb), nb->nbody_mult, nb->red, 1);
@@ -635,6 +673,20 @@ static int sink_hybrid_step(gh_ctx *gas, gh_nbody *nb)
   gh_host_stars S;
   if ((rc = nb_pull(nb, S))) return rc;
   if ((rc = gh_sinks_step(gas, S, tt[0], tt[1]))) return rc;
+  if (levels) {
+    // ComputeBlockTimesteps over gas and stars, EndTimestep of both (:842, 868-872)
+    if ((rc = gh_block_timesteps_hybrid(gas, S, nb->nbody_mult))) return rc;
+    gh_kdk_end_impl(gas, 0, 0.0, 0.0);
+    if ((rc = gh_sync_collect(gas, "gh_hybrid_step/sinks"))) return rc;
+    gas->rebuild_tree = false;
+    if ((rc = gh_block_pull(gas))) return rc;
+    GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+    gas->t = tt[0]; gas->timestep = tt[1];
+    sink_star_end_host(S, gas->n, tt[0]);
+    if ((rc = nb_push(nb, S))) return rc;
+    NB_CHECK(nb, hipMemcpy(nb->tdt, tt, sizeof(tt), hipMemcpyHostToDevice));
+    return GH_OK;
+  }
   if ((rc = nb_push(nb, S))) return rc;
   double star_min;
   if ((rc = sink_star_end(nb, &star_min))) return rc;
@@ -656,12 +708,31 @@ static int sink_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided)
   if ((rc = gh_setup_passes(gas, initial_h_provided))) return rc;
   double td[2] = {gas->t, 0.0};
   NB_CHECK(nb, hipMemcpy(nb->tdt, td, sizeof(td), hipMemcpyHostToDevice));
+  nb->act_on = false;                                        // every star takes part in the setup
   if ((rc = sink_star_forces(gas, nb))) return rc;
-  double star_min;
-  if ((rc = sink_star_end(nb, &star_min))) return rc;
   gas->timestep = 0.0; gas->n = 0;
   double tt0[2] = {gas->t, 0.0};
   GH_CHECK(gas, hipMemcpyAsync(gh_time_dev(gas), tt0, sizeof(tt0), hipMemcpyHostToDevice, gas->stream));
+  if (gas->cfg.Nlevels > 1) {
+    gas->nresync = 0;
+    const int blk[8] = {0, 0, 0, 0, 0, 0, 1, 1};
+    GH_CHECK(gas, hipMemcpyAsync(gas->d_blk, blk, sizeof(blk), hipMemcpyHostToDevice, gas->stream));
+    gh_host_stars S;
+    if ((rc = nb_pull(nb, S))) return rc;
+    if ((rc = gh_block_timesteps_hybrid(gas, S, nb->nbody_mult))) return rc;      // n == nresync == 0: resynchronise (:539)
+    gh_kdk_end_impl(gas, 0, 0.0, 0.0);
+    if ((rc = gh_sync_collect(gas, "gh_hybrid_setup/sinks"))) return rc;
+    if ((rc = gh_block_pull(gas))) return rc;
+    double tt[2];
+    GH_CHECK(gas, hipMemcpy(tt, gh_time_dev(gas), sizeof(tt), hipMemcpyDeviceToHost));
+    gas->t = tt[0]; gas->timestep = tt[1];
+    sink_star_end_host(S, gas->n, tt[0]);
+    if ((rc = nb_push(nb, S))) return rc;
+    NB_CHECK(nb, hipMemcpy(nb->tdt, tt, sizeof(tt), hipMemcpyHostToDevice));
+    return GH_OK;
+  }
+  double star_min;
+  if ((rc = sink_star_end(nb, &star_min))) return rc;
   return sink_finish_step(gas, nb, star_min, "gh_hybrid_setup/sinks");
 }
 

@@ -198,7 +198,7 @@ struct SinkTab { const double *r, *v, *a, *rad; int n, ndim; };   // [n][3] star
 
 // formation criteria of one particle against every sink (Sinks.cpp:158-197); block arg-max of the density over the
 // particles that pass (ties: the lowest slot, as the reference's ascending scan with "rho > rho_max" keeps the first)
-__global__ __launch_bounds__(256) void k_sink_search(DevicePtrs d, SinkTab S, double rho_sink, double sink_radius, double *best_rho, int *best_slot, int *best_idx)
+__global__ __launch_bounds__(256) void k_sink_search(DevicePtrs d, SinkTab S, double rho_sink, double sink_radius, int n, double *best_rho, int *best_slot, int *best_idx)
 {
   __shared__ double s_rho[256];
   __shared__ int s_slot[256], s_idx[256];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_sink_search(DevicePtrs d, SinkTab S, do
     const int fl = (int) d.f[D_FLAGS][i];
     const double rh = d.f[D_RHO][i];
     bool ok = !(fl & GH_FLAG_DEAD) && (fl & GH_FLAG_POTMIN) && !(rh < rho_sink);
-    if (ok && d.levels) ok = false;                          // block timesteps: n % nstep (not built yet - refused at setup)
+    if (ok && d.levels && n%(int) d.f[D_NSTEP][i] != 0) ok = false;      // the candidate is at the end of its own step (:172)
     if (ok) {
       const double h = d.f[D_H][i];
       for (int s = 0; s < S.n && ok; s++) {
@@ -281,6 +281,15 @@ __global__ void k_sink_apply(DevicePtrs d, const int *idx, const double *mnew, i
   const int j = idx[e];
   d.f[D_M][j] = mnew[e];
   if (mnew[e] == 0.0) d.f[D_FLAGS][j] = (double) ((((int) d.f[D_FLAGS][j]) | GH_FLAG_DEAD) & ~GH_FLAG_ACTIVE);
+}
+
+// part.levelneib = max(part.levelneib, star->level) for the gas a sink accretes from (Sinks.cpp:516)
+__global__ void k_sink_levelneib(DevicePtrs d, const int *idx, const int *lvl, int n)
+{
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int j = idx[e];
+  if ((int) d.f[D_LEVELNEIB][j] < lvl[e]) d.f[D_LEVELNEIB][j] = (double) lvl[e];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,6 +405,7 @@ static int sk_create(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, int idx, dou
   }
   S.m[sk.istar] = row[D_M]; S.h[sk.istar] = K.invkernrange*sk.radius; S.gpot[sk.istar] = row[D_GPOT];
   S.tlast[sk.istar] = t; S.dti[sk.istar] = 9.9e20;
+  if (ctx->cfg.Nlevels > 1) { S.level[sk.istar] = (int) row[D_LEVEL]; S.nstep[sk.istar] = (int) row[D_NSTEP]; S.nlast[sk.istar] = (int) row[D_NLAST]; }
   // the particle is gone: m = 0, dead
   const double zero = 0.0;
   GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, &zero, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -435,7 +445,7 @@ static int sk_search(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double t)
     SinkTab T;
     if ((rc = sk_upload_stars(ctx, W, S, T))) return rc;
     double *b_rho = W.d_rows; int *b_slot = W.d_i, *b_idx = W.d_i + nblk;
-    hipLaunchKernelGGL(k_sink_search, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev(ctx), T, ctx->cfg.rho_sink, ctx->cfg.sink_radius, b_rho, b_slot, b_idx);
+    hipLaunchKernelGGL(k_sink_search, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev(ctx), T, ctx->cfg.rho_sink, ctx->cfg.sink_radius, ctx->n, b_rho, b_slot, b_idx);
     std::vector<double> hr((size_t) nblk); std::vector<int> hs((size_t) 2*nblk);
     GH_CHECK(ctx, hipMemcpyAsync(hr.data(), b_rho, sizeof(double)*(size_t) nblk, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK(ctx, hipMemcpyAsync(hs.data(), b_slot, sizeof(int)*(size_t) 2*nblk, hipMemcpyDeviceToHost, ctx->stream));
@@ -485,14 +495,14 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
   for (size_t e = 0; e < all.size(); e++) mnew[e] = rows[e*SK_ROW + D_M];
   const SinkKernel K(ctx);
   const double small_number = SK_SMALL, pi = 3.14159265358979, twopi = 6.28318530717959;
-  const int n_clock = 1;                                             // global timestep: n = nstep = 1 when this runs
+  std::vector<int> lnb_idx, lnb_lvl;                                 // levelneib of the particles a sink accretes from (:516)
 
   for (int s = 0; s < ns; s++) {
     gh_sink_rec &sk = ctx->sinks[s];
     const int is = sk.istar;
     double *sr = &S.r[3*is], *sv = &S.v[3*is], *sa = &S.a[3*is];
     double &sm = S.m[is];
-    if (sk.Ngas == 0 || n_clock%1 != 0) continue;
+    if (sk.Ngas == 0 || ctx->n%S.nstep[is] != 0) continue;
     double wnorm = 0.0;
     sk.menc = 0.0; sk.trad = 0.0; sk.tvisc = 1.0; sk.ketot = 0.0; sk.rotketot = 0.0; sk.gpetot = 0.0;
     // particles of this sink inside its radius, sorted by distance (InsertionSortIds, InlineFuncs.h:226-248: stable)
@@ -505,6 +515,7 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
       const double drsqd = dot3(dr, dr, nd);
       if (drsqd > sk.radius*sk.radius) continue;
       il.push_back(e); rs.push_back(drsqd);
+      if (ctx->cfg.Nlevels > 1) { lnb_idx.push_back(all[e]); lnb_lvl.push_back(S.level[is]); }
     }
     const int Nneib = (int) il.size();
     for (int j = 1; j < Nneib; j++) {
@@ -541,7 +552,7 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
       sk.trot = twopi*sqrt(pow(sk.radius, 3)/(sk.menc + sm));
       sk.taccrete = pow(sk.trad, 1.0 - efrac)*pow(sk.tvisc, efrac);
       if (sk.mmax > small_number && sk.menc > sk.mmax) sk.taccrete *= pow(sk.mmax/sk.menc, 2);
-      dt = 1.0*timestep;                                               // star->nstep * timestep
+      dt = (double) S.nstep[is]*timestep;                              // star->nstep * timestep
       macc = sk.menc*std::max(1.0 - exp(-dt/sk.taccrete), 0.0);
       sk.dmdt = macc/dt;
     }
@@ -597,6 +608,14 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
     GH_CHECK(ctx, hipMemcpyAsync(W.d_i, all.data(), sizeof(int)*all.size(), hipMemcpyHostToDevice, ctx->stream));
     GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, mnew.data(), sizeof(double)*all.size(), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_sink_apply, dim3(cdiv(all.size(), 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, W.d_rows, (int) all.size());
+    GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (!lnb_idx.empty()) {
+    const size_t nl = lnb_idx.size();
+    if ((rc = sk_reserve(ctx, W, ns, 2*nl + 16, 1))) return rc;
+    GH_CHECK(ctx, hipMemcpyAsync(W.d_i, lnb_idx.data(), sizeof(int)*nl, hipMemcpyHostToDevice, ctx->stream));
+    GH_CHECK(ctx, hipMemcpyAsync(W.d_i + nl, lnb_lvl.data(), sizeof(int)*nl, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_sink_levelneib, dim3(cdiv(nl, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, W.d_i + nl, (int) nl);
     GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return GH_OK;

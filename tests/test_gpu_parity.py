@@ -308,16 +308,19 @@ def test_hybrid_run_from_ic_matches_reference():
     assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9
 
 
-def test_sinks_match_reference():
+@pytest.mark.parametrize("case", ["bb_sinks_8k", "bb_sinks_8k_levels"])
+def test_sinks_match_reference(case):
     """Boss-Bodenheimer cloud with sink creation + smooth accretion (Sinks.cpp:118-777, the potmin flag and
     rho_sink floor of GradhSph::ComputeH, DeleteDeadParticles): gh_hybrid_setup + 12 gh_hybrid_step calls from the
     reference's own initial condition, no stars at the start.  Discrete results - which particles become sinks and when, the
     sinkid of every particle, which particles die, the compacted particle order, Ngas - are exact; sums to the step
-    tolerances.  (potmin is maintained where rho >= rho_sink only, which is where the sink search reads it.)"""
+    tolerances.  (potmin is maintained where rho >= rho_sink only, which is where the sink search reads it.)
+    `_levels`: the same on the block-timestep ladder (Nlevels = 5, the reference's bossbodenheimer.dat setting): 40 steps,
+    gas and stars change levels, a sixth level opens; level / nstep / nlast of every particle and the clock exact."""
     from gandalf_amd.capi import NbodyHip
     from test_oracle import bb_initial_h
-    case = "bb_sinks_8k"
     g = load_golden(case + "_steps")
+    levels = case.endswith("_levels")
     sim, p = make(case)
     s = lambda k: g["setup_" + k]  # noqa: E731
     sim.upload(s("r"), s("m"), bb_initial_h(p, s("m")), v=s("v"), u=s("u"))
@@ -330,12 +333,19 @@ def test_sinks_match_reference():
     tf, dtf = g["final_t_timestep"]
     assert sim.N == int(g["final_Nhydro"][0]) and nb.num_stars() == int(g["final_Nsink"][0]) == 2
     assert abs(t - tf) <= 1e-11*abs(tf) and abs(dt - dtf) <= 1e-8*abs(dtf)
+    if levels:
+        for k in ["level", "levelneib", "nstep", "nlast"]:
+            assert np.array_equal(sim.download(k).astype(np.int64)[g["final_m"] > 0], g["final_" + k][g["final_m"] > 0]), k
+        clock, dt_max = sim.get_block_clock()
+        assert clock[0] == g["final_n_Nsteps_nresync"][0] and clock[1] == g["final_n_Nsteps_nresync"][2]
+        assert list(clock[2:4]) == list(g["final_levelmax_levelstep_Nlevels_diffmax"][:2])
     # discrete state: exact
     fl = sim.download("flags").astype(np.int64)
     assert np.array_equal((fl & 4) != 0, (g["final_flags"] & 1) != 0)                       # dead
     assert np.array_equal(sim.download("sinkid").astype(np.int64), g["final_sinkid"])
-    dense = (g["final_rho"] >= float(p["rho_sink"])) & ((g["final_flags"] & 1) == 0)
-    assert dense.sum() > 100 and np.array_equal((fl[dense] & 8) != 0, (g["final_flags"][dense] & 8) != 0)     # potmin
+    if not levels:      # (block timesteps: the flag of a particle is only current on the step it is active)
+        dense = (g["final_rho"] >= float(p["rho_sink"])) & ((g["final_flags"] & 1) == 0)
+        assert dense.sum() > 100 and np.array_equal((fl[dense] & 8) != 0, (g["final_flags"][dense] & 8) != 0)     # potmin
     assert np.array_equal(sim.download("m") == 0.0, g["final_m"] == 0.0)
     # gas: the particle order is the reference's compacted order, so arrays compare element for element
     assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
