@@ -404,7 +404,7 @@ static int sink_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided);
 
 extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_out, double *timestep_out)
 {
-  if (gas && nb && gas->cfg.sink_particles) {                // sink runs: the star list may be empty and grows
+  if (gas && nb && (gas->cfg.sink_particles || gas->cfg.Nlevels > 1)) {      // sink runs (the star list may be empty and grows), stars on the block-timestep ladder
     if (gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
     for (int s = 0; s < nsteps; s++) { const int rc = sink_hybrid_step(gas, nb); if (rc) return rc; }
     if (t_out) *t_out = gas->t;
@@ -412,7 +412,7 @@ extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_o
     return GH_OK;
   }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
-  if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
+  if (gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
   const int64_t Ns = nb->N;
   const int nd = nb->ndim;
@@ -468,7 +468,7 @@ int gh_setup_passes(gh_ctx *ctx, int initial_h_provided);    // api.hip
 // (gas tree part + direct sum, :500-514), first timestep = minimum over both species (:538), EndTimestep of both (:551-553)
 extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided, double *timestep_out)
 {
-  if (gas && nb && gas->cfg.sink_particles) {
+  if (gas && nb && (gas->cfg.sink_particles || gas->cfg.Nlevels > 1)) {
     if (gas->N <= 0) return GH_ERR_INVALID;
     const int rc = sink_hybrid_setup(gas, nb, initial_h_provided);
     if (rc) return rc;
@@ -476,7 +476,7 @@ extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided
     return GH_OK;
   }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0) return GH_ERR_INVALID;
-  if (gas->cfg.Nlevels > 1 || gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: global timestep, one rank");
+  if (gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs: one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
   const int64_t Ns = nb->N;
   const int nd = nb->ndim;
@@ -698,7 +698,7 @@ static int sink_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided)
   int rc;
   // SphSimulation.cpp:229-237: stars present at the start are sinks of radius kernrange*h
   gas->sinks.clear();
-  if (nb->N > 0) {
+  if (nb->N > 0 && gas->cfg.sink_particles) {
     gh_host_stars S;
     if ((rc = nb_pull(nb, S))) return rc;
     const double kr = (gas->cfg.kernel == GH_KERNEL_QUINTIC || gas->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;

@@ -146,6 +146,27 @@ def sinks(name, nsteps=12):
         print(name, "sinks ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def hybrid_levels(name, nsteps=24):
+    """gas + stars on the block-timestep ladder (no sinks): setup state and the state after nsteps MainLoop calls, gas incl. the
+    level structure, stars incl. level / nstep / nlast"""
+    par = os.path.join(ROOT, "tests", "params", name + ".dat")
+    with tempfile.TemporaryDirectory() as tmp:
+        run(["steps", par, os.path.join(tmp, "s"), str(nsteps)], tmp)
+        setup = read_gdmp(os.path.join(tmp, "s_setup.gdmp"))
+        final = read_gdmp(os.path.join(tmp, "s_final.gdmp"))
+        out = {"ndim": setup["ndim"], "Nhydro": setup["Nhydro"], "nsteps": np.array([nsteps], dtype=np.int32)}
+        for k in STEP_OUT + LEVEL_OUT:
+            out["setup_" + k] = setup[k]
+            out["final_" + k] = final[k]
+        out["setup_m"] = setup["m"]
+        for k in SINK_STAR:
+            if "star_" + k in setup:
+                out["setup_star_" + k] = setup["star_" + k]
+                out["final_star_" + k] = final["star_" + k]
+        np.savez_compressed(os.path.join(GOLD, name + "_steps.npz"), **out)
+        print(name, "hybrid levels ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 def treeerror(n=32768):
     """the reference's tree-accuracy measurement (tests/paper_tests/treeerror.py:22-35): RMS relative force error of the
     KD-tree run against neib_search = bruteforce on the same Plummer sphere.  Stored: the brute-force accelerations and
@@ -231,6 +252,8 @@ if __name__ == "__main__":
             fromfile(cfg)
         elif "_sinks" in cfg:
             sinks(cfg, 40 if cfg.endswith("_levels") else 12)
+        elif cfg.endswith("_stars_levels"):
+            hybrid_levels(cfg)
         elif cfg.endswith("_levels") or cfg.endswith("_levels_single"):
             levels(cfg)
         elif cfg == "treeerror":

@@ -308,6 +308,37 @@ def test_hybrid_run_from_ic_matches_reference():
     assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9
 
 
+def test_hybrid_block_timesteps_match_reference():
+    """gas + 64 stars on the block-timestep ladder (Nlevels = 5, no sinks; the star branches of ComputeBlockTimesteps, active
+    masks in the star kernels): gh_hybrid_setup from the IC + 24 gh_hybrid_step calls; levels and clock exact"""
+    from gandalf_amd.capi import NbodyHip
+    from test_oracle import initial_h_guess
+    case = "plummer_4k_stars_levels"
+    g = load_golden(case + "_steps")
+    sim, p = make(case)
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    h0 = np.full(len(s("m")), initial_h_guess(s("r"), float(p["h_fac"])))
+    sim.upload(s("r"), s("m"), h0, v=s("v"), u=s("u"))
+    nb = NbodyHip(ndim=3, softening=int(p["nbody_softening"]), nbody_mult=float(p["nbody_mult"]))
+    nb.upload(s("star_r"), s("star_v"), s("star_m"), s("star_h"))
+    dt = nb.hybrid_setup(sim, initial_h_provided=False)
+    assert abs(dt - g["setup_t_timestep"][1]) <= 1e-10*dt
+    for k in ["level", "nstep", "nlast"]:
+        assert np.array_equal(sim.download(k).astype(np.int64), s(k)), k
+    t, dt = nb.hybrid_step(sim, int(g["nsteps"][0]))
+    tf, dtf = g["final_t_timestep"]
+    assert abs(t - tf) <= 1e-11*abs(tf) and abs(dt - dtf) <= 1e-10*abs(dtf)
+    for k in ["level", "levelneib", "nstep", "nlast"]:
+        assert np.array_equal(sim.download(k).astype(np.int64), g["final_" + k]), k
+    clock, dt_max = sim.get_block_clock()
+    assert clock[0] == g["final_n_Nsteps_nresync"][0] and clock[1] == g["final_n_Nsteps_nresync"][2]
+    assert np.max(np.abs(sim.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    assert relerr(sim.download("rho"), g["final_rho"]) < 1e-9
+    assert np.max(np.abs(nb.download("r") - g["final_star_r"])) < 1e-10*np.abs(g["final_star_r"]).max()
+    assert np.max(np.abs(nb.download("v") - g["final_star_v"])) < 1e-9*np.abs(g["final_star_v"]).max()
+    assert vec_err(nb.download("a"), g["final_star_a"]) < 1e-9
+
+
 @pytest.mark.parametrize("case", ["bb_sinks_8k", "bb_sinks_8k_levels"])
 def test_sinks_match_reference(case):
     """Boss-Bodenheimer cloud with sink creation + smooth accretion (Sinks.cpp:118-777, the potmin flag and

@@ -217,6 +217,32 @@ def test_restocked_tree_steps_bitwise(case):
         assert np.array_equal(o.get(k), g["final_" + k]), k
 
 
+def test_hybrid_levels_bitwise():
+    """gas + 64 stars on the block-timestep ladder (Nlevels = 5, no sinks): setup from the IC and 24 MainLoop calls - levels,
+    clocks and state of both species bit for bit (star branches of Simulation::ComputeBlockTimesteps)"""
+    from oracle.pyoracle import NbodyOracle
+    case = "plummer_4k_stars_levels"
+    g = load_golden(case + "_steps")
+    p = read_params_file("%s/%s.dat" % (PARAMS, case))
+    s = lambda k: g["setup_" + k]  # noqa: E731
+    o = Oracle(p, nthreads=4)
+    h0 = np.full(len(s("m")), initial_h_guess(s("r"), float(p["h_fac"])))
+    o.set_particles(s("r"), s("m"), h0, v=s("v"), u=s("u"))
+    nb = NbodyOracle(s("star_r"), s("star_v"), s("star_m"), s("star_h"), int(p["nbody_softening"]), float(p["nbody_mult"]))
+    nb.hybrid_setup(o, h_provided=False)
+    assert o.timestep == g["setup_t_timestep"][1]
+    for k in ["level", "nstep", "nlast"]:
+        assert np.array_equal(o.get_int(k), s(k)), k
+    nb.hybrid_step(o, int(g["nsteps"][0]))
+    assert (o.t, o.timestep) == tuple(g["final_t_timestep"])
+    for k in ["r", "v", "a", "h", "rho", "u"]:
+        assert np.array_equal(o.get(k), g["final_" + k]), k
+    for k in ["level", "levelneib", "nstep", "nlast"]:
+        assert np.array_equal(o.get_int(k), g["final_" + k]), k
+    for k in ["r", "v", "a", "r0", "v0", "a0", "gpot"]:
+        assert np.array_equal(nb.get(k), g["final_star_" + k]), "star " + k
+
+
 def bb_initial_h(p, m):
     """BossBodenheimerIc::Generate (BossBodenheimerIc.cpp:126, 56-62): h = h_fac (m / rho0)^(1/3), rho0 = 3 mcloud / (4 pi radius^3)"""
     rho0 = 3.0*float(p["mcloud"])/(4.0*3.14159265358979*float(p["radius"])**3)
