@@ -304,9 +304,10 @@ struct SinkScratch {
 
 static int sk_reserve(gh_ctx *ctx, SinkScratch &W, size_t nstar, size_t nint, size_t nrows)
 {
-  if (10*nstar + 8 > W.cap_st) { if (W.d_st) (void) hipFree(W.d_st); W.cap_st = 10*nstar + 64; GH_CHECK(ctx, hipMalloc((void**) &W.d_st, sizeof(double)*W.cap_st)); }
-  if (nint > W.cap_i) { if (W.d_i) (void) hipFree(W.d_i); W.cap_i = nint + 1024; GH_CHECK(ctx, hipMalloc((void**) &W.d_i, sizeof(int)*W.cap_i)); }
-  if (nrows*SK_ROW > W.cap_rows) { if (W.d_rows) (void) hipFree(W.d_rows); W.cap_rows = (nrows + 256)*SK_ROW; GH_CHECK(ctx, hipMalloc((void**) &W.d_rows, sizeof(double)*W.cap_rows)); }
+  // (a failed allocation leaves pointer and capacity cleared)
+  if (10*nstar + 8 > W.cap_st) { if (W.d_st) (void) hipFree(W.d_st); W.d_st = nullptr; W.cap_st = 0; GH_CHECK(ctx, hipMalloc((void**) &W.d_st, sizeof(double)*(10*nstar + 64))); W.cap_st = 10*nstar + 64; }
+  if (nint > W.cap_i) { if (W.d_i) (void) hipFree(W.d_i); W.d_i = nullptr; W.cap_i = 0; GH_CHECK(ctx, hipMalloc((void**) &W.d_i, sizeof(int)*(nint + 1024))); W.cap_i = nint + 1024; }
+  if (nrows*SK_ROW > W.cap_rows) { if (W.d_rows) (void) hipFree(W.d_rows); W.d_rows = nullptr; W.cap_rows = 0; GH_CHECK(ctx, hipMalloc((void**) &W.d_rows, sizeof(double)*(nrows + 256)*SK_ROW)); W.cap_rows = (nrows + 256)*SK_ROW; }
   return GH_OK;
 }
 

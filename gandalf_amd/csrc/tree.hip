@@ -329,6 +329,15 @@ __global__ void k_qsel_init(DevicePtrs d, int *ids, const int *gate)
   if (p < d.N) ids[d.iorig[p]] = p;                 // caller order -> current storage position
 }
 
+#define GH_QCAP 2048       /* elements of a quick-select range held in LDS (two buffers) */
+// One Lomuto pass in closed form.  "for j: if a[j] <= pivot: swap(a[j], a[jguess++])" leaves (i) everything before the first
+// element > pivot (position f0) where it is, (ii) the later "<=" elements packed behind it in their order, (iii) the ">"
+// elements as a queue that every later "<=" element rotates by one (its front goes to position j).  Number the operations
+// from f0 (op i acts on position f0 + i - 1): every op leaves a token at its position - a push its own element, the k-th
+// rotation the element of token k (tokens are consumed in the order they were made) - and the tokens R+1 .. M survive in
+// place (R rotations, M ops).  So the element that ends at a position >= f0 + R is found by following "rotation at op i ->
+// token (number of rotations up to i)" until a push is reached: a chain of strictly decreasing positions, O(log M) long.
+// All positions are independent: the pass is a prefix sum and a gather instead of M/64 dependent block steps.
 __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level, int *ids, double *keys, double *dbbmin, double *dbbmax,
                                                         int *kdiv, const int *gate)
 {
@@ -336,6 +345,9 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
   __shared__ int s_wave[16];
   __shared__ int s_tot;
   __shared__ double s_piv;
+  __shared__ double s_qk[2][GH_QCAP];
+  __shared__ int s_qi[2][GH_QCAP];
+  __shared__ int s_rk[GH_QCAP];
   const int n = (1 << level) - 1 + blockIdx.x;
   const int first = d.cfirst[n], cnt = d.cN[n];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
@@ -359,8 +371,23 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
     __syncthreads();
     return tot;
   };
+  // ... of an integer
+  auto iscan = [&](int v, int &pre) -> int {
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int w = 0; w < nw; w++) { const int c = s_wave[w]; s_wave[w] = run; run += c; } s_tot = run; }
+    __syncthreads();
+    pre = s_wave[wv] + inc - v;
+    const int tot = s_tot;
+    __syncthreads();
+    return tot;
+  };
   if (cnt > 0) {
-    for (;;) {
+    bool converged = false;
+    // ---- ranges larger than the LDS buffers: block steps on the global arrays
+    while (right - left + 1 > GH_QCAP) {
       const int jg0 = (left + right)/2;                       // pivot guess: the middle element ...
       if (tid == 0) {
         s_piv = keys[jg0];
@@ -409,7 +436,85 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
       __syncthreads();
       if (jguess < jpivot) left = jguess + 1;
       else if (jguess > jpivot) right = jguess - 1;
-      else break;
+      else { converged = true; break; }
+    }
+    // ---- the range fits: stage it, closed-form passes between two LDS buffers
+    if (!converged) {
+      const int base = left, m0 = right - left + 1;
+      for (int r = tid; r < m0; r += nt) { s_qk[0][r] = keys[base + r]; s_qi[0][r] = ids[base + r]; }
+      __syncthreads();
+      int cur = 0;
+      int lo = 0, hi = m0 - 1;
+      const int jp = jpivot - base;
+      for (;;) {
+        double *A = s_qk[cur], *B = s_qk[cur ^ 1];
+        int *Ai = s_qi[cur], *Bi = s_qi[cur ^ 1];
+        const int jg0 = (lo + hi)/2;
+        if (tid == 0) {
+          s_piv = A[jg0];
+          const int ti = Ai[jg0]; Ai[jg0] = Ai[hi]; Ai[hi] = ti;
+          const double tk = A[jg0]; A[jg0] = A[hi]; A[hi] = tk;
+        }
+        __syncthreads();
+        rpivot = s_piv;
+        const int mc = hi - lo;                                // positions lo .. hi-1 take part; hi holds the pivot
+        const int E = (mc + nt - 1)/nt;                        // consecutive positions per thread
+        const int q0 = lo + tid*E, q1 = min(q0 + E, hi);
+        int nle = 0, fgt = 0x7fffffff;
+        for (int q = q0; q < q1; q++) { if (A[q] <= rpivot) nle++; else if (fgt == 0x7fffffff) fgt = q; }
+        int pre;
+        const int tot_le = iscan(nle, pre);
+        { int run = pre; for (int q = q0; q < q1; q++) { if (A[q] <= rpivot) run++; s_rk[q] = run; } }      // inclusive count of "<=" in [lo, q]
+        // first element > pivot
+        for (int off = 32; off > 0; off >>= 1) fgt = min(fgt, __shfl_xor(fgt, off, 64));
+        if (lane == 0) s_wave[wv] = fgt;
+        __syncthreads();
+        int f0 = 0x7fffffff;
+        for (int w = 0; w < nw; w++) f0 = min(f0, s_wave[w]);
+        __syncthreads();
+        int jguess;
+        if (f0 == 0x7fffffff) jguess = hi;                     // nothing > pivot: every swap was with itself
+        else {
+          const int nb4 = f0 - lo;                             // all "<=": untouched
+          const int R = tot_le - nb4;                          // rotations
+          jguess = f0 + R;
+          for (int q = q0; q < q1; q++) {
+            if (q < f0) { B[q] = A[q]; Bi[q] = Ai[q]; }
+            else if (A[q] <= rpivot) { const int t = f0 + (s_rk[q] - nb4) - 1; B[t] = A[q]; Bi[t] = Ai[q]; }
+            if (q >= jguess) {
+              int src = q;
+              while (A[src] <= rpivot) src = f0 + (s_rk[src] - nb4) - 1;
+              B[q] = A[src]; Bi[q] = Ai[src];
+            }
+          }
+          if (tid == 0) { B[hi] = A[hi]; Bi[hi] = Ai[hi]; }
+          __syncthreads();
+          cur ^= 1;
+        }
+        {
+          double *C = s_qk[cur]; int *Ci = s_qi[cur];
+          if (tid == 0) {                                      // the pivot goes between the two sides
+            const int ti = Ci[hi]; Ci[hi] = Ci[jguess]; Ci[jguess] = ti;
+            const double tk = C[hi]; C[hi] = C[jguess]; C[jguess] = tk;
+          }
+        }
+        __syncthreads();
+        // (positions outside [lo, hi] of the other buffer are stale: carry the settled ones along when the buffers swap)
+        if (jguess < jp) {
+          const int nlo = jguess + 1;
+          for (int q = lo + tid; q < nlo; q += nt) { s_qk[cur ^ 1][q] = s_qk[cur][q]; s_qi[cur ^ 1][q] = s_qi[cur][q]; }
+          lo = nlo;
+        }
+        else if (jguess > jp) {
+          const int nhi = jguess - 1;
+          for (int q = nhi + 1 + tid; q <= hi; q += nt) { s_qk[cur ^ 1][q] = s_qk[cur][q]; s_qi[cur ^ 1][q] = s_qi[cur][q]; }
+          hi = nhi;
+        }
+        else break;
+        __syncthreads();
+      }
+      __syncthreads();
+      for (int r = tid; r < m0; r += nt) { keys[base + r] = s_qk[cur][r]; ids[base + r] = s_qi[cur][r]; }
     }
   }
   if (tid == 0) {
