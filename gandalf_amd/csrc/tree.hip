@@ -339,15 +339,18 @@ __global__ void k_qsel_init(DevicePtrs d, int *ids, const int *gate)
 // token (number of rotations up to i)" until a push is reached: a chain of strictly decreasing positions, O(log M) long.
 // All positions are independent: the pass is a prefix sum and a gather instead of M/64 dependent block steps.
 __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level, int *ids, double *keys, double *dbbmin, double *dbbmax,
-                                                        int *kdiv, const int *gate)
+                                                        int *kdiv, const int *gate, int qcap)
 {
   if (gate && !*gate) return;
   __shared__ int s_wave[16];
   __shared__ int s_tot;
   __shared__ double s_piv;
-  __shared__ double s_qk[2][GH_QCAP];
-  __shared__ int s_qi[2][GH_QCAP];
-  __shared__ int s_rk[GH_QCAP];
+  // LDS buffers sized by the launch: qcap = min(largest cell of the level, GH_QCAP) elements (28 bytes each), so that the many
+  // small cells of the deep levels do not each reserve the 56 KB the top levels need
+  extern __shared__ double s_dyn[];
+  double *const s_qk[2] = {s_dyn, s_dyn + qcap};
+  int *const s_qi[2] = {(int*) (s_dyn + 2*qcap), (int*) (s_dyn + 2*qcap) + qcap};
+  int *const s_rk = (int*) (s_dyn + 2*qcap) + 2*qcap;
   const int n = (1 << level) - 1 + blockIdx.x;
   const int first = d.cfirst[n], cnt = d.cN[n];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
@@ -384,10 +387,42 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
     __syncthreads();
     return tot;
   };
+  // closed-form Lomuto pass over the LDS positions [lo, hi) of buffer A against pivot rp (see above): the result goes to B
+  // (returns true) unless no element exceeds the pivot, when nothing moves (returns false); jguess = where the "> pivot" run starts
+  auto cf_pass = [&](const double *A, const int *Ai, double *B, int *Bi, int lo, int hi, double rp, int &jguess) -> bool {
+    const int mc = hi - lo;
+    const int E = (mc + nt - 1)/nt;                          // consecutive positions per thread
+    const int q0 = lo + tid*E, q1 = min(q0 + E, hi);
+    int nle = 0, fgt = 0x7fffffff;
+    for (int q = q0; q < q1; q++) { if (A[q] <= rp) nle++; else if (fgt == 0x7fffffff) fgt = q; }
+    int pre;
+    const int tot_le = iscan(nle, pre);
+    { int run = pre; for (int q = q0; q < q1; q++) { if (A[q] <= rp) run++; s_rk[q] = run; } }      // inclusive count of "<=" in [lo, q]
+    for (int off = 32; off > 0; off >>= 1) fgt = min(fgt, __shfl_xor(fgt, off, 64));                  // first element > pivot
+    if (lane == 0) s_wave[wv] = fgt;
+    __syncthreads();
+    int f0 = 0x7fffffff;
+    for (int w = 0; w < nw; w++) f0 = min(f0, s_wave[w]);
+    __syncthreads();
+    if (f0 == 0x7fffffff) { jguess = hi; return false; }     // nothing > pivot: every swap was with itself
+    const int nb4 = f0 - lo;                                 // all "<=": untouched
+    const int R = tot_le - nb4;                              // rotations
+    jguess = f0 + R;
+    for (int q = q0; q < q1; q++) {
+      if (q < f0) { B[q] = A[q]; Bi[q] = Ai[q]; }
+      else if (A[q] <= rp) { const int t = f0 + (s_rk[q] - nb4) - 1; B[t] = A[q]; Bi[t] = Ai[q]; }
+      if (q >= jguess) {
+        int src = q;
+        while (A[src] <= rp) src = f0 + (s_rk[src] - nb4) - 1;
+        B[q] = A[src]; Bi[q] = Ai[src];
+      }
+    }
+    return true;
+  };
   if (cnt > 0) {
     bool converged = false;
     // ---- ranges larger than the LDS buffers: block steps on the global arrays
-    while (right - left + 1 > GH_QCAP) {
+    while (right - left + 1 > qcap) {
       const int jg0 = (left + right)/2;                       // pivot guess: the middle element ...
       if (tid == 0) {
         s_piv = keys[jg0];
@@ -399,24 +434,10 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
       int jguess = left, j = left;
       while (j < right) {
         const int g = j - jguess;                             // elements > pivot seen so far: they occupy [jguess, j)
-        if (g == 0) {
-          // elements <= pivot swap with themselves: skip the whole run, stop at the first element > pivot
-          const int nv = min(nt, right - j);
-          const bool gt = tid < nv && !(keys[j + tid] <= rpivot);
-          int pre;
-          const int ngt = scan(gt, pre);
-          int run = nv;
-          if (ngt > 0) {                                       // position of the first one
-            if (gt && pre == 0) s_tot = tid;
-            __syncthreads();
-            run = s_tot;
-            __syncthreads();
-          }
-          jguess += run; j += run;
-          if (run < nv) j += 1;
-        }
-        else {
-          const int w = min(min(nt, g), right - j);
+        if (g >= nt) {
+          // a block step: the next nt elements against a run of "> pivot" elements at least as long - the k-th "<=" element
+          // of the block swaps with the k-th element of the run, all swaps disjoint
+          const int w = min(nt, right - j);
           bool le = false; int idb = 0; double kb = 0.0;
           if (tid < w) { kb = keys[j + tid]; idb = ids[j + tid]; le = kb <= rpivot; }
           int pre;
@@ -427,6 +448,20 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
           if (le) { ids[jguess + pre] = idb; keys[jguess + pre] = kb; ids[j + tid] = idt; keys[j + tid] = kt; }
           __syncthreads();
           jguess += c; j += w;
+        }
+        else {
+          // a short run (always at the start of a pass, and throughout a pass with few "> pivot" elements) would make the
+          // block steps as narrow as the run: take the run and what follows it, up to qcap positions, in closed form
+          // instead (the run's elements are "pushes" like any other "> pivot" element)
+          const int hn = min(qcap, right - jguess);
+          for (int r = tid; r < hn; r += nt) { s_qk[0][r] = keys[jguess + r]; s_qi[0][r] = ids[jguess + r]; }
+          __syncthreads();
+          int jg;
+          const bool moved = cf_pass(s_qk[0], s_qi[0], s_qk[1], s_qi[1], 0, hn, rpivot, jg);
+          __syncthreads();
+          if (moved) for (int r = tid; r < hn; r += nt) { keys[jguess + r] = s_qk[1][r]; ids[jguess + r] = s_qi[1][r]; }
+          __syncthreads();
+          j = jguess + hn; jguess = jguess + jg;
         }
       }
       if (tid == 0) {                                          // the pivot goes between the two sides
@@ -457,36 +492,8 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
         }
         __syncthreads();
         rpivot = s_piv;
-        const int mc = hi - lo;                                // positions lo .. hi-1 take part; hi holds the pivot
-        const int E = (mc + nt - 1)/nt;                        // consecutive positions per thread
-        const int q0 = lo + tid*E, q1 = min(q0 + E, hi);
-        int nle = 0, fgt = 0x7fffffff;
-        for (int q = q0; q < q1; q++) { if (A[q] <= rpivot) nle++; else if (fgt == 0x7fffffff) fgt = q; }
-        int pre;
-        const int tot_le = iscan(nle, pre);
-        { int run = pre; for (int q = q0; q < q1; q++) { if (A[q] <= rpivot) run++; s_rk[q] = run; } }      // inclusive count of "<=" in [lo, q]
-        // first element > pivot
-        for (int off = 32; off > 0; off >>= 1) fgt = min(fgt, __shfl_xor(fgt, off, 64));
-        if (lane == 0) s_wave[wv] = fgt;
-        __syncthreads();
-        int f0 = 0x7fffffff;
-        for (int w = 0; w < nw; w++) f0 = min(f0, s_wave[w]);
-        __syncthreads();
         int jguess;
-        if (f0 == 0x7fffffff) jguess = hi;                     // nothing > pivot: every swap was with itself
-        else {
-          const int nb4 = f0 - lo;                             // all "<=": untouched
-          const int R = tot_le - nb4;                          // rotations
-          jguess = f0 + R;
-          for (int q = q0; q < q1; q++) {
-            if (q < f0) { B[q] = A[q]; Bi[q] = Ai[q]; }
-            else if (A[q] <= rpivot) { const int t = f0 + (s_rk[q] - nb4) - 1; B[t] = A[q]; Bi[t] = Ai[q]; }
-            if (q >= jguess) {
-              int src = q;
-              while (A[src] <= rpivot) src = f0 + (s_rk[src] - nb4) - 1;
-              B[q] = A[src]; Bi[q] = Ai[src];
-            }
-          }
+        if (cf_pass(A, Ai, B, Bi, lo, hi, rpivot, jguess)) {
           if (tid == 0) { B[hi] = A[hi]; Bi[hi] = Ai[hi]; }
           __syncthreads();
           cur ^= 1;
@@ -554,7 +561,8 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
     mx += 1;
     int bs = 64;
     while (bs < mx && bs < 1024) bs <<= 1;
-    hipLaunchKernelGGL(k_qselect_level, dim3(1 << l), dim3(bs), 0, s, d, l, ctx->qs_ids, ctx->qs_keys, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, gate);
+    const int qcap = std::min(std::max(mx, 2), GH_QCAP);
+    hipLaunchKernelGGL(k_qselect_level, dim3(1 << l), dim3(bs), (size_t) 28*qcap, s, d, l, ctx->qs_ids, ctx->qs_keys, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, gate, qcap);
   }
   hipLaunchKernelGGL(k_copy_if, dim3(cdiv(N, 256)), dim3(256), 0, s, ctx->qs_ids, perm_out, N, gate);
   return GH_OK;
