@@ -116,6 +116,11 @@ class HipSphTree : public SphNeighbourSearch<ndim>
     c.gamma_eos = fp["gamma_eos"]; c.temp0 = fp["temp0"]; c.mu_bar = fp["mu_bar"]; c.rho_bary = fp["rho_bary"];
     c.thetamaxsqd = fp["thetamaxsqd"]; c.macerror = fp["macerror"];
     c.courant_mult = fp["courant_mult"]; c.accel_mult = fp["accel_mult"]; c.energy_mult = fp["energy_mult"];
+    // sink particles: the shell keeps GANDALF's own Sinks object (it reaches the device through GetGatherNeighbourList below);
+    // the device needs the parameters for ComputeH's rho_sink floor, in-sink branch and potential-minimum flag
+    // (GradhSph.cpp:163-169, 270-280, 309-312) and builds its tree in the reference's particle order for them
+    c.sink_particles = ip["sink_particles"]; c.create_sinks = c.sink_particles ? ip["create_sinks"] : 0;
+    c.rho_sink = sph->rho_sink;                      // already in code units (SphSimulation.cpp:128-129)
     if (gh_create(&c, &ctx) != GH_OK) {
       std::string msg = ctx ? gh_last_error(ctx) : "gh_create failed";
       ExceptionHandler::getIstance().raise(msg);
@@ -183,7 +188,19 @@ class HipSphTree : public SphNeighbourSearch<ndim>
   // ---- SphNeighbourSearch<ndim> ---------------------------------------------------------------------------------
   virtual void UpdateAllSphProperties(Sph<ndim> *sph, Nbody<ndim> *)                                  // GradhSphTree.cpp:83-271
   {
+    if (sph->sink_particles) {                                           // Particle::sinkid, set by Sinks::AccreteMassToSinks
+      GradhSphParticle<ndim> *p = parts(sph);
+      buf.resize(sph->Nhydro);
+      for (int i = 0; i < sph->Nhydro; i++) buf[i] = (double) p[i].sinkid;
+      check(gh_upload_field(ctx, GH_F_SINKID, &buf[0]));
+    }
     check(gh_update_density(ctx, 0));
+    if (sph->create_sinks == 1) {                                        // the potmin flag Sinks::SearchForNewSinkParticles reads
+      GradhSphParticle<ndim> *p = parts(sph);
+      buf.resize(sph->Nhydro);
+      check(gh_download(ctx, GH_F_FLAGS, &buf[0]));
+      for (int i = 0; i < sph->Nhydro; i++) { if ((int) buf[i] & 8) p[i].flags.set(potmin); else p[i].flags.unset(potmin); }
+    }
     DownloadScalar(sph, GH_F_H, &GradhSphParticle<ndim>::h);             DownloadScalar(sph, GH_F_RHO, &GradhSphParticle<ndim>::rho);
     DownloadScalar(sph, GH_F_INVOMEGA, &GradhSphParticle<ndim>::invomega); DownloadScalar(sph, GH_F_ZETA, &GradhSphParticle<ndim>::zeta);
     DownloadScalar(sph, GH_F_HFACTOR, &GradhSphParticle<ndim>::hfactor);  DownloadScalar(sph, GH_F_HRANGESQD, &GradhSphParticle<ndim>::hrangesqd);
