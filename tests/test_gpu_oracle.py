@@ -174,6 +174,18 @@ def test_config1_full_run_vs_reference():
     assert np.max(np.abs(dev.download("v") - g["final_v"])) < 1e-7
     rho = dev.download("rho")
     assert 0.2 < rho.min() and rho.max() < 1.1          # between the two initial states (rhofluid2 = 0.25, rhofluid1 = 1)
+    # the reference's own acceptance criterion for the Sod tube (tests/hydro_tests/test_adsod.py:11-18): L1 error of
+    # vx against the exact Riemann solution < 9e-3 (analysis/compute.py:109-146: mean |vx - exact| over the particles;
+    # taken over the part of the tube the waves have reached, |x| < 10) - and the same number as the reference's final state
+    from riemann import exact_riemann, l1_error
+    x, vx = dev.download("r")[:, 0], dev.download("v")[:, 0]
+    m = np.abs(x) < 10.0
+    _, u_exact, _ = exact_riemann(x[m], sim.t, 1.0, 0.0, 1.0, 0.25, 0.0, 0.1795, 1.4)
+    l1 = l1_error(x[m], vx[m], u_exact)
+    xr, vr = g["final_r"][:, 0], g["final_v"][:, 0]
+    mr = np.abs(xr) < 10.0
+    l1_ref = l1_error(xr[mr], vr[mr], exact_riemann(xr[mr], float(g["final_t_timestep"][0]), 1.0, 0.0, 1.0, 0.25, 0.0, 0.1795, 1.4)[1])
+    assert l1 < 9e-3 and abs(l1 - l1_ref) < 1e-6, (l1, l1_ref)
 
 
 @pytest.mark.parametrize("case", ["adsod_1d_levels", "plummer_4k_levels"])
