@@ -308,3 +308,38 @@ def test_sink_run_from_parameter_file():
     sk = dev.sinks()
     assert np.array_equal(sk["Ngas"], g["final_sink_Ngas"])
     assert np.max(np.abs(sk["menc"] - g["final_sink_menc"])/g["final_sink_menc"]) < 1e-9
+
+
+def test_sinks_64k_vs_oracle():
+    """sinks + block timesteps at a size where the exact-mode tree build leaves its LDS-only regime (cells of up to 65 536
+    particles: block steps and closed-form chunks on the global arrays): the Boss-Bodenheimer cloud with 65 536 particles,
+    Nlevels = 5, setup + 10 steps on the GPU and in the CPU restatement - particle count, the particle order the dead
+    particles leave behind, sinkid, levels, potmin of the dense particles and the sinks' gas counts exact, sums to tolerance"""
+    from gandalf_amd.host import Simulation
+    from oracle.pyoracle import Oracle, NbodyOracle
+    par = "%s/bb_sinks_8k_levels.dat" % PARAMS
+    sim = Simulation(par, Nhydro=65536, run_id="BB64K")
+    ic = sim.generate_ic()
+    sim.post_ic_setup()
+    sim.main_loop(10)
+    p = read_params_file(par)
+    p["Nhydro"] = "65536"
+    o = Oracle(p, nthreads=16)
+    o.set_particles(ic["r"], ic["m"], ic["h"], v=ic["v"], u=ic["u"])
+    e = np.zeros(0)
+    no = NbodyOracle(e.reshape(0, 3), e.reshape(0, 3), e, e, int(p["nbody_softening"]), float(p["nbody_mult"]))
+    no.hybrid_setup(o, h_provided=True)
+    no.hybrid_step(o, 10)
+    dev = sim.device()
+    assert dev.N == o.num_particles() < 65536
+    assert abs(sim.t - o.t) <= 1e-11*o.t
+    alive = o.get("m") > 0
+    for k in ["level", "nstep", "nlast", "sinkid"]:
+        assert np.array_equal(dev.download(k).astype(np.int64)[alive], o.get_int(k)[alive]), k
+    assert np.array_equal(dev.download("m") == 0.0, ~alive)
+    assert np.max(np.abs(dev.download("r") - o.get("r"))) < 1e-10*np.abs(o.get("r")).max()
+    assert np.max(np.abs(dev.download("rho")[alive]/o.get("rho")[alive] - 1)) < 1e-9
+    sk, so = dev.sinks(), o.sinks()
+    assert len(sk["radius"]) == len(so["radius"]) >= 1
+    assert np.array_equal(sk["Ngas"], so["Ngas"]) and np.array_equal(sk["istar"], so["istar"])
+    assert np.max(np.abs(sk["menc"] - so["menc"])/so["menc"]) < 1e-9
