@@ -46,7 +46,9 @@ __device__ __forceinline__ void neib_from_tile(Neib &n, const double (*s_t)[64],
 }
 
 // one SPH pair, particle i <- neighbour j               (GradhSph.cpp:384-448 / 498-572)
-template <int ND, bool GRAV, int KT>
+// TDAV: per-particle alpha in a self-gravity kernel (cd2010: ComputeH updates alpha whatever the force driver; only the fused
+// kernel is instantiated with it)
+template <int ND, bool GRAV, int KT, bool TDAV = false>
 __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti, Accum &A, const Neib &nb,
                                          const double dr_in[3], double r2)
 {
@@ -84,7 +86,7 @@ __device__ __forceinline__ void sph_pair(const ForceParams &P, const TargetI &ti
     // mon97mm97 (GradhSph.cpp:419-424): the pair's mean alpha.  Only the hydro-only driver ever updates alpha
     // (GradhSphTree.cpp:403; UpdateAllSphForces never writes dalphadt back), so with self-gravity every alpha
     // stays alpha_visc_min and the host passes that as alpha_visc with avisc = mon97.
-    if (!GRAV && (P.avisc == GH_AVISC_MON97MM97 || P.avisc == GH_AVISC_MON97CD2010)) {
+    if ((!GRAV || TDAV) && (P.avisc == GH_AVISC_MON97MM97 || P.avisc == GH_AVISC_MON97CD2010)) {
       const double alpha_mean = 0.5*(ti.alpha + nb.alpha);
       const double vsignal = ti.sound + nb.sound - P.beta_visc*alpha_mean*dvdr;
       paux -= alpha_mean*vsignal*dvdr*winvrho;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 // near-list entry: first particle (27 bits) | count << 27
 __device__ __forceinline__ int near_entry(int first, int n) { return first | (n << 27); }
 
-template <int ND, bool COUNT, int KT>
+template <int ND, bool COUNT, int KT, bool TDAV = false>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags, const int *only_if)
 {
   typedef typename KSel<ND, KT>::type K;
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
 
   TargetI ti;
   load_target(d, i, ND, ti);
+  if (TDAV) ti.alpha = d.f[D_ALPHA][i];
   Accum A;
   for (int k = 0; k < 3; k++) { A.a[k] = 0.0; A.at[k] = 0.0; }
   A.dudt = 0.0; A.div_v = 0.0;
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
-          sph_pair<ND, true, KT>(P, ti, A, nb, dr, r2);
+          if (TDAV) nb.alpha = d.f[D_ALPHA][first + k];
+          sph_pair<ND, true, KT, TDAV>(P, ti, A, nb, dr, r2);
           if (COUNT) n_pairs++;
           if (lv && act) { lnmax = max(lnmax, (int) d.f[D_LEVEL][first + k]); raise_levelneib(d, first + k, mylevel); }
         }
@@ -646,7 +648,9 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
   hipStream_t s = ctx->stream;
   if (nblocks > 0) {
 #define LAUNCH(ND_, KT_)                                                                                           \
-    if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
+    if (P.avisc == GH_AVISC_MON97CD2010 && count) hipLaunchKernelGGL((k_grav_forces<ND_, true, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
+    else if (P.avisc == GH_AVISC_MON97CD2010) hipLaunchKernelGGL((k_grav_forces<ND_, false, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
+    else if (count) hipLaunchKernelGGL((k_grav_forces<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if); \
     else hipLaunchKernelGGL((k_grav_forces<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags, only_if);
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
@@ -657,7 +661,11 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if)
 int gh_all_forces_impl(gh_ctx *ctx, bool count)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_all_forces: no tree");
-  if (ctx->cfg.avisc == GH_AVISC_MON97CD2010) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "time_dependent_avisc = cd2010 is built for hydro-only runs (self_gravity = 0)");
+  // cd2010 with self-gravity: the pair terms need every particle's own alpha (ComputeH updates it): done by the fused kernel,
+  // which evaluates monopoles with the geometric MAC only
+  const bool cd_grav = ctx->cfg.avisc == GH_AVISC_MON97CD2010;
+  if (cd_grav && (ctx->cfg.multipole != GH_MULTIPOLE_MONOPOLE || ctx->cfg.gravity_mac != GH_MAC_GEOMETRIC || ctx->nranks > 1))
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "time_dependent_avisc = cd2010 with self-gravity: multipole = monopole, gravity_mac = geometric, one rank");
   for (int k = 0; k < ctx->ndim; k++)
     if (ctx->cfg.boundary_lhs[k] != GH_BOUNDARY_OPEN || ctx->cfg.boundary_rhs[k] != GH_BOUNDARY_OPEN)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, "self-gravity needs open boundaries (periodic gravity = Ewald, out of scope)");
@@ -670,7 +678,7 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
     // GH_GRAV_FUSED=1 (or leaves wider than the evaluation kernel handles) selects the single fused kernel
     const char *fused = getenv("GH_GRAV_FUSED");
-    if (!(fused && fused[0] == '1') && ctx->leafocc <= 6) return gh_grav_lists_impl(ctx, count);
+    if (!(fused && fused[0] == '1') && ctx->leafocc <= 6 && !cd_grav) return gh_grav_lists_impl(ctx, count);
   }
   if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole / gravity_mac=gadget2 need the list kernels (Nleafmax <= 6)");
   hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx));
