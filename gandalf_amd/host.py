@@ -32,6 +32,8 @@ HOST_SYMBOLS = {
     "gah_timestep": (C.c_double, [_H]),
     "gah_ctx": (C.c_void_p, [_H]),
     "gah_write_snapshot": (C.c_int, [_H, C.c_char_p, C.c_char_p]),
+    "gah_diagnostics": (C.c_int, [_H, _PD, C.c_char_p]),
+    "gah_write_timing": (C.c_int, [_H, C.c_char_p]),
     "gah_snapshot_error": (C.c_char_p, []),
     "gah_snapshot_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, _PD, _PD, _PD, _PD, _PD, _PD,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_long), _PD]),
@@ -174,6 +176,21 @@ class Simulation:
     def write_snapshot(self, filename, fileform="su"):
         """SimulationBase::WriteSnapshotFile: the current device state as a column / su snapshot"""
         self._chk(self.lib.gah_write_snapshot(self.h, filename.encode(), fileform.encode()))
+
+    DIAG = ["t", "Nsteps", "timestep", "dt_min_hydro", "dt_min_nbody", "level_max", "Nhydro", "Nstar", "Ndead", "mtot", "Etot", "ketot",
+            "utot", "gpetot"]
+
+    def diagnostics(self, filename=None):
+        """Simulation::CalculateDiagnostics (SimAnalysis.hpp:52-200); with a filename also appends the <run_id>.diag line"""
+        o = np.zeros(29)
+        self._chk(self.lib.gah_diagnostics(self.h, o.ctypes.data_as(_PD), filename.encode() if filename else None))
+        d = {k: o[i] for i, k in enumerate(self.DIAG)}
+        d.update(angmom=o[14:17].copy(), rcom=o[17:20].copy(), vcom=o[20:23].copy(), mom=o[23:26].copy(), force=o[26:29].copy())
+        return d
+
+    def write_timing(self, filename):
+        """CodeTiming::ComputeTimingStatistics: the <run_id>.timing table (device phases)"""
+        self._chk(self.lib.gah_write_timing(self.h, filename.encode()))
 
     def main_loop(self, nsteps=1):
         self._chk(self.lib.gah_main_loop(self.h, nsteps))

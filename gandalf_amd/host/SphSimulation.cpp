@@ -1,4 +1,7 @@
 #include "SphSimulation.h"
+#include <fstream>
+#include <iomanip>
+#include <sys/time.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -425,6 +428,7 @@ void SphSimulation::PostInitialConditionsSetup()
   else check(ctx, gh_setup(ctx, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
   Nsteps = 0;
   setup = true;
+  { struct timeval tv; gettimeofday(&tv, 0); wall_start = tv.tv_sec + 1e-6*tv.tv_usec; }
 }
 
 void SphSimulation::SetupSimulation()
@@ -471,4 +475,125 @@ void SphSimulation::Download(int field, std::vector<double> &out)
   const bool vec = field <= GH_F_A0;
   out.resize((size_t) sph->part.N*(vec ? ndim : 1));
   check(ctx, gh_download(ctx, field, out.data()), "Download");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagnostics and timing files (Simulation::CalculateDiagnostics / RecordDiagnostics, SimAnalysis.hpp:52-300;
+// CodeTiming::ComputeTimingStatistics, CodeTiming.cpp:238-420).  The sums run on the host over the downloaded arrays in
+// the reference's particle order, dead particles skipped, stars and the sinks' internal angular momentum added.
+// out: t, Nsteps, timestep, dt_min_hydro, dt_min_nbody, level_max, Nhydro, Nstar, Ndead, mtot, Etot, ketot, utot, gpetot,
+//      angmom[3], rcom[3], vcom[3], mom[3], force[3]  (unused components of ndim < 3 runs are zero)
+void SphSimulation::CalculateDiagnostics(double *o)
+{
+  if (!ctx) throw GandalfError("CalculateDiagnostics: no device context");
+  const int N = (int) gh_num_particles(ctx);
+  sph->part.N = N;
+  std::vector<double> r, v, a, m, u, gpot, fl;
+  Download(GH_F_R, r); Download(GH_F_V, v); Download(GH_F_A, a); Download(GH_F_M, m); Download(GH_F_U, u); Download(GH_F_GPOT, gpot);
+  if (cfg.sink_particles) Download(GH_F_FLAGS, fl);
+  int Ndead = 0;
+  double mtot = 0.0, ketot = 0.0, utot = 0.0, gpetot = 0.0, rcom[3] = {0, 0, 0}, vcom[3] = {0, 0, 0}, mom[3] = {0, 0, 0}, force[3] = {0, 0, 0}, angmom[3] = {0, 0, 0};
+  auto dead = [&](int i) { return cfg.sink_particles && ((int) fl[i] & 4); };
+  for (int i = 0; i < N; i++) {
+    if (dead(i)) { Ndead++; continue; }
+    double vv = 0.0;
+    for (int k = 0; k < ndim; k++) vv += v[(size_t) i*ndim + k]*v[(size_t) i*ndim + k];
+    mtot += m[i]; ketot += m[i]*vv; utot += m[i]*u[i]; gpetot -= m[i]*gpot[i];
+    for (int k = 0; k < ndim; k++) {
+      rcom[k] += m[i]*r[(size_t) i*ndim + k]; vcom[k] += m[i]*v[(size_t) i*ndim + k];
+      mom[k] += m[i]*v[(size_t) i*ndim + k]; force[k] += m[i]*a[(size_t) i*ndim + k];
+    }
+  }
+  auto add_angmom = [&](double mm, const double *rr, const double *vv) {
+    if (ndim == 2) angmom[2] += mm*(rr[0]*vv[1] - rr[1]*vv[0]);
+    else if (ndim == 3) {
+      angmom[0] += mm*(rr[1]*vv[2] - rr[2]*vv[1]);
+      angmom[1] += mm*(rr[2]*vv[0] - rr[0]*vv[2]);
+      angmom[2] += mm*(rr[0]*vv[1] - rr[1]*vv[0]);
+    }
+  };
+  for (int i = 0; i < N; i++) if (!dead(i)) add_angmom(m[i], &r[(size_t) i*ndim], &v[(size_t) i*ndim]);
+  int Nstar = 0;
+  if (nbody) {
+    Nstar = (int) gh_nbody_num_stars(nbody);
+    if (Nstar > 0) {
+      std::vector<double> sr((size_t) Nstar*ndim), sv((size_t) Nstar*ndim), sa((size_t) Nstar*ndim), sm(Nstar), sg(Nstar);
+      if (gh_nbody_download(nbody, GH_NB_R, sr.data()) || gh_nbody_download(nbody, GH_NB_V, sv.data()) || gh_nbody_download(nbody, GH_NB_A, sa.data()) ||
+          gh_nbody_download(nbody, GH_NB_GPOT, sg.data()) || gh_nbody_download_scalar(nbody, 0, sm.data()))
+        throw GandalfError(std::string("CalculateDiagnostics: ") + gh_nbody_last_error(nbody));
+      for (int i = 0; i < Nstar; i++) {
+        double vv = 0.0;
+        for (int k = 0; k < ndim; k++) vv += sv[(size_t) i*ndim + k]*sv[(size_t) i*ndim + k];
+        mtot += sm[i]; ketot += sm[i]*vv; gpetot -= sm[i]*sg[i];
+        for (int k = 0; k < ndim; k++) {
+          rcom[k] += sm[i]*sr[(size_t) i*ndim + k]; vcom[k] += sm[i]*sv[(size_t) i*ndim + k];
+          mom[k] += sm[i]*sv[(size_t) i*ndim + k]; force[k] += sm[i]*sa[(size_t) i*ndim + k];
+        }
+        add_angmom(sm[i], &sr[(size_t) i*ndim], &sv[(size_t) i*ndim]);
+      }
+    }
+    int ns = 0;
+    gh_get_sinks(ctx, &ns, nullptr, nullptr);
+    if (ns > 0) {
+      std::vector<double> rec((size_t) ns*GH_SINK_NREC);
+      gh_get_sinks(ctx, &ns, rec.data(), nullptr);
+      for (int s = 0; s < ns; s++) for (int k = 0; k < 3; k++) angmom[k] += rec[(size_t) s*GH_SINK_NREC + 12 + k];
+    }
+  }
+  ketot *= 0.5; gpetot *= 0.5;
+  double Etot = ketot;
+  if (mtot > 0) for (int k = 0; k < ndim; k++) { rcom[k] /= mtot; vcom[k] /= mtot; }
+  if (cfg.hydro_forces == 1) Etot += utot;
+  if (cfg.self_gravity == 1 || Nstar > 0) Etot += gpetot;
+  int clk[4] = {0, 0, 0, 0}; double dtm = 0.0;
+  if (cfg.Nlevels > 1) gh_get_block_clock(ctx, clk, &dtm);
+  int q = 0;
+  o[q++] = t; o[q++] = Nsteps; o[q++] = timestep;
+  o[q++] = timestep;                                       // dt_min_hydro (the device keeps the minimum over both species only)
+  o[q++] = Nstar > 0 ? timestep : 9.9e50;                  // dt_min_nbody
+  o[q++] = clk[2]; o[q++] = N; o[q++] = Nstar; o[q++] = Ndead; o[q++] = mtot; o[q++] = Etot; o[q++] = ketot; o[q++] = utot; o[q++] = gpetot;
+  for (int k = 0; k < 3; k++) o[q++] = angmom[k];
+  for (int k = 0; k < 3; k++) o[q++] = rcom[k];
+  for (int k = 0; k < 3; k++) o[q++] = vcom[k];
+  for (int k = 0; k < 3; k++) o[q++] = mom[k];
+  for (int k = 0; k < 3; k++) o[q++] = force[k];
+}
+
+void SphSimulation::RecordDiagnostics(const std::string &filename)
+{
+  double o[29];
+  CalculateDiagnostics(o);
+  std::ofstream outfile(filename.c_str(), std::ofstream::app);
+  if (!outfile) throw GandalfError("cannot open " + filename);
+  outfile << o[0] << "     " << (int) o[1] << "      " << o[2] << "      " << o[3] << "      " << o[4] << "      " << (int) o[5] << "      ";
+  outfile << (int) o[6] << "     " << (int) o[7] << "     " << (int) o[8] << "     ";
+  for (int q = 9; q < 14; q++) outfile << o[q] << "     ";
+  for (int k = 0; k < 3; k++) outfile << o[14 + k] << "     ";
+  for (int k = 0; k < ndim; k++) outfile << o[17 + k] << "     ";
+  for (int k = 0; k < ndim; k++) outfile << o[20 + k] << "     ";
+  for (int k = 0; k < ndim; k++) outfile << o[23 + k] << "     ";
+  for (int k = 0; k < ndim; k++) outfile << o[26 + k] << "     ";
+  outfile << std::endl;
+}
+
+void SphSimulation::WriteTimingStatistics(const std::string &filename)
+{
+  if (!ctx) throw GandalfError("WriteTimingStatistics: no device context");
+  double ms[GH_T_COUNT];
+  if (gh_get_timers(ctx, ms, nullptr, nullptr)) throw GandalfError(gh_last_error(ctx));
+  struct timeval tv; gettimeofday(&tv, 0);
+  const double ttot = (tv.tv_sec + 1e-6*tv.tv_usec) - wall_start;
+  const char *names[GH_T_COUNT] = {"BUILD_TREE", "SPH_PROPERTIES", cfg.self_gravity ? "SPH_ALL_FORCES" : "SPH_HYDRO_FORCES", "SPH_LFKDK", "GRAV_INTERACTION_LISTS"};
+  std::ofstream outfile(filename.c_str());
+  if (!outfile) throw GandalfError("cannot open " + filename);
+  const std::string bar(100, '-');
+  auto row = [&](const std::string &name, double tw) {
+    outfile << std::setw(40) << std::left << name << std::setw(15) << tw << std::setw(15) << 100.0*tw/ttot << std::setw(15) << tw << std::setw(15) << 100.0*tw/ttot << std::endl;
+  };
+  outfile << bar << std::endl << "Total simulation wall clock time : " << ttot << std::endl << "Threads: Total=1, OpenMP=1  (device phases timed with HIP events)" << std::endl << bar << std::endl;
+  outfile << "Level : 1" << std::endl << std::setw(40) << std::left << "Block" << std::setw(15) << "Max Wall time" << std::setw(15) << "%time" << std::setw(15) << "Av. CPU Time" << std::setw(15) << "%time" << std::endl << bar << std::endl;
+  double acc = 0.0;
+  for (int k = 0; k < GH_T_COUNT; k++) { if (k == 4 && !cfg.self_gravity) continue; row(names[k], 1e-3*ms[k]); acc += 1e-3*ms[k]; }
+  row("REMAINDER", ttot - acc);
+  outfile << bar << std::endl;
 }

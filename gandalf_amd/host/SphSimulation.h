@@ -72,6 +72,10 @@ class SphSimulation {
   void Run(int Nadvance = -1);             // Simulation.cpp:382
   void Download(int field, std::vector<double> &out);
   void WriteSnapshotFile(const std::string &filename, const std::string &fileform);   // SimulationIO.hpp:96
+  void CalculateDiagnostics(double *out29);        // SimAnalysis.hpp:52-200 (returns the numbers of one .diag line)
+  void RecordDiagnostics(const std::string &filename);   // SimAnalysis.hpp:262-300: appends one line of <run_id>.diag
+  void WriteTimingStatistics(const std::string &filename);   // CodeTiming::ComputeTimingStatistics (CodeTiming.cpp:238-420): <run_id>.timing
+  double wall_start = 0.0;
 
   int ndim;
   Parameters *simparams;

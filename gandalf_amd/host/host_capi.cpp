@@ -79,6 +79,17 @@ double gah_time(gah_sim *s) { return s->sim->t; }
 double gah_timestep(gah_sim *s) { return s->sim->timestep; }
 gh_ctx *gah_ctx(gah_sim *s) { return s->sim ? s->sim->ctx : nullptr; }
 int gah_write_snapshot(gah_sim *s, const char *filename, const char *fileform) { GAH_TRY(s, s->sim->WriteSnapshotFile(filename, fileform)) }
+// Simulation::CalculateDiagnostics + RecordDiagnostics (<run_id>.diag line; out29 may be NULL, filename may be NULL)
+int gah_diagnostics(gah_sim *s, double *out29, const char *filename)
+{
+  GAH_TRY(s, {
+    double tmp[29];
+    if (filename) s->sim->RecordDiagnostics(filename);
+    if (out29 || !filename) { s->sim->CalculateDiagnostics(out29 ? out29 : tmp); }
+  })
+}
+// CodeTiming::ComputeTimingStatistics (<run_id>.timing)
+int gah_write_timing(gah_sim *s, const char *filename) { GAH_TRY(s, s->sim->WriteTimingStatistics(filename)) }
 
 // ---- snapshot files without a simulation object (SnapshotIO.h); header = {Noutsnap, Nsteps, Noutlitesnap},
 //      hd = {tsnaplast, mmean, tlitesnaplast, h_fac}

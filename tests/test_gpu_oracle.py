@@ -343,3 +343,33 @@ def test_sinks_64k_vs_oracle():
     assert len(sk["radius"]) == len(so["radius"]) >= 1
     assert np.array_equal(sk["Ngas"], so["Ngas"]) and np.array_equal(sk["istar"], so["istar"])
     assert np.max(np.abs(sk["menc"] - so["menc"])/so["menc"]) < 1e-9
+
+
+def test_diag_and_timing_files(tmp_path):
+    """<run_id>.diag (Simulation::CalculateDiagnostics / RecordDiagnostics, SimAnalysis.hpp:52-300) and <run_id>.timing
+    (CodeTiming::ComputeTimingStatistics) from the host shell: the .diag line after the setup of the Boss-Bodenheimer case against
+    the line the reference wrote for the same setup (tests/golden/bb_sinks_8k_setup.diag: six significant digits), and the
+    layout of the timing table"""
+    from gandalf_amd.host import Simulation
+    sim = Simulation("%s/bb_sinks_8k.dat" % PARAMS)
+    sim.setup()
+    f = str(tmp_path/"BB.diag")
+    d = sim.diagnostics(f)
+    ours = [float(x) for x in open(f).read().split()]
+    ref = [float(x) for x in open(os.path.join(os.path.dirname(__file__), "golden", "bb_sinks_8k_setup.diag")).read().split()]
+    assert len(ours) == len(ref) == 29
+    scale = {14: 0.3, 15: 0.3, 16: 0.3}                      # angular momentum components share the scale of the largest
+    for i, (a, b) in enumerate(zip(ours, ref)):
+        if i in (17, 18, 19, 20, 21, 22, 23, 24, 25):        # centre of mass / momentum: zero to rounding (com_frame = 1)
+            assert abs(a) < 1e-12 and abs(b) < 1e-12, i
+        elif i in (26, 27, 28):                              # net force: tree-force error, not conserved exactly
+            assert abs(a - b) < 2e-9, (i, a, b)
+        else:
+            assert abs(a - b) <= 2e-6*max(abs(b), scale.get(i, 0.0)), (i, a, b)
+    assert d["Nhydro"] == 8000 and d["Ndead"] == 0 and abs(d["Etot"] - (d["ketot"] + d["utot"] + d["gpetot"])) < 1e-14
+    sim.main_loop(3)
+    t = str(tmp_path/"BB.timing")
+    sim.write_timing(t)
+    txt = open(t).read()
+    for key in ["Total simulation wall clock time", "Level : 1", "Block", "BUILD_TREE", "SPH_PROPERTIES", "SPH_ALL_FORCES", "REMAINDER"]:
+        assert key in txt, key
