@@ -186,18 +186,57 @@ void SphSimulation::GenerateIC()
   sph->AllocateMemory(std::max(N, 1));
   HydroParticles &p = sph->part;
   if (ic == "box") {
+    // UniformIc::Generate (UniformIc.cpp:50-131): random positions, or a cubic / hexagonal lattice of Nlattice1[] points
+    // scaled to the x extent of the box (Ic::AddCubicLattice / AddHexagonalLattice with normalise = true, Ic.cpp:641-768)
     if (ip["dimensionless"] == 0) throw GandalfError("dimensionless units required");
-    if (sp["particle_distribution"] != "random") throw GandalfError("Invalid particle distribution option");
+    const std::string dist = sp["particle_distribution"];
     double volume = 1.0;
     for (int k = 0; k < ndim; k++) volume *= cfg.boxmax[k] - cfg.boxmin[k];
-    for (int i = 0; i < N; i++)
-      for (int k = 0; k < ndim; k++)
-        p.r[(size_t) i*ndim + k] = cfg.boxmin[k] + (cfg.boxmax[k] - cfg.boxmin[k])*randnumb->floatrand();
+    int Np = N;
+    if (dist == "random") {
+      for (int i = 0; i < N; i++)
+        for (int k = 0; k < ndim; k++)
+          p.r[(size_t) i*ndim + k] = cfg.boxmin[k] + (cfg.boxmax[k] - cfg.boxmin[k])*randnumb->floatrand();
+    }
+    else if (dist == "cubic_lattice" || dist == "hexagonal_lattice") {
+      int Nl[3] = {1, 1, 1};
+      for (int k = 0; k < ndim; k++) Nl[k] = ip["Nlattice1[" + std::to_string(k) + "]"];
+      Np = Nl[0]*Nl[1]*Nl[2];
+      sph->AllocateMemory(std::max(Np, 1));
+      HydroParticles &q = sph->part;
+      const double *bmin = cfg.boxmin;
+      if (dist == "cubic_lattice") {
+        const double spacing = (cfg.boxmax[0] - cfg.boxmin[0])/(double) Nl[0];
+        for (int kk = 0; kk < Nl[2]; kk++) for (int jj = 0; jj < Nl[1]; jj++) for (int ii = 0; ii < Nl[0]; ii++) {
+          const size_t i = (size_t) kk*Nl[0]*Nl[1] + (size_t) jj*Nl[0] + ii;
+          const int idx[3] = {ii, jj, kk};
+          for (int k = 0; k < ndim; k++) q.r[i*ndim + k] = bmin[k] + ((double) idx[k] + 0.5)*spacing;
+        }
+      }
+      else {
+        const double rad = 0.5*(cfg.boxmax[0] - cfg.boxmin[0])/(double) Nl[0];
+        for (int kk = 0; kk < Nl[2]; kk++) for (int jj = 0; jj < Nl[1]; jj++) for (int ii = 0; ii < Nl[0]; ii++) {
+          const size_t i = (size_t) kk*Nl[0]*Nl[1] + (size_t) jj*Nl[0] + ii;
+          if (ndim == 1) q.r[i] = bmin[0] + 0.5*rad + 2.0*(double) ii*rad;
+          else if (ndim == 2) {
+            q.r[i*2] = bmin[0] + 0.5*rad + (2.0*(double) ii + (double) (jj%2))*rad;
+            q.r[i*2 + 1] = bmin[1] + 0.5*sqrt(3.0)*rad + (double) jj*sqrt(3.0)*rad;
+          }
+          else {
+            q.r[i*3] = bmin[0] + 0.5*rad + (2.0*(double) ii + (double) (jj%2) + (double) ((kk + 1)%2))*rad;
+            q.r[i*3 + 1] = bmin[1] + 0.5*sqrt(3.0)*rad + (double) jj*sqrt(3.0)*rad + (double) (kk%2)*rad/sqrt(3.0);
+            q.r[i*3 + 2] = bmin[2] + sqrt(6.0)*rad/3.0 + (double) kk*2.0*sqrt(6.0)*rad/3.0;
+          }
+        }
+      }
+    }
+    else throw GandalfError("Invalid particle distribution option");
+    HydroParticles &q = sph->part;
     const double invndim = 1.0/ndim;
-    for (int i = 0; i < N; i++) {
-      p.m[i] = volume/(double) N;
-      p.h[i] = cfg.h_fac*pow(volume/(double) N, invndim);
-      p.u[i] = 1.5;
+    for (int i = 0; i < Np; i++) {
+      q.m[i] = volume/(double) Np;
+      q.h[i] = cfg.h_fac*pow(volume/(double) Np, invndim);
+      q.u[i] = 1.5;
     }
     initial_h_provided = true;
   }

@@ -67,7 +67,7 @@ def test_boss_bodenheimer_ic_bitwise():
     assert ic["initial_h_provided"]
 
 
-@pytest.mark.parametrize("case", ["box3d_4k", "plummer_4k", "adsod_1d"])
+@pytest.mark.parametrize("case", ["box3d_4k", "plummer_4k", "adsod_1d", "lattice3d_cubic_grav", "lattice3d_hex_grav"])
 def test_ic_generators_bitwise(case):
     from gandalf_amd.host import Simulation
     g = load_golden(case + "_passes")
