@@ -209,6 +209,10 @@ struct gh_ctx {
 #define GH_MAX_RANKS 16
 
 // kernel launch dispatch on (ndim, smoothing kernel): L(ND, KT) is the launch macro of the call site
+#ifdef GH_PROBE_3D_M4
+// development builds (scripts/probe/mkvariant.sh): only the 3-D M4 instantiations, for quick A/B timing of one kernel
+#define GH_DISPATCH(ctx, L) { L(3, 0) }
+#else
 #define GH_DISPATCH(ctx, L)                                                                                  \
   if ((ctx)->cfg.kernel == GH_KERNEL_QUINTIC) {                                                               \
     if ((ctx)->ndim == 1) { L(1, 1) } else if ((ctx)->ndim == 2) { L(2, 1) } else { L(3, 1) }                 \
@@ -222,6 +226,7 @@ struct gh_ctx {
   else {                                                                                                      \
     if ((ctx)->ndim == 1) { L(1, 0) } else if ((ctx)->ndim == 2) { L(2, 0) } else { L(3, 0) }                 \
   }
+#endif
 
 #define GH_CHECK(ctx, call)                                                                   \
   do {                                                                                        \

@@ -722,14 +722,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
   };
   auto hyd_tile = [&](bool valid, int j, int) {
-    const double4 *r = d.hrec + 4*(size_t) (valid ? j : 0);
-    double4 q0 = r[0];
-    double hr2 = r[1].w;
+    // position and mass from the 32-byte pack (consecutive slots of a range share cache lines); the support radius from
+    // the neighbour record (the SoA array does not hold imported halo particles)
+    const int jc = valid ? j : 0;
+    double4 q0 = d.posm[jc];
+    double hr2 = d.hrec[4*(size_t) jc + 1].w;
     if (!valid) { q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0; }
     if (COUNT) n_lcand += valid ? 1 : 0;
     hyd_process(valid, j, q0, hr2);
   };
-  {
+  // Expansion of the (first, count) ranges into 64-candidate tiles.  Usual case (<= GH_RBCAP ranges, < 32*(GH_RBCAP-1)
+  // candidates): one pass over the list leaves, in the ring's storage, the compacted range table (first - slot offset)
+  // and a bit array with the start slot of every range; a tile then finds its ranges with one 64-bit mask read and a
+  // popcount per lane instead of a prefix scan and a binary search per tile.
+  bool hyd_fast = lenh <= GH_RBCAP;
+  int hyd_slots = 0;
+  if (hyd_fast) {
+    int *s_radj = s_ring.first;                       // [k]: first particle of range k minus its first slot
+    unsigned int *s_bits = (unsigned int*) s_ring.cnt; // bit s: slot s starts a range
+    for (int w = lane; w < GH_RBCAP; w += 64) s_bits[w] = 0u;
+    __syncthreads();
+    int kc = 0;
+    for (int c0 = 0; c0 < lenh; c0 += 64) {
+      const int e = c0 + lane;
+      int2 ent = make_int2(0, 0);
+      if (e < lenh) ent = hydl[e];
+      const int c = ent.y > 0 ? ent.y : 0;
+      int inc = c;
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+      const int tot = __shfl(inc, 63, 64);
+      if (hyd_slots + tot > 32*(GH_RBCAP - 2)) { hyd_fast = false; break; }
+      const int excl = hyd_slots + inc - c;
+      const unsigned long long vm = __ballot(c > 0);
+      if (c > 0) {
+        s_radj[kc + __popcll(vm & lt)] = ent.x - excl;
+        atomicOr(&s_bits[excl >> 5], 1u << (excl & 31));
+      }
+      kc += __popcll(vm);
+      hyd_slots += tot;
+    }
+    __syncthreads();
+  }
+  if (hyd_fast) {
+    const int *s_radj = s_ring.first;
+    const unsigned int *s_bits = (const unsigned int*) s_ring.cnt;
+    const unsigned long long le = lt | (1ull << lane);
+    int cbase = -1;                                   // ranges started before this tile, minus one
+    for (int t0 = 0; t0 < hyd_slots; t0 += 64) {
+      const unsigned int lo = s_bits[t0 >> 5], hi = s_bits[(t0 >> 5) + 1];
+      const unsigned long long m = (unsigned long long) lo | ((unsigned long long) hi << 32);
+      const bool valid = t0 + lane < hyd_slots;
+      const int idx = cbase + __popcll(m & le);
+      const int j = valid ? s_radj[idx] + t0 + lane : 0;
+      hyd_tile(valid, j, 0);
+      cbase += __popcll(m);
+    }
+    __syncthreads();
+  }
+  else {
+    __syncthreads();
     RangeState R; R.nrb = 0; R.nslots = 0;
     for (int c0 = 0; c0 < lenh; c0 += 64) {
       const int e = c0 + lane;

@@ -90,9 +90,10 @@ __device__ __forceinline__ double particle_timestep(const DevicePtrs &d, const T
   return ts;
 }
 
-__global__ void k_timestep_partial(DevicePtrs d, TimestepParams tp, double *partial)
+#define GH_TS_THREADS 1024      /* 256 blocks of 16 waves: one wave per SIMD left the kernel latency-bound */
+__global__ __launch_bounds__(GH_TS_THREADS) void k_timestep_partial(DevicePtrs d, TimestepParams tp, double *partial)
 {
-  __shared__ double s[256];
+  __shared__ double s[GH_TS_THREADS];
   double dtmin = 9.9e50;                                   // big_number_dp
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
     if (d.levels && d.sinks && ((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD)) continue;      // Simulation.cpp:1811 (the global-timestep loop, :1696, has no such skip)
@@ -102,7 +103,7 @@ __global__ void k_timestep_partial(DevicePtrs d, TimestepParams tp, double *part
   }
   s[threadIdx.x] = dtmin;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = GH_TS_THREADS/2; off > 0; off >>= 1) {
     if ((int) threadIdx.x < off) s[threadIdx.x] = fmin(s[threadIdx.x], s[threadIdx.x + off]);
     __syncthreads();
   }
@@ -195,7 +196,7 @@ int gh_timestep_impl_extra(gh_ctx *ctx, int nextra)
   tp.courant_mult = ctx->cfg.courant_mult; tp.accel_mult = ctx->cfg.accel_mult; tp.energy_mult = ctx->cfg.energy_mult;
   tp.energy_integration = ctx->cfg.energy_integration; tp.hydro_forces = ctx->cfg.hydro_forces;
   const int nblk = 256;
-  hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev_own(ctx), tp, ctx->redbuf);
+  hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(GH_TS_THREADS), 0, ctx->stream, gh_dev_own(ctx), tp, ctx->redbuf);
   hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, ctx->stream, ctx->redbuf, nblk + nextra, gh_time_dev(ctx));
   { const int rc = gh_dd_min_dt(ctx); if (rc) return rc; }      // multi-GPU: minimum over the ranks (Simulation.cpp:1738)
   hipLaunchKernelGGL(k_set_dt_next, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), gh_time_dev(ctx));
@@ -387,7 +388,7 @@ int gh_block_timesteps_impl(gh_ctx *ctx)
   double *time = gh_time_dev(ctx);
   if (ctx->n == ctx->nresync) {
     const int nblk = 256;
-    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, s, d, fill_tp(ctx), ctx->redbuf);
+    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(GH_TS_THREADS), 0, s, d, fill_tp(ctx), ctx->redbuf);
     hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
     hipLaunchKernelGGL(k_block_resync_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time, ctx->cfg.Nlevels);
     hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time, ctx->cfg.sph_single_timestep);
@@ -420,7 +421,7 @@ int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult)
   int blk[12];
   if (ctx->n == ctx->nresync) {
     const int nblk = 256;
-    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(256), 0, s, d, fill_tp(ctx), ctx->redbuf);
+    hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(GH_TS_THREADS), 0, s, d, fill_tp(ctx), ctx->redbuf);
     hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
     GH_CHECK(ctx, hipMemcpyAsync(tt, time, sizeof(tt), hipMemcpyDeviceToHost, s));
     GH_CHECK(ctx, hipStreamSynchronize(s));

@@ -29,10 +29,11 @@ static const double BIG = 9.9e20;   // reference Constants.h:72 big_number
 // ------------------------------------------------------------------------------------------------
 // root box: min/max over particles of r -/+ kernrange*h           (KDTree.cpp:269-280)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */, int *cellnode0, int node0)
+#define GH_RB_THREADS 1024       /* 256 blocks of 16 waves (4 waves per block left one wave per SIMD: latency-bound) */
+__global__ __launch_bounds__(GH_RB_THREADS) void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /* [nblk][6] */, int *cellnode0, int node0)
 {
   // d is the view of this rank's own particles (all particles on one rank); cellnode0 is shifted likewise
-  __shared__ double s[6][256];
+  __shared__ double s[6][GH_RB_THREADS];
   double mn[3] = {BIG, BIG, BIG}, mx[3] = {-BIG, -BIG, -BIG};
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < d.N; i += gridDim.x*blockDim.x) {
     cellnode0[i] = node0;              // every particle starts in the root cell (of this rank's subtree)
@@ -45,7 +46,7 @@ __global__ void k_rootbox_partial(DevicePtrs d, double kernrange, double *out /*
   }
   for (int k = 0; k < 3; k++) { s[k][threadIdx.x] = mn[k]; s[3 + k][threadIdx.x] = mx[k]; }
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = GH_RB_THREADS/2; off > 0; off >>= 1) {
     if ((int) threadIdx.x < off)
       for (int k = 0; k < 3; k++) {
         s[k][threadIdx.x] = fmin(s[k][threadIdx.x], s[k][threadIdx.x + off]);
@@ -1029,7 +1030,7 @@ int gh_dd_decompose(gh_ctx *ctx);                    // comm.hip: global root bo
 void gh_rootbox_local(gh_ctx *ctx, int node0)
 {
   const int nblk = 256;
-  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev_own(ctx), KERNRANGE_OF(ctx->cfg), ctx->redbuf,
+  hipLaunchKernelGGL(k_rootbox_partial, dim3(nblk), dim3(GH_RB_THREADS), 0, ctx->stream, gh_dev_own(ctx), KERNRANGE_OF(ctx->cfg), ctx->redbuf,
                      ctx->cellnode[0] + ctx->own_first, node0);
   hipLaunchKernelGGL(k_rootbox_final, dim3(1), dim3(64), 0, ctx->stream, ctx->redbuf, nblk, ctx->dbbmin, ctx->dbbmax);
 }
