@@ -452,11 +452,37 @@ __device__ __forceinline__ bool let_may_open(const LetGeom &Q, const CellBox &yb
   return dr2 <= r1*r1*e || dc2 <= r2*r2*e || db2*(1.0 - 1e-12) < yg.cdistsqd;
 }
 
+// periodic domains: the destination's walks also meet Y as its periodic images (density: image codes of the walk,
+// k_dens_walk; hydro: GhostNeighbourFinder::PeriodicBoxOverlap, GhostNeighbours.hpp:202-226) - Y is needed if any image
+// within one box length can be opened.  len[k] = box size of a periodic dimension, 0 otherwise.
+struct LetPeriod { double len[3]; };
+template <int PHASE>
+__device__ __forceinline__ bool let_may_open_img(const LetGeom &Q, const CellBox &yb, const CellH &yh, const CellGeo &yg,
+                                                 int ndim, double kernrange, double widen, const LetPeriod &per)
+{
+  if (let_may_open<PHASE>(Q, yb, yh, yg, ndim, kernrange, widen)) return true;
+  if (per.len[0] == 0.0 && per.len[1] == 0.0 && per.len[2] == 0.0) return false;
+  if (Q.N <= 0) return false;
+  const int n0 = per.len[0] > 0.0 ? 1 : 0, n1 = (ndim > 1 && per.len[1] > 0.0) ? 1 : 0, n2 = (ndim > 2 && per.len[2] > 0.0) ? 1 : 0;
+  for (int i0 = -n0; i0 <= n0; i0++)
+    for (int i1 = -n1; i1 <= n1; i1++)
+      for (int i2 = -n2; i2 <= n2; i2++) {
+        if (i0 == 0 && i1 == 0 && i2 == 0) continue;
+        const double sh[3] = {i0*per.len[0], i1*per.len[1], i2*per.len[2]};
+        CellBox b = yb; CellH h = yh; CellGeo g = yg;
+        for (int k = 0; k < 3; k++) {
+          b.bbmin[k] += sh[k]; b.bbmax[k] += sh[k]; h.hbmin[k] += sh[k]; h.hbmax[k] += sh[k]; g.rcell[k] += sh[k];
+        }
+        if (let_may_open<PHASE>(Q, b, h, g, ndim, kernrange, widen)) return true;
+      }
+  return false;
+}
+
 // grid (2^P, nranks): workgroup (j, r) marks what rank r needs of the subtree below this rank's published bottom
 // cell j, level by level with the visit flags in LDS
 template <int PHASE>
 __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const char *fine_base, size_t fine_stride,
-                                                  int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags)
+                                                  int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags, LetPeriod per)
 {
   const int r = blockIdx.y;
   if (r == self) return;
@@ -504,8 +530,8 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
         if (yb.N > 0) {
           const CellH yh = d.ch[n]; const CellGeo yg = d.cgeo[n];
           for (int qi = 0; qi < nq && !open; qi++) {
-            if (!let_may_open<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen)) continue;
-            for (int f = 0; f < nf && !open; f++) { LetGeom e; let_expand(fine[(size_t) qi*nf + f], e); open = let_may_open<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen); }
+            if (!let_may_open_img<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen, per)) continue;
+            for (int f = 0; f < nf && !open; f++) { LetGeom e; let_expand(fine[(size_t) qi*nf + f], e); open = let_may_open_img<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen, per); }
           }
         }
       }
@@ -655,9 +681,10 @@ extern "C" int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops
   if (ctx->N > 0) return gh_fail(ctx, GH_ERR_INVALID, "gh_comm_init: call before gh_upload_particles");
   if (nranks > 1) {
     const gh_config &c = ctx->cfg;
-    bool open = true;
-    for (int k = 0; k < ctx->ndim; k++) open = open && c.boundary_lhs[k] == GH_BOUNDARY_OPEN && c.boundary_rhs[k] == GH_BOUNDARY_OPEN;
-    if (!open) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: open boundaries only");
+    bool ok = true;                                        // open or periodic (both faces of a dimension alike); no mirrors
+    for (int k = 0; k < ctx->ndim; k++)
+      ok = ok && c.boundary_lhs[k] == c.boundary_rhs[k] && (c.boundary_lhs[k] == GH_BOUNDARY_OPEN || c.boundary_lhs[k] == GH_BOUNDARY_PERIODIC);
+    if (!ok) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: open or periodic boundaries only");
     if (c.Nlevels > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: global timestep only (Nlevels = 1)");
     if (c.self_gravity && c.gravity_mac != GH_MAC_GEOMETRIC) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: gravity_mac = geometric only");
     if (c.avisc == GH_AVISC_MON97CD2010 || c.avisc == GH_AVISC_MON97MM97) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: no time-dependent viscosity");
@@ -857,9 +884,12 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   hipLaunchKernelGGL(k_let_invalidate, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, s, d, L, P, ctx->rank, ctx->Ncell);
   GH_CHECK(ctx, hipMemsetAsync(D->let_cnt, 0, sizeof(int)*8*GH_MAX_RANKS, s));
   const dim3 grid(1 << P, W);
-  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
-  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  LetPeriod per;
+  for (int k = 0; k < 3; k++)
+    per.len[k] = (k < ctx->ndim && ctx->cfg.boundary_lhs[k] == GH_BOUNDARY_PERIODIC) ? ctx->cfg.boxmax[k] - ctx->cfg.boxmin[k] : 0.0;
+  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
+  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
+  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
   // counts to everybody (2 ints per pair), then sizes on the host
   DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*2*GH_MAX_RANKS));
   std::vector<int> all((size_t) W*2*GH_MAX_RANKS);

@@ -80,6 +80,8 @@ def _relerr(a, b):
 CASES = {
     "gravity": ("plummer_4k", {}),                                         # hydro + self-gravity (tree walk with MAC)
     "hydro": ("plummer_4k", {"self_gravity": 0, "run_id": "PLUMHYD"}),      # hydro only (scatter-gather walk)
+    "periodic": ("box3d_4k", {}),                                          # periodic box: the halo selection tests the images too
+    "periodic32k": ("box3d_4k", {"Nhydro": 32768, "run_id": "BOXP32K"}),    # ... with a halo that is a layer, not the whole box
 }
 
 
