@@ -176,8 +176,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_flags, sizeof(int)));
   GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
   GH_CHECK(ctx, hipMalloc((void**) &ctx->d_ptrtab, sizeof(double*)*4*D_COUNT));
-  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_blk, sizeof(int)*16));
-  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
+  GH_CHECK(ctx, hipMalloc((void**) &ctx->d_blk, sizeof(int)*24));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*24));
   if (cfg->kernel == GH_KERNEL_M4_TAB || cfg->kernel == GH_KERNEL_QUINTIC_TAB) { const int rc = gh_build_kernel_tables(ctx); if (rc) return rc; }
   return GH_OK;
 }
@@ -313,7 +313,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->exact_armed = false;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
-  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*16));
+  GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*24));
   return GH_OK;
 }
 

@@ -33,6 +33,7 @@
 // tree order (GradhSphTree.cpp:200-219), hmax being the cell's 1.05^k hmax of the successful ComputeH call.  The flag is
 // cleared if some neighbour j has gpot_j > 1.000000001 gpot_i while the distance of the neighbour BEFORE it in the list
 // (for j = 0: of the last one) lies inside kernrange*h of the last h iteration.
+__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd);
 __global__ void k_potmin(DevicePtrs d, double rho_sink, double kernrangesqd)
 {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;
@@ -41,6 +42,11 @@ __global__ void k_potmin(DevicePtrs d, double rho_sink, double kernrangesqd)
   if (fl & GH_FLAG_DEAD) return;
   if (d.levels && !(fl & GH_FLAG_ACTIVE)) return;
   if (!(d.f[D_RHO][i] >= rho_sink)) return;
+  potmin_serial(d, i, kernrangesqd);
+}
+__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd)
+{
+  const int fl = (int) d.f[D_FLAGS][i];
   const double cull = d.pm_cullsqd[i], invhsqd = d.pm_invhsqd[i];
   const double thr = 1.000000001*d.f[D_GPOT][i];
   double ri[3] = {0.0, 0.0, 0.0};
@@ -79,11 +85,136 @@ __global__ void k_potmin(DevicePtrs d, double rho_sink, double kernrangesqd)
   d.f[D_FLAGS][i] = (double) (pm ? (fl | GH_FLAG_POTMIN) : (fl & ~GH_FLAG_POTMIN));
 }
 
+// The same test with one wavefront per dense particle.  The serial walk above costs one memory latency per node and per
+// candidate (3.4 of the 15 ms of a 262 144-particle sink step); here the ordered list of leaves inside the cull radius is
+// built level by level - lane = node, culled nodes dropped, the others replaced by their two children IN ORDER through a
+// prefix sum (all leaves of the balanced tree sit on the last level) - and the candidates are then taken 8 leaves x 8
+// slots at a time: "the neighbour before me in the list" is the nearest accepted lower lane (ballot), or the last accepted
+// one of the previous chunk.  Same arithmetic, same decisions; a particle whose frontier outgrows the LDS list is left
+// to the serial kernel (mask).
+#define PM_CAP 1536
+__global__ void k_potmin_collect(DevicePtrs d, double rho_sink, int *list, int *count)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  const int fl = (int) d.f[D_FLAGS][i];
+  if (fl & GH_FLAG_DEAD) return;
+  if (d.levels && !(fl & GH_FLAG_ACTIVE)) return;
+  if (!(d.f[D_RHO][i] >= rho_sink)) return;
+  list[atomicAdd(count, 1)] = i;
+}
+
+__global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernrangesqd, const int *list, const int *count, int *redo, int *nredo)
+{
+  __shared__ int s_a[PM_CAP], s_b[PM_CAP];
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int leaf0 = d.gtot - 1;
+  const int ncand = *count;
+  for (int c = blockIdx.x; c < ncand; c += gridDim.x) {
+    const int i = list[c];
+    const int fl = (int) d.f[D_FLAGS][i];
+    const double cull = d.pm_cullsqd[i], invhsqd = d.pm_invhsqd[i];
+    const double thr = 1.000000001*d.f[D_GPOT][i];
+    double ri[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < d.ndim; k++) ri[k] = d.f[D_RX + k][i];
+    int *cur = s_a, *nxt = s_b;
+    int ncur = 1;
+    bool overflow = false;
+    __syncthreads();
+    if (lane == 0) cur[0] = 0;
+    __syncthreads();
+    // levels 0 .. ltot: cull, expand in order; after the last round `cur` holds the kept leaves
+    for (int lev = 0; lev <= d.ltot && !overflow; lev++) {
+      int nout = 0;
+      for (int c0 = 0; c0 < ncur; c0 += 64) {
+        const int e = c0 + lane;
+        int n = 0, cnt = 0;
+        if (e < ncur) {
+          n = cur[e];
+          const CellBox b = d.cbox[n];
+          if (b.N > 0) {
+            double md = 0.0;
+            for (int k = 0; k < d.ndim; k++) {
+              const double x = ri[k] < b.bbmin[k] ? b.bbmin[k] - ri[k] : (ri[k] > b.bbmax[k] ? ri[k] - b.bbmax[k] : 0.0);
+              md += x*x;
+            }
+            if (!(md*(1.0 - 1e-12) > cull)) cnt = n >= leaf0 ? 1 : 2;
+          }
+        }
+        int inc = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+        const int tot = __shfl(inc, 63, 64);
+        if (nout + tot > PM_CAP) { overflow = true; break; }
+        const int pos = nout + inc - cnt;
+        if (cnt == 1) nxt[pos] = n;
+        else if (cnt == 2) { nxt[pos] = 2*n + 1; nxt[pos + 1] = 2*n + 2; }
+        nout += tot;
+      }
+      __syncthreads();
+      int *t = cur; cur = nxt; nxt = t;
+      ncur = nout;
+    }
+    if (overflow) {
+      if (lane == 0) redo[atomicAdd(nredo, 1)] = i;
+      continue;
+    }
+    // candidates in list order: 8 leaves x 8 slots per round
+    bool pm = true, have_first = false;
+    double d2_prev = 0.0, g_first = 0.0;
+    for (int l0 = 0; l0 < ncur; l0 += 8) {
+      const int li = l0 + (lane >> 3), t = lane & 7;
+      bool acc = false;
+      double d2 = 0.0, gj = 0.0;
+      if (li < ncur) {
+        const CellBox b = d.cbox[cur[li]];
+        if (t < b.N) {
+          const int j = b.first + t;
+          for (int k = 0; k < d.ndim; k++) { const double dx = d.f[D_RX + k][j] - ri[k]; d2 += dx*dx; }
+          acc = d2 + SK_SMALL <= cull;
+          gj = d.f[D_GPOT][j];
+        }
+      }
+      const unsigned long long am = __ballot(acc);
+      if (am) {
+        const unsigned long long below = am & lt;
+        const int prevlane = below ? 63 - __clzll((long long) below) : 0;
+        const double d2p_lane = __shfl(d2, prevlane, 64);
+        const double d2p = below ? d2p_lane : d2_prev;
+        const int firstlane = __ffsll((long long) am) - 1;
+        const bool is_first = !have_first && lane == firstlane;
+        const bool fail = acc && !is_first && gj > thr && d2p*invhsqd < kernrangesqd;
+        if (__any(fail)) pm = false;
+        if (!have_first) { g_first = __shfl(gj, firstlane, 64); have_first = true; }
+        d2_prev = __shfl(d2, 63 - __clzll((long long) am), 64);
+      }
+    }
+    if (have_first && g_first > thr && d2_prev*invhsqd < kernrangesqd) pm = false;
+    if (lane == 0) d.f[D_FLAGS][i] = (double) (pm ? (fl | GH_FLAG_POTMIN) : (fl & ~GH_FLAG_POTMIN));
+  }
+}
+
+// the serial test for the particles the wave kernel left (frontier larger than its list)
+__global__ void k_potmin_redo(DevicePtrs d, double kernrangesqd, const int *redo, const int *nredo)
+{
+  const int n = *nredo;
+  for (int c = blockIdx.x*blockDim.x + threadIdx.x; c < n; c += gridDim.x*blockDim.x) potmin_serial(d, redo[c], kernrangesqd);
+}
+
 int gh_sinks_potmin(gh_ctx *ctx)
 {
   if (!ctx->cfg.sink_particles || ctx->cfg.create_sinks != 1) return GH_OK;
   const double krs = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 9.0 : 4.0;
-  hipLaunchKernelGGL(k_potmin, dim3(cdiv(ctx->N, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, krs);
+  // scratch: candidate list and redo list in the (otherwise idle) sort-value buffer, two counters behind the block clock
+  int *list = ctx->P[0][0], *redo = ctx->P[0][1], *cnt = ctx->d_blk + 16;
+  if (!list || !redo || getenv("GH_POTMIN_SERIAL")) {
+    hipLaunchKernelGGL(k_potmin, dim3(cdiv(ctx->N, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, krs);
+    return GH_OK;
+  }
+  GH_CHECK(ctx, hipMemsetAsync(cnt, 0, 2*sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_potmin_collect, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, list, cnt);
+  hipLaunchKernelGGL(k_potmin_wave, dim3(8192), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, list, cnt, redo, cnt + 1);
+  hipLaunchKernelGGL(k_potmin_redo, dim3(256), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, redo, cnt + 1);
   return GH_OK;
 }
 
