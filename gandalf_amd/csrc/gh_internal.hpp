@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include "../../include/gandalf_hip.h"
 
 #define GH_WAVE 64
@@ -132,6 +133,7 @@ struct gh_ctx {
   int ltot = 0, gtot = 0, Ncell = 0, lgroup = 0, ngroups = 0, leafocc = 0;
   int64_t tree_layout_N = -1;
   std::vector<int> h_cfirst, h_cN, h_cleft;
+  std::unordered_map<void*, size_t> tree_bytes;   // capacity of every buffer gh_alloc_tree owns, keyed by the address of its pointer
   int *cfirst = nullptr, *cN = nullptr, *cleft = nullptr;
   CellBox *cbox = nullptr;
   CellH *ch = nullptr;

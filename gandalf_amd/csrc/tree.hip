@@ -948,7 +948,17 @@ int gh_alloc_tree(gh_ctx *ctx)
     if (ctx->lsub < L) ctx->lsub = L;
   }
 
-  auto re = [&](void **p, size_t bytes) -> hipError_t { if (*p) (void) hipFree(*p); *p = nullptr; return hipMalloc(p, bytes); };
+  // buffers are kept while they are large enough: in a sink run N shrinks by a few particles whenever gas is accreted, the
+  // cell count stays, and a hipFree + hipMalloc per array (each a device synchronisation) cost 1.4 ms of such a step
+  auto re = [&](void **p, size_t bytes) -> hipError_t {
+    size_t &have = ctx->tree_bytes[(void*) p];
+    if (*p && have >= bytes) return hipSuccess;
+    if (*p) (void) hipFree(*p);
+    *p = nullptr; have = 0;
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+  };
   GH_CHECK(ctx, re((void**) &ctx->cfirst, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cN, sizeof(int)*Ncell));
   GH_CHECK(ctx, re((void**) &ctx->cleft, sizeof(int)*Ncell));
