@@ -33,6 +33,7 @@
 #define DD_G 2048            /* histogram bins per refinement of a median search */
 #define DD_CAPL 2048         /* candidates per rank and cell gathered in the final bin */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
+#define DD_VIS 16384         /* leaves below one published bottom cell that k_let_mark can flag (1M particles on 2 ranks: 4 096) */
 #define DD_FMAX 6            /* halo selection: 2^F fine geometry entries per published bottom cell */
 #define DD_REC 43            /* doubles per migrating particle: D_COUNT_BASE fields + iorig */
 
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
   const int r = blockIdx.y;
   if (r == self) return;
   __shared__ LetGeom s_q[1 << DD_PMAX];
-  __shared__ unsigned char s_vis[2][2048];
+  __shared__ unsigned char s_vis[2][DD_VIS];
   const int nq = 1 << P, nf = 1 << F;
   const LetGeomF *fine = (const LetGeomF*) (fine_base + (size_t) r*fine_stride);
   if ((int) threadIdx.x < nq) {
@@ -879,7 +880,8 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   hipStream_t s = ctx->stream;
   DevicePtrs d = gh_dev(ctx);
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
-  if (ctx->ltot - (L + P) > 11) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU: subtree below the published levels deeper than 11 levels");
+  if (((size_t) 1 << (ctx->ltot - (L + P))) > (size_t) DD_VIS)
+    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU: more than DD_VIS leaves below a published cell (k_let_mark keeps one visit flag per cell of a level in LDS)");
   if (phase == GH_HALO_DENSITY && widen != D->fine_widen) { const int rc = dd_publish_fine(ctx, widen); if (rc) return rc; }
   hipLaunchKernelGGL(k_let_invalidate, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, s, d, L, P, ctx->rank, ctx->Ncell);
   GH_CHECK(ctx, hipMemsetAsync(D->let_cnt, 0, sizeof(int)*8*GH_MAX_RANKS, s));

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""W ranks of the domain-decomposed path inside ONE process, one thread per rank, all contexts on GPU 0.
+
+A one-GPU box allows at most 6 processes on the card, so the 8-rank case of the scaling bench cannot be rehearsed with
+one process per rank.  The library only asks its host for two collectives over device buffers (gh_comm_ops); here they
+are device-to-device copies between the ranks' buffers behind a thread barrier.  Functional check only (results of W
+ranks against the one-rank run), never a measurement.
+
+    python scripts/probe/threaded_ranks.py 8 65536 [nsteps] [params]
+"""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gandalf_amd.host import Simulation                                   # noqa: E402
+from gandalf_amd.multigpu import _ALLGATHER_T, _ALLTOALLV_T, _OpsStruct, _DevPtr   # noqa: E402
+
+
+class Shared:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.send = [0]*world
+        self.sbytes = [None]*world
+        self.errors = []
+
+
+def dev_view(ptr, nbytes):
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda:0")
+    return torch.as_tensor(_DevPtr(ptr, nbytes), device="cuda:0")
+
+
+class ThreadOps:
+    def __init__(self, shared, rank):
+        self.sh, self.rank = shared, rank
+        self._ag = _ALLGATHER_T(self._allgather)
+        self._a2a = _ALLTOALLV_T(self._alltoallv)
+        self.struct = _OpsStruct(None, self._ag, self._a2a)
+        self.ptr = C.addressof(self.struct)
+
+    def _allgather(self, user, send, recv, nbytes, stream):
+        try:
+            sh, W = self.sh, self.sh.world
+            torch.cuda.synchronize()
+            sh.send[self.rank] = int(send)
+            sh.barrier.wait()
+            out = dev_view(recv, nbytes*W)
+            for r in range(W):
+                out[r*nbytes:(r + 1)*nbytes].copy_(dev_view(sh.send[r], nbytes))
+            torch.cuda.synchronize()
+            sh.barrier.wait()
+            return 0
+        except Exception as e:          # noqa: BLE001
+            self.sh.errors.append(e)
+            return 1
+
+    def _alltoallv(self, user, send, send_bytes, recv, recv_bytes, stream):
+        try:
+            sh, W = self.sh, self.sh.world
+            torch.cuda.synchronize()
+            sh.send[self.rank] = int(send)
+            sh.sbytes[self.rank] = [int(send_bytes[r]) for r in range(W)]
+            rb = [int(recv_bytes[r]) for r in range(W)]
+            sh.barrier.wait()
+            out = dev_view(recv, sum(rb))
+            ro = 0
+            for r in range(W):
+                sb = sh.sbytes[r]
+                assert sb[self.rank] == rb[r], ("block size mismatch", r, self.rank, sb[self.rank], rb[r])
+                if rb[r] > 0:
+                    so = sum(sb[:self.rank])
+                    out[ro:ro + rb[r]].copy_(dev_view(sh.send[r] + so, rb[r]))
+                ro += rb[r]
+            torch.cuda.synchronize()
+            sh.barrier.wait()
+            return 0
+        except Exception as e:          # noqa: BLE001
+            self.sh.errors.append(e)
+            try:
+                self.sh.barrier.abort()
+            except Exception:           # noqa: BLE001
+                pass
+            return 1
+
+
+def run(world, N, nsteps, params):
+    over = {"Nhydro": N, "run_id": "THR%d" % world}
+    sims = []
+    for r in range(world):
+        sim = Simulation(os.path.join(ROOT, "tests", "params", params + ".dat"), **over)
+        sim.generate_ic()
+        sims.append(sim)
+    shared = Shared(world)
+    ops = [ThreadOps(shared, r) for r in range(world)]
+    out = [None]*world
+    fail = []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            sim = sims[r]
+            if world > 1:
+                sim.init_comm(r, world, ops[r].ptr)
+            sim.post_ic_setup()
+            if nsteps > 0:
+                sim.main_loop(nsteps)
+            dev = sim.device()
+            out[r] = {k: np.nan_to_num(dev.download(k), nan=0.0) for k in ("h", "rho", "a", "gpot", "dudt")}
+            out[r]["info"] = dev.comm_info()
+        except Exception as e:          # noqa: BLE001
+            fail.append((r, e))
+            try:
+                shared.barrier.abort()
+            except Exception:           # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if fail or shared.errors:
+        raise RuntimeError("ranks failed: %r %r" % (fail, shared.errors))
+    res = {k: sum(o[k] for o in out) for k in ("h", "rho", "a", "gpot", "dudt")}     # every particle is owned by one rank
+    return res, [o["info"] for o in out]
+
+
+def relerr(a, b):
+    mag = np.abs(a) if a.ndim == 1 else np.linalg.norm(a, axis=1)
+    scale = np.maximum(mag, mag.mean())
+    diff = np.abs(a - b) if a.ndim == 1 else np.linalg.norm(a - b, axis=1)
+    return float(np.max(diff/scale)) if np.any(scale > 0) else float(np.max(np.abs(b)))
+
+
+def main():
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    params = sys.argv[4] if len(sys.argv) > 4 else "plummer_4k"
+    one, _ = run(1, N, nsteps, params)
+    many, info = run(world, N, nsteps, params)
+    errs = {k: relerr(one[k], many[k]) for k in one}
+    own = [int(i[1]) for i in info]
+    held = [int(i[2]) for i in info]
+    print("world %d N %d steps %d %s: max rel err vs one rank %s" % (world, N, nsteps, params, {k: "%.2e" % v for k, v in errs.items()}))
+    print("own", own, "held", held)
+    assert all(v <= 1e-13 for v in errs.values()), errs
+    print("OK")
+
+
+if __name__ == "__main__":
+    main()

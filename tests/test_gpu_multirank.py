@@ -99,6 +99,18 @@ def test_ranks_equal_one_rank(case, world, tmp_path):
         assert _relerr(a, b) <= 1e-13, (k, _relerr(a, b))
 
 
+def test_two_ranks_at_the_benchmark_size(tmp_path):
+    """configs[2] itself (1 048 576-particle Plummer sphere) on 2 ranks: 4 096 leaves below every published cell of a rank's
+    subtree - the deepest marking walk of the halo selection any of the 2 / 4 / 8-rank runs of the scaling bench needs
+    (a fixed 2 048-flag array refused exactly this case) - equal to the one-rank run after setup + 1 step."""
+    over = {"Nhydro": 1048576, "run_id": "PLUM1M2R"}
+    one = _run(tmp_path, "plummer_4k", 1, 1, over)
+    two = _run(tmp_path, "plummer_4k", 2, 1, over)
+    assert np.all(two["info"][:, 0] == 1048576//2)
+    for k in ("h", "rho", "a", "gpot", "dudt"):
+        assert _relerr(one[k], two[k]) <= 1e-13, (k, _relerr(one[k], two[k]))
+
+
 def test_ranks_hold_only_their_share(tmp_path):
     """65 536-particle uniform cube (open boundaries, self-gravity) on 2 and 4 ranks: every rank owns N / world particles
     and holds, with the imported halo, well under the whole set (the replicated scheme of round 1 held N on every rank).
