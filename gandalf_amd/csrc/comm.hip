@@ -482,7 +482,7 @@ __device__ __forceinline__ bool let_may_open_img(const LetGeom &Q, const CellBox
 // grid (2^P, nranks): workgroup (j, r) marks what rank r needs of the subtree below this rank's published bottom
 // cell j, level by level with the visit flags in LDS
 template <int PHASE>
-__global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const char *fine_base, size_t fine_stride,
+__global__ __launch_bounds__(1024) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const char *fine_base, size_t fine_stride,
                                                   int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags, LetPeriod per)
 {
   const int r = blockIdx.y;
@@ -524,15 +524,42 @@ __global__ __launch_bounds__(256) void k_let_mark(DevicePtrs d, int L, int P, in
       const int k = k0 + threadIdx.x;
       bool vis = false, open = false;
       int n = 0;
+      bool test = false;
       if (k < nn && s_vis[cur][k]) {
         vis = true;
         n = nbase + k;
-        const CellBox yb = d.cbox[n];
-        if (yb.N > 0) {
-          const CellH yh = d.ch[n]; const CellGeo yg = d.cgeo[n];
-          for (int qi = 0; qi < nq && !open; qi++) {
-            if (!let_may_open_img<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen, per)) continue;
-            for (int f = 0; f < nf && !open; f++) { LetGeom e; let_expand(fine[(size_t) qi*nf + f], e); open = let_may_open_img<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen, per); }
+        // a visited leaf travels whether or not its particles would be touched (below): no opening test on the last level,
+        // where half of all cells sit and where an exhaustive "no" is the usual answer
+        test = d.cbox[n].N > 0 && !(leaflevel && t > 0);
+      }
+      // the opening test of one node is shared by the wave: lane = published cell of the destination for the coarse test,
+      // lane = fine entry of one published cell for the fine test (one coalesced read per round).  One thread per node with
+      // the fine entries in a serial early-exit loop was latency-bound: 75 ms per launch for 1M particles on 2 ranks.
+      {
+        const int lanei = threadIdx.x & 63;
+        unsigned long long tm = __ballot(test);
+        while (tm) {
+          const int j = __ffsll((long long) tm) - 1;
+          tm &= tm - 1ull;
+          const int nj = __shfl(n, j, 64);
+          const CellBox yb = d.cbox[nj]; const CellH yh = d.ch[nj]; const CellGeo yg = d.cgeo[nj];
+          bool cpass = false;
+          for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int qi = q0 + lanei;
+            if (qi < nq) cpass = let_may_open_img<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen, per);
+            unsigned long long cm = __ballot(cpass);
+            bool any = false;
+            while (cm && !any) {
+              const int qq = q0 + __ffsll((long long) cm) - 1;
+              cm &= cm - 1ull;
+              bool o = false;
+              for (int f0 = 0; f0 < nf; f0 += 64) {
+                const int f = f0 + lanei;
+                if (f < nf) { LetGeom e; let_expand(fine[(size_t) qq*nf + f], e); o = o || let_may_open_img<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen, per); }
+              }
+              any = __any(o);
+            }
+            if (any) { if (lanei == j) open = true; break; }
           }
         }
       }
@@ -889,9 +916,9 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   LetPeriod per;
   for (int k = 0; k < 3; k++)
     per.len[k] = (k < ctx->ndim && ctx->cfg.boundary_lhs[k] == GH_BOUNDARY_PERIODIC) ? ctx->cfg.boxmax[k] - ctx->cfg.boxmin[k] : 0.0;
-  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
-  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
-  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(256), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
+  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
+  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
+  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
   // counts to everybody (2 ints per pair), then sizes on the host
   DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*2*GH_MAX_RANKS));
   std::vector<int> all((size_t) W*2*GH_MAX_RANKS);

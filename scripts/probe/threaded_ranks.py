@@ -12,6 +12,7 @@ import ctypes as C
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 import torch
@@ -100,6 +101,7 @@ def run(world, N, nsteps, params):
     shared = Shared(world)
     ops = [ThreadOps(shared, r) for r in range(world)]
     out = [None]*world
+    wall = [0.0]*world
     fail = []
 
     def work(r):
@@ -110,7 +112,13 @@ def run(world, N, nsteps, params):
                 sim.init_comm(r, world, ops[r].ptr)
             sim.post_ic_setup()
             if nsteps > 0:
+                torch.cuda.synchronize()
+                if world > 1:
+                    shared.barrier.wait()
+                t0 = time.perf_counter()
                 sim.main_loop(nsteps)
+                torch.cuda.synchronize()
+                wall[r] = (time.perf_counter() - t0)/nsteps
             dev = sim.device()
             out[r] = {k: np.nan_to_num(dev.download(k), nan=0.0) for k in ("h", "rho", "a", "gpot", "dudt")}
             out[r]["info"] = dev.comm_info()
@@ -129,6 +137,9 @@ def run(world, N, nsteps, params):
     if fail or shared.errors:
         raise RuntimeError("ranks failed: %r %r" % (fail, shared.errors))
     res = {k: sum(o[k] for o in out) for k in ("h", "rho", "a", "gpot", "dudt")}     # every particle is owned by one rank
+    # all ranks share ONE GPU: the wall time of a step is (roughly) the SUM of the ranks' work plus the harness's device-wide
+    # synchronisations - an upper bound of the mean work per rank when divided by the rank count, not a multi-GPU timing
+    print("world %d: %.2f ms per step on one shared GPU = %.2f ms per rank" % (world, 1e3*max(wall), 1e3*max(wall)/world))
     return res, [o["info"] for o in out]
 
 
