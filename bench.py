@@ -49,23 +49,39 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(workload, verbose=False):
-    """The compiled reference (oracle/_ref/ref_dump, OpenMP) timed on this box's host cores on a bounded
-    sample of the same workload shape.  Reported beside the GPU number, never as part of it."""
+def cpu_baseline(workload, sim=None):
+    """The compiled reference (oracle/_ref/ref_dump, OpenMP) timed on this box's host cores on a bounded sample of the
+    same workload.  Reported beside the GPU number, never as part of it.
+
+    Same-size sample: the state the GPU run has reached is written as a SEREN `su` snapshot
+    (the reference's own format; SnapshotIO.cpp) and the reference starts from it with `ic = file` - it then carries
+    converged smoothing lengths (SimulationIO.hpp:794 sets initial_h_provided), which avoids the reference's ~500 s
+    first density pass from one global h guess at 1M Plummer particles."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
     if not os.path.exists(exe):
         return None
     cores = min(os.cpu_count() or 1, int(os.environ.get("GH_CPU_THREADS", "16")))
-    # bounded samples of the same workload shape: ~10-30 s of CPU work in all (the 1M Plummer setup alone
-    # takes the reference ~500 s on 8 cores because of its first density pass, SURVEY.md section 6)
+    wl = WORKLOADS[workload]
+    n = int(wl["overrides"].get("Nhydro", 4096))
     if workload.startswith("plummer"):
-        par, n, steps, warm = "plummer_4k.dat", 131072, 8, 1
+        steps, warm = (2, 1) if n > 300000 else (8, 1)
         shape = "Plummer gas sphere self-gravity theta=0.5 monopole"
     else:
-        par, n, steps, warm = "box3d_4k.dat", 262144, 10, 1
+        steps, warm = 10, 1
         shape = "uniform-random periodic box, hydro only"
     with tempfile.TemporaryDirectory() as tmp:
-        src = open(os.path.join(ROOT, "tests", "params", par)).read().replace("Nhydro = 4096", "Nhydro = %d" % n)
+        src = open(os.path.join(ROOT, "tests", "params", wl["params"])).read()
+        start = "its own IC generator"
+        if sim is not None and n > 300000:
+            snap = os.path.join(tmp, "state.su")
+            sim.write_snapshot(snap, "su")
+            src = "\n".join(l for l in src.splitlines() if not l.startswith("ic ")) + "\nic = file\nin_file = %s\nin_file_form = su\n" % snap
+            start = "the GPU run's state as an su snapshot (h provided)"
+        else:
+            src = src.replace("Nhydro = 4096", "Nhydro = %d" % n)
+        for k, v in wl["overrides"].items():
+            if k not in ("Nhydro", "run_id"):
+                src = "\n".join(l for l in src.splitlines() if not l.startswith(k + " ")) + "\n%s = %s\n" % (k, v)
         pf = os.path.join(tmp, "p.dat")
         open(pf, "w").write(src)
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
@@ -74,11 +90,12 @@ def cpu_baseline(workload, verbose=False):
         wall = time.time() - t0
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if out.returncode != 0 or not line:
+        sys.stderr.write("cpu_baseline: ref_dump failed (%d): %s\n" % (out.returncode, out.stderr[-500:]))
         return None
     r = json.loads(line[-1])
     return {"value": r["particle_steps_per_s"], "unit": "particle-steps/s", "cores": r["threads"], "kind": "reference",
-            "sample": "%s, N=%d, %d timed steps after %d warm-up (GANDALF reference built -O3 OpenMP by oracle/ref.mk; "
-                      "whole run incl. setup %.0f s)" % (shape, n, steps, warm, wall)}
+            "sample": "%s, N=%d, %d timed steps after %d warm-up, started from %s (GANDALF reference built -O3 OpenMP by "
+                      "oracle/ref.mk, %d threads; whole run incl. setup %.0f s)" % (shape, r["N"], steps, warm, start, r["threads"], wall)}
 
 
 def spawn_ranks(n, argv):
@@ -135,8 +152,16 @@ def main():
     sim.set_param("device", local_rank)
     ic = sim.generate_ic()
     N = ic["r"].shape[0]
-    runner = multigpu.DistributedRunner(sim, rank, world)       # world == 1: plain single-GPU stepping
+    # N > 1: the library's own RCCL binding carries every collective of the stepped loop (csrc/rccl_comm.hip);
+    # GH_COMM=torch routes them through torch.distributed callbacks instead (the gloo rehearsal always does)
+    transport = os.environ.get("GH_COMM", "rccl" if (backend == "nccl" and world > 1) else "torch")
+    runner = multigpu.DistributedRunner(sim, rank, world, transport=transport, device=local_rank)       # world == 1: plain single-GPU stepping
     runner.setup()
+
+    def comm_calls():
+        if runner.ops is None:
+            return {"allgather": 0, "alltoallv": 0, "bytes": 0}
+        return runner.ops.counters() if transport == "rccl" else dict(runner.ops.calls)
 
     def sync():
         torch.cuda.synchronize()
@@ -148,15 +173,27 @@ def main():
     dev = sim.device()
     dev.reset_timers()
     sync()
+    c0 = comm_calls()
     t0 = time.perf_counter()
     runner.steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    c1 = comm_calls()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     timers, dst, fst = dev.timers()
+    # per-rank device time of the walk + evaluation phases: max / mean over the ranks is the work imbalance of the
+    # count-balanced decomposition (the reference balances on measured work, MpiKDTreeDecomposition.cpp:282-360)
+    imbalance = None
+    if world > 1:
+        mine = {k: float(v)/args.steps for k, v in timers.items()}
+        allt = [None]*world
+        dist.all_gather_object(allt, mine)
+        work = [t.get("SPH_PROPERTIES", 0.0) + t.get("GRAV_WALK", 0.0) + t.get("SPH_FORCES", 0.0) for t in allt]
+        imbalance = {"work_ms_per_rank": work, "max_over_mean": max(work)/(sum(work)/world) if sum(work) > 0 else None,
+                     "phase_ms_per_rank": allt}
 
     # ---- roofline accounting.  Interaction counts come from the kernels' own counters (one
     #      instrumented pass on the final state), durations from the HIP events the library records on its stream
@@ -240,9 +277,14 @@ def main():
             "phase_ms_per_step": {k: v/args.steps for k, v in timers.items()},
             "counters": {"density": dens, "forces": forc},
         }
+        if world > 1:
+            out["multi_gpu"] = {"transport": "RCCL bound natively in libgandalf_hip.so (ncclAllGather, grouped ncclSend/ncclRecv)" if transport == "rccl"
+                                else "torch.distributed callbacks (%s)" % backend,
+                                "collectives_per_step": {k: (c1[k] - c0[k])/args.steps for k in ("allgather", "alltoallv")},
+                                "bytes_per_step": (c1["bytes"] - c0["bytes"])/args.steps, "imbalance": imbalance}
         if world > 1 and backend != "nccl":
             out["note"] = "REHEARSAL: %d ranks sharing one GPU over gloo - not a measurement" % world
-        cb = None if (args.no_cpu or world > 1) else cpu_baseline(args.workload)
+        cb = None if (args.no_cpu or world > 1) else cpu_baseline(args.workload, sim)
         out["cpu_baseline"] = cb
         print(json.dumps(out))
     if world > 1:

@@ -112,6 +112,15 @@ SYMBOLS = {
     "gh_nbody_num_stars": (C.c_int64, [_CTX]),
     "gh_nbody_download_scalar": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_hybrid_setup": (C.c_int, [_CTX, _CTX, C.c_int, _PD]),
+    # native RCCL transport (csrc/rccl_comm.hip)
+    "gh_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "gh_rccl_create": (C.c_int, [C.POINTER(_CTX), C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "gh_rccl_create_all": (C.c_int, [C.POINTER(_CTX), C.c_int, _PI]),
+    "gh_rccl_ops": (C.c_void_p, [_CTX]),
+    "gh_rccl_last_error": (C.c_char_p, [_CTX]),
+    "gh_rccl_load_error": (C.c_char_p, []),
+    "gh_rccl_counters": (C.c_int, [_CTX, _PL, _PL, _PL, C.c_int]),
+    "gh_rccl_destroy": (None, [_CTX]),
 }
 
 _lib = None

@@ -32,8 +32,9 @@
 
 #define DD_G 2048            /* histogram bins per refinement of a median search */
 #define DD_CAPL 2048         /* candidates per rank and cell gathered in the final bin */
+#define DD_WCAP 512          /* speculative splits: candidates per rank and cell inside the window around last step's median */
+#define DD_WHDR 4            /* ... header slots of a rank's block (the rank's particle extent rides in them) */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
-#define DD_VIS 16384         /* leaves below one published bottom cell that k_let_mark can flag (1M particles on 2 ranks: 4 096) */
 #define DD_FMAX 6            /* halo selection: 2^F fine geometry entries per published bottom cell */
 #define DD_REC 43            /* doubles per migrating particle: D_COUNT_BASE fields + iorig */
 
@@ -49,6 +50,7 @@ struct DDCell {                      // one cell of the level being split (devic
   double rdiv; int rdiv_id, pad;     // the split: first particle of the right half in (coordinate, id) order
 };
 struct DDCand { double key; int id, pad; };
+struct DDWin { double lo, hi; int kd, pad; };         // window of one cell of the level being split: lo <= x <= hi travel as candidates
 struct LetGeomF;
 
 struct gh_dd {
@@ -59,6 +61,15 @@ struct gh_dd {
   int *hist = nullptr, *hist_all = nullptr;          // [nranks/2][DD_G], [nranks][nranks/2][DD_G]
   DDCand *cand = nullptr, *cand_all = nullptr;       // [nranks/2][1 + DD_CAPL], [nranks][...]  (slot 0: count in .id)
   double *box6 = nullptr, *box6_all = nullptr;       // local extent, all ranks' extents
+  // speculative splits (one collective per level): last step's median, window half-width and split axis of every
+  // shared top cell; per-level window table; the ranks' window blocks; status word (non-zero: redo in exact mode)
+  double *spl_prev = nullptr, *spl_win = nullptr; int *spl_kd = nullptr, *spl_fail = nullptr;
+  struct DDWin *wins = nullptr;
+  DDCand *wnd = nullptr, *wnd_all = nullptr;
+  bool have_splits = false;
+  long long n_spec = 0, n_exact = 0;                  // decompositions done speculatively / with the three-collective search
+  // pinned host staging of the halo exchange (sizes in, counts and offsets out): no stack array is read by an async copy
+  int *h_cnt = nullptr; long long *h_off = nullptr; int *h_all = nullptr;
   // migration
   int *mig_cnt = nullptr;            // [2*nranks + 4]: leavers per destination, arrivals per source, cursor words
   int *mig_slot = nullptr;           // [own_count] position of every leaver in its destination's block
@@ -75,6 +86,8 @@ struct gh_dd {
   int *let_cnt = nullptr;            // [2*MAX] cells / leaves marked per destination, then [2*MAX] received per source
   long long *let_off = nullptr;      // [2*MAX] send / receive block offsets in doubles
   int *let_cells = nullptr, *let_leaves = nullptr;   // [nranks][cap] marked cell ids, leaf ids
+  struct LetWork *let_work = nullptr;                  // [nranks << (P + F)] work items of the marking walk
+  unsigned char *let_vis = nullptr; size_t vis_stride = 0;   // [nranks][cells of the own subtree] visit flags of k_let_walk
   size_t let_cellcap = 0, let_leafcap = 0;
   char *let_send = nullptr, *let_recv = nullptr; size_t let_send_bytes = 0, let_recv_bytes = 0;
   long long migrated = 0;            // particles this rank sent away in the last decomposition
@@ -199,7 +212,8 @@ __global__ void k_dd_collect(DevicePtrs d, const int *topcell, const DDCell *cel
 // one workgroup per cell: the candidate of rank (target - base) in (coordinate, id) order is the split; the
 // children's inherited boxes follow (KDTree.cpp:508-527)
 __global__ __launch_bounds__(1024) void k_dd_select(DDCell *cells, const DDCand *cand_all, int ncells, int nranks,
-                                                    double *dbbmin, double *dbbmax, int *kdiv, int *flags)
+                                                    double *dbbmin, double *dbbmax, int *kdiv, int *flags,
+                                                    double *spl_prev, double *spl_win, int *spl_kd)
 {
   const int c = blockIdx.x;
   __shared__ int s_off[GH_MAX_RANKS + 1];
@@ -235,6 +249,10 @@ __global__ __launch_bounds__(1024) void k_dd_select(DDCell *cells, const DDCand 
     const int n = q.node, c1 = 2*n + 1, c2 = 2*n + 2, kd = q.kd;
     if (s_found >= 0) { const DDCand m = entry(s_found); w.rdiv = m.key; w.rdiv_id = m.id; }
     else if (ntot > 0 || q.target > 0) atomicOr(flags, FLAG_DD_SPLIT);       // the bracket lost the median: never expected
+    // what next step's speculative split starts from: the median, the axis, and a window that holds ~256 candidates at
+    // the density of the final bin (ntot candidates in a bin of width 1/scB)
+    spl_prev[n] = w.rdiv; spl_kd[n] = kd;
+    spl_win[n] = (q.scB > 0.0 && ntot > 0) ? 128.0/(q.scB*(double) ntot) : 0.0;
     for (int k = 0; k < 3; k++) {
       dbbmin[c1*3 + k] = dbbmin[n*3 + k]; dbbmax[c1*3 + k] = (k == kd) ? w.rdiv : dbbmax[n*3 + k];
       dbbmin[c2*3 + k] = (k == kd) ? w.rdiv : dbbmin[n*3 + k]; dbbmax[c2*3 + k] = dbbmax[n*3 + k];
@@ -253,6 +271,154 @@ __global__ void k_dd_assign(DevicePtrs d, int *topcell, const DDCell *cells)
   const double x = d.f[D_RX + q.kd][i];
   const int right = (q.rdiv_id >= 0 && (x > q.rdiv || (x == q.rdiv && d.iorig[i] >= q.rdiv_id))) ? 1 : 0;
   topcell[i] = 2*c + right;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// speculative splits: ONE collective per shared level (and none for the root box).  The median of a top cell moves by a
+// few dozen particle ranks per step, so every rank sends, per cell, the number of its particles below a narrow window
+// around LAST step's median and the (coordinate, id) of those inside it; every rank then finds the exact median among
+// the gathered candidates - the same element the histogram search below finds.  If a window misses its median, a rank
+// overflows its block or a cell's longest axis changed, a status word is raised, rides in the migration counts to every
+// rank, and all ranks redo the decomposition with the exact search (gh_dd_decompose).  Windows adapt: wide enough for
+// four times the last shift and for ~256 candidates at the density seen.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dd_win_init(DDCell *cells, DDWin *wins, int level, const double *dbbmin, const double *dbbmax, const int *cN, int ndim,
+                              const double *spl_prev, const double *spl_win, const int *spl_kd, int *fail)
+{
+  const int c = threadIdx.x;
+  if (c >= (1 << level)) return;
+  const int n = (1 << level) - 1 + c;
+  int kd = spl_kd[n];
+  double rkmax = 0.0;
+  if (level > 0) {                                     // the root's box is only known after the gather (k_dd_wselect checks it)
+    int k2 = 0;
+    for (int k = 0; k < ndim; k++) { const double ext = dbbmax[n*3 + k] - dbbmin[n*3 + k]; if (ext > rkmax) { rkmax = ext; k2 = k; } }
+    if (k2 != kd) { atomicOr(fail, 1); kd = k2; }
+  }
+  DDCell q;
+  q.kd = kd; q.node = n;
+  q.loA = 0.0; q.scA = 0.0; q.loB = 0.0; q.scB = 0.0; q.binA = -1; q.binB = -1;
+  q.base = 0; q.target = cN[n]/2;
+  q.rdiv = spl_prev[n]; q.rdiv_id = -1; q.pad = 0;
+  cells[c] = q;
+  DDWin w;
+  w.lo = spl_prev[n] - spl_win[n]; w.hi = spl_prev[n] + spl_win[n]; w.kd = kd; w.pad = 0;
+  wins[c] = w;
+}
+
+// block layout per rank: [DD_WHDR header slots | per cell: 1 count slot (key bits = particles below the window, id =
+// particles inside) + DD_WCAP candidates]
+__global__ __launch_bounds__(256) void k_dd_window(DevicePtrs d, const int *topcell, const DDWin *wins, int ncells, DDCand *blk, int *fail)
+{
+  __shared__ unsigned int s_below[GH_MAX_RANKS];
+  if (threadIdx.x < GH_MAX_RANKS) s_below[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < d.N) {
+    const int c = topcell[i];
+    const DDWin w = wins[c];
+    const double x = d.f[D_RX + w.kd][i];
+    if (x < w.lo) atomicAdd(&s_below[c], 1u);
+    else if (x <= w.hi) {
+      DDCand *cc = blk + DD_WHDR + (size_t) c*(1 + DD_WCAP);
+      const int slot = atomicAdd(&cc[0].id, 1);
+      if (slot < DD_WCAP) { cc[1 + slot].key = x; cc[1 + slot].id = d.iorig[i]; cc[1 + slot].pad = 0; }
+    }
+  }
+  __syncthreads();
+  if ((int) threadIdx.x < ncells && s_below[threadIdx.x])
+    atomicAdd((unsigned long long*) &blk[DD_WHDR + (size_t) threadIdx.x*(1 + DD_WCAP)].key, (unsigned long long) s_below[threadIdx.x]);
+}
+
+__global__ void k_dd_win_box(const double *dbbmin, const double *dbbmax, DDCand *blk)
+{
+  if (threadIdx.x < 3) { ((double*) blk)[threadIdx.x] = dbbmin[threadIdx.x]; ((double*) blk)[3 + threadIdx.x] = dbbmax[threadIdx.x]; }
+}
+
+// one workgroup per cell of the level: exact median among the gathered window candidates
+__global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand *all, size_t stride /* DDCand per rank */, int level, int nranks, int ndim,
+                                                     double *dbbmin, double *dbbmax, int *kdiv, double *spl_prev, double *spl_win, int *spl_kd, int *fail)
+{
+  const int c = blockIdx.x;
+  __shared__ int s_off[GH_MAX_RANKS + 1];
+  __shared__ long long s_base;
+  __shared__ int s_found, s_bad;
+  __shared__ int s_cnt[GH_MAX_RANKS];
+  __shared__ long long s_below[GH_MAX_RANKS];
+  __shared__ double s_box[6];
+  if ((int) threadIdx.x < nranks) {                      // the ranks' headers side by side: one memory latency, not nranks
+    const DDCand h = all[(size_t) threadIdx.x*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP)];
+    s_cnt[threadIdx.x] = h.id; s_below[threadIdx.x] = (long long) __double_as_longlong(h.key);
+  }
+  if (level == 0 && threadIdx.x >= 64 && threadIdx.x < 70) {
+    // global root box from the ranks' extents (KDTree.cpp:269-280)
+    const int k = threadIdx.x - 64;
+    double v = k < 3 ? 9.9e20 : -9.9e20;
+    for (int r = 0; r < nranks; r++) { const double x = ((const double*) (all + (size_t) r*stride))[k]; v = k < 3 ? fmin(v, x) : fmax(v, x); }
+    s_box[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0; long long base = 0; int bad = 0;
+    for (int r = 0; r < nranks; r++) {
+      s_off[r] = run;
+      if (s_cnt[r] > DD_WCAP) bad = 1;
+      run += min(s_cnt[r], DD_WCAP);
+      base += s_below[r];
+    }
+    s_off[nranks] = run; s_base = base; s_found = -1; s_bad = bad;
+    if (level == 0) {
+      // ... then the root's longest axis against the guess
+      double rkmax = 0.0; int kd = 0;
+      for (int k = 0; k < 3; k++) {
+        dbbmin[k] = s_box[k]; dbbmax[k] = s_box[3 + k];
+        if (k < ndim && s_box[3 + k] - s_box[k] > rkmax) { rkmax = s_box[3 + k] - s_box[k]; kd = k; }
+      }
+      if (kd != cells[0].kd) s_bad = 1;
+    }
+  }
+  __syncthreads();
+  const DDCell q = cells[c];
+  const int ntot = s_off[nranks];
+  const long long want = q.target - s_base;
+  auto entry = [&](int e) -> DDCand {
+    int r = 0;
+    while (r + 1 < nranks && e >= s_off[r + 1]) r++;
+    return all[(size_t) r*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP) + 1 + (e - s_off[r])];
+  };
+  if (!s_bad && want >= 0 && want < ntot) {
+    for (int e = threadIdx.x; e < ntot; e += blockDim.x) {
+      const DDCand me = entry(e);
+      long long rank = 0;
+      for (int r = 0; r < nranks; r++) {
+        const DDCand *p = all + (size_t) r*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP) + 1;
+        const int nr = s_off[r + 1] - s_off[r];
+        for (int t = 0; t < nr; t++) { const DDCand o = p[t]; if (o.key < me.key || (o.key == me.key && o.id < me.id)) rank++; }
+      }
+      if (rank == want) s_found = e;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DDCell w = q;
+    const int n = q.node, c1 = 2*n + 1, c2 = 2*n + 2, kd = q.kd;
+    if (s_found >= 0) {
+      const DDCand m = entry(s_found);
+      w.rdiv = m.key; w.rdiv_id = m.id;
+      const double wold = spl_win[n], shift = fabs(m.key - spl_prev[n]);
+      double wnew = fmax(4.0*shift, 256.0*wold/(double) ntot);
+      wnew = fmin(wnew, 0.25*(dbbmax[n*3 + kd] - dbbmin[n*3 + kd]));
+      spl_prev[n] = m.key; spl_win[n] = wnew;
+    }
+    else atomicOr(fail, 1);
+    for (int k = 0; k < 3; k++) {
+      dbbmin[c1*3 + k] = dbbmin[n*3 + k]; dbbmax[c1*3 + k] = (k == kd) ? w.rdiv : dbbmax[n*3 + k];
+      dbbmin[c2*3 + k] = (k == kd) ? w.rdiv : dbbmin[n*3 + k]; dbbmax[c2*3 + k] = dbbmax[n*3 + k];
+    }
+    kdiv[n] = kd;
+    cells[c] = w;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,19 +596,25 @@ __device__ __forceinline__ bool let_may_open(const LetGeom &Q, const CellBox &yb
 {
   if (Q.N <= 0) return false;
   if (PHASE == GH_HALO_DENSITY) {
-    for (int k = 0; k < ndim; k++) if (Q.dbmin[k] > yb.bbmax[k] || yb.bbmin[k] > Q.dbmax[k]) return false;
-    return true;
+    bool o = true;                                       // (fixed trip count + predicate: Q stays in registers)
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k < ndim && (Q.dbmin[k] > yb.bbmax[k] || yb.bbmin[k] > Q.dbmax[k])) o = false;
+    return o;
   }
   if (PHASE == GH_HALO_HYDRO) {
     bool o1 = true, o2 = true;
-    for (int k = 0; k < ndim; k++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (k >= ndim) continue;
       if (Q.bbmin[k] > yh.hbmax[k] || yh.hbmin[k] > Q.bbmax[k]) o1 = false;
       if (Q.hbmin[k] > yb.bbmax[k] || yb.bbmin[k] > Q.hbmax[k]) o2 = false;
     }
     return o1 || o2;
   }
   double dr2 = 0.0, dc2 = 0.0, db2 = 0.0;            // squared distance of Y's centre from the three boxes
-  for (int k = 0; k < ndim; k++) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k >= ndim) continue;
     const double gr = fmax(fmax(Q.rbmin[k] - yg.rcell[k], yg.rcell[k] - Q.rbmax[k]), 0.0);
     const double gc = fmax(fmax(Q.cbmin[k] - yg.rcell[k], yg.rcell[k] - Q.cbmax[k]), 0.0);
     const double gb = fmax(fmax(Q.bbmin[k] - yg.rcell[k], yg.rcell[k] - Q.bbmax[k]), 0.0);
@@ -479,198 +651,225 @@ __device__ __forceinline__ bool let_may_open_img(const LetGeom &Q, const CellBox
   return false;
 }
 
-// grid (2^P, nranks): workgroup (j, r) marks what rank r needs of the subtree below this rank's published bottom
-// cell j, level by level with the visit flags in LDS
-template <int PHASE>
-__global__ __launch_bounds__(1024) void k_let_mark(DevicePtrs d, int L, int P, int F, int self, double kernrange, double widen, const char *fine_base, size_t fine_stride,
-                                                  int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags, LetPeriod per)
+// Marking = the destination's own walks, run on the sender at the granularity of the destination's fine table
+// (2^(P+F) entries per rank: its particle groups, or small bundles of them).
+//   k_let_prepass  one thread per (destination rank, fine entry): which of THIS rank's 2^P published bottom cells can
+//                  that entry's walks open?  Entries that open none (most of them: the far side of the other domains)
+//                  cost nothing further; the others become work items (rank, entry, start-cell mask).
+//   k_let_walk     persistent wavefronts take work items off a queue: a depth-first walk of this rank's subtree below the
+//                  item's start cells (stack in LDS, up to 64 nodes popped per round, lane = node) with the conservative
+//                  opening test of the phase.  An entry only ever follows the nodes it opened itself, so no (entry, node)
+//                  pair is tested unless the destination's walks really can get near that node - the level-by-level
+//                  version this replaces tested every visited node against the destination's whole table (32 published
+//                  cells x 64 fine entries, 75 ms per launch for 1M particles on two ranks).
+// Measured on the way (8 ranks, 1M Plummer): one wave per (rank, entry) without the prepass cost 180 / 275 us (density /
+// gravity phase) - the sum of 14 336 wave lifetimes over the ~3 000 waves the device holds, whatever the walks did; more,
+// smaller walks (one per start-cell chunk) scaled with the wave count (x8 waves: 520 / 960 us), bundles of 8 entries per
+// wave with a union pre-test lost in the density phase what they won in the gravity phase (union boxes are loose).
+// Visited cells get a flag byte in vis[r][subtree-local heap index] (1 = cell record travels, 2 = the leaf's particles
+// travel; plain idempotent byte stores, every writer of a byte writes the same value); k_let_compact turns the flags into
+// the per-destination id lists.
+#define LW_CAP 2048
+struct LetWork { int r, e; unsigned int mask; int pad; };
+__device__ __forceinline__ int let_loc(int n, int L, int self)
+{
+  const int lev = 31 - __clz(n + 1), rl = lev - L;
+  return (1 << rl) - 1 + (n - ((1 << lev) - 1) - (self << rl));
+}
+template <int PHASE, bool PER>
+__device__ __forceinline__ bool let_test(const LetGeom &Q, const DevicePtrs &d, int n, double kernrange, double widen, const LetPeriod &per)
+{
+  CellBox yb; CellH yh; CellGeo yg;
+  if (PHASE == GH_HALO_GRAVITY) { yg = d.cgeo[n]; yb.N = yg.N; }
+  else { yb = d.cbox[n]; if (PHASE == GH_HALO_HYDRO) yh = d.ch[n]; }
+  if (yb.N <= 0) return false;
+  if (PER) return let_may_open_img<PHASE>(Q, yb, yh, yg, d.ndim, kernrange, widen, per);
+  return let_may_open<PHASE>(Q, yb, yh, yg, d.ndim, kernrange, widen);
+}
+
+template <int PHASE, bool PER>
+__global__ __launch_bounds__(256) void k_let_prepass(DevicePtrs d, int L, int P, int PF, int self, int nranks, double kernrange, double widen,
+                                                     const char *fine_base, size_t fine_stride, LetPeriod per, LetWork *work, int *nwork)
+{
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  const int r = t >> PF, e = t & ((1 << PF) - 1);
+  if (r >= nranks || r == self) return;
+  LetGeom Q;
+  let_expand(((const LetGeomF*) (fine_base + (size_t) r*fine_stride))[e], Q);
+  if (Q.N <= 0) return;
+  const int y0 = (1 << (L + P)) - 1 + (self << P);
+  unsigned int mask = 0;
+  for (int c = 0; c < (1 << P); c++)
+    if (let_test<PHASE, PER>(Q, d, y0 + c, kernrange, widen, per)) mask |= 1u << c;
+  if (mask) { LetWork w; w.r = r; w.e = e; w.mask = mask; w.pad = 0; work[atomicAdd(nwork, 1)] = w; }
+}
+
+template <int PHASE, bool PER, int NPL /* nodes per lane and round */, int CAP /* stack entries */>
+__global__ __launch_bounds__(64) void k_let_walk(DevicePtrs d, int L, int P, int self, double kernrange, double widen,
+                                                 const char *fine_base, size_t fine_stride, unsigned char *vis, size_t vis_stride, LetPeriod per,
+                                                 const LetWork *work, const int *nwork, int *head)
+{
+  __shared__ int s_stack[CAP + 128*NPL];
+  __shared__ int s_item;
+  const int lane = threadIdx.x;
+  const int nw = *nwork;
+  const int depth = d.ltot - (L + P);                    // levels below the published bottom cells
+  const int y0 = (1 << (L + P)) - 1 + (self << P);
+  for (;;) {
+    if (lane == 0) s_item = atomicAdd(head, 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nw) break;                               // every wave ends here: the queue is finite and only ever drained
+    const LetWork w = work[item];
+    LetGeom Q;
+    let_expand(((const LetGeomF*) (fine_base + (size_t) w.r*fine_stride))[w.e], Q);
+    unsigned char *v = vis + (size_t) w.r*vis_stride;
+    const bool mine = lane < (1 << P) && ((w.mask >> lane) & 1u);
+    const unsigned long long sm = __ballot(mine);
+    if (mine) s_stack[__popcll(sm & ((1ull << lane) - 1ull))] = y0 + lane;
+    int top = __popcll(sm);
+    __syncthreads();
+    while (top > 0) {
+      // pops narrow when the stack is nearly full: one node at a time it grows by at most one entry per level
+      const int take = top > CAP - 128*NPL ? 1 : min(top, 64*NPL);
+      int n[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; k++) n[k] = k*64 + lane < take ? s_stack[top - 1 - (k*64 + lane)] : -1;
+      top -= take;
+      __syncthreads();
+      bool open[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; k++) open[k] = n[k] >= 0 && let_test<PHASE, PER>(Q, d, n[k] < 0 ? 0 : n[k], kernrange, widen, per);
+#pragma unroll
+      for (int k = 0; k < NPL; k++) {
+        bool push = false;
+        if (open[k]) {
+          if (depth == 0) v[let_loc(n[k], L, self)] = 2;   // the published bottom cell is a leaf: its particles travel
+          else {
+            // a visited leaf travels with its particles whether or not they would be touched (a leaf with one particle enters
+            // the gravity lists as a particle, Tree.cpp:713): no walk below the last-but-one level
+            const bool childleaf = 31 - __clz(n[k] + 1) + 1 == d.ltot;
+            const int l1 = let_loc(2*n[k] + 1, L, self);
+            v[l1] = childleaf ? 3 : 1; v[l1 + 1] = childleaf ? 3 : 1;
+            push = !childleaf;
+          }
+        }
+        const unsigned long long pm = __ballot(push);
+        if (push) {
+          const int at = top + 2*__popcll(pm & ((1ull << lane) - 1ull));
+          s_stack[at] = 2*n[k] + 1; s_stack[at + 1] = 2*n[k] + 2;
+        }
+        top += 2*__popcll(pm);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// flags -> per-destination lists of cell ids (records travel) and leaf ids (particles travel)
+__global__ __launch_bounds__(256) void k_let_compact(int L, int self, const unsigned char *vis, size_t vis_stride, int nloc,
+                                                     int *cnt, int *cells, int *leaves, size_t cellcap, size_t leafcap, int *flags)
 {
   const int r = blockIdx.y;
   if (r == self) return;
-  __shared__ LetGeom s_q[1 << DD_PMAX];
-  __shared__ unsigned char s_vis[2][DD_VIS];
-  const int nq = 1 << P, nf = 1 << F;
-  const LetGeomF *fine = (const LetGeomF*) (fine_base + (size_t) r*fine_stride);
-  if ((int) threadIdx.x < nq) {
-    // published bottom cell of the destination = union of its fine entries
-    LetGeom q;
-    let_expand(fine[(size_t) threadIdx.x*nf], q);
-    for (int f = 1; f < nf; f++) {
-      LetGeom e;
-      let_expand(fine[(size_t) threadIdx.x*nf + f], e);
-      if (e.N <= 0) continue;
-      if (q.N <= 0) { q = e; continue; }
-      for (int k = 0; k < 3; k++) {
-        q.bbmin[k] = fmin(q.bbmin[k], e.bbmin[k]); q.bbmax[k] = fmax(q.bbmax[k], e.bbmax[k]);
-        q.hbmin[k] = fmin(q.hbmin[k], e.hbmin[k]); q.hbmax[k] = fmax(q.hbmax[k], e.hbmax[k]);
-        q.rbmin[k] = fmin(q.rbmin[k], e.rbmin[k]); q.rbmax[k] = fmax(q.rbmax[k], e.rbmax[k]);
-        q.cbmin[k] = fmin(q.cbmin[k], e.cbmin[k]); q.cbmax[k] = fmax(q.cbmax[k], e.cbmax[k]);
-        q.dbmin[k] = fmin(q.dbmin[k], e.dbmin[k]); q.dbmax[k] = fmax(q.dbmax[k], e.dbmax[k]);
-      }
-      q.N += e.N;
-    }
-    s_q[threadIdx.x] = q;
-  }
-  const int depth = d.ltot - (L + P);                    // levels below the published bottom cell
-  const int y0 = (1 << (L + P)) - 1 + (self << P) + blockIdx.x;
-  if (threadIdx.x == 0) s_vis[0][0] = 1;
-  __syncthreads();
-  int cur = 0;
-  for (int t = 0; t <= depth; t++) {
-    const int nn = 1 << t;
-    const int nbase = ((y0 + 1) << t) - 1;
-    const bool leaflevel = t == depth;
-    for (int k0 = 0; k0 < nn; k0 += blockDim.x) {
-      const int k = k0 + threadIdx.x;
-      bool vis = false, open = false;
-      int n = 0;
-      bool test = false;
-      if (k < nn && s_vis[cur][k]) {
-        vis = true;
-        n = nbase + k;
-        // a visited leaf travels whether or not its particles would be touched (below): no opening test on the last level,
-        // where half of all cells sit and where an exhaustive "no" is the usual answer
-        test = d.cbox[n].N > 0 && !(leaflevel && t > 0);
-      }
-      // the opening test of one node is shared by the wave: lane = published cell of the destination for the coarse test,
-      // lane = fine entry of one published cell for the fine test (one coalesced read per round).  One thread per node with
-      // the fine entries in a serial early-exit loop was latency-bound: 75 ms per launch for 1M particles on 2 ranks.
-      {
-        const int lanei = threadIdx.x & 63;
-        unsigned long long tm = __ballot(test);
-        while (tm) {
-          const int j = __ffsll((long long) tm) - 1;
-          tm &= tm - 1ull;
-          const int nj = __shfl(n, j, 64);
-          const CellBox yb = d.cbox[nj]; const CellH yh = d.ch[nj]; const CellGeo yg = d.cgeo[nj];
-          bool cpass = false;
-          for (int q0 = 0; q0 < nq; q0 += 64) {
-            const int qi = q0 + lanei;
-            if (qi < nq) cpass = let_may_open_img<PHASE>(s_q[qi], yb, yh, yg, d.ndim, kernrange, widen, per);
-            unsigned long long cm = __ballot(cpass);
-            bool any = false;
-            while (cm && !any) {
-              const int qq = q0 + __ffsll((long long) cm) - 1;
-              cm &= cm - 1ull;
-              bool o = false;
-              for (int f0 = 0; f0 < nf; f0 += 64) {
-                const int f = f0 + lanei;
-                if (f < nf) { LetGeom e; let_expand(fine[(size_t) qq*nf + f], e); o = o || let_may_open_img<PHASE>(e, yb, yh, yg, d.ndim, kernrange, widen, per); }
-              }
-              any = __any(o);
-            }
-            if (any) { if (lanei == j) open = true; break; }
-          }
-        }
-      }
-      if (!leaflevel && k < nn) { s_vis[cur ^ 1][2*k] = open; s_vis[cur ^ 1][2*k + 1] = open; }
-      // visited cells below the published levels travel as records; opened leaves (and every visited leaf: a leaf
-      // with one particle enters the gravity lists as a particle, Tree.cpp:713) travel with their particles
-      const bool sendcell = vis && t > 0;
-      const unsigned long long cm = __ballot(sendcell);
-      if (cm) {
-        int base = 0;
-        const int lanei = threadIdx.x & 63;
-        if (lanei == 0) base = atomicAdd(&cnt[2*r], __popcll(cm));
-        base = __shfl(base, 0, 64);
-        if (sendcell) {
-          const size_t pos = (size_t) base + __popcll(cm & (lanei ? ((~0ull) >> (64 - lanei)) : 0ull));
-          if (pos < cellcap) cells[(size_t) r*cellcap + pos] = n; else atomicOr(flags, FLAG_LEAFLIST_OVERFLOW);
-        }
-      }
-      const bool sendleaf = vis && leaflevel && (t == 0 ? open : true);
-      const unsigned long long lm = __ballot(sendleaf);
-      if (lm) {
-        int base = 0;
-        const int lanei = threadIdx.x & 63;
-        if (lanei == 0) base = atomicAdd(&cnt[2*r + 1], __popcll(lm));
-        base = __shfl(base, 0, 64);
-        if (sendleaf) {
-          const size_t pos = (size_t) base + __popcll(lm & (lanei ? ((~0ull) >> (64 - lanei)) : 0ull));
-          if (pos < leafcap) leaves[(size_t) r*leafcap + pos] = n; else atomicOr(flags, FLAG_LEAFLIST_OVERFLOW);
-        }
+  const int lanei = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lanei) - 1ull;
+  for (int l0 = blockIdx.x*blockDim.x; l0 < nloc; l0 += gridDim.x*blockDim.x) {
+    const int loc = l0 + threadIdx.x;
+    const unsigned char val = loc < nloc ? vis[(size_t) r*vis_stride + loc] : 0;
+    int n = 0;
+    if (val) { const int rl = 31 - __clz(loc + 1); n = (1 << (L + rl)) - 1 + (self << rl) + (loc - ((1 << rl) - 1)); }
+    const unsigned long long cm = __ballot(val & 1);
+    if (cm) {
+      int base = 0;
+      if (lanei == 0) base = atomicAdd(&cnt[2*r], __popcll(cm));
+      base = __shfl(base, 0, 64);
+      if (val & 1) {
+        const size_t pos = (size_t) base + __popcll(cm & below);
+        if (pos < cellcap) cells[(size_t) r*cellcap + pos] = n; else atomicOr(flags, FLAG_LEAFLIST_OVERFLOW);
       }
     }
-    __syncthreads();
-    cur ^= 1;
+    const unsigned long long lm = __ballot(val & 2);
+    if (lm) {
+      int base = 0;
+      if (lanei == 0) base = atomicAdd(&cnt[2*r + 1], __popcll(lm));
+      base = __shfl(base, 0, 64);
+      if (val & 2) {
+        const size_t pos = (size_t) base + __popcll(lm & below);
+        if (pos < leafcap) leaves[(size_t) r*leafcap + pos] = n; else atomicOr(flags, FLAG_LEAFLIST_OVERFLOW);
+      }
+    }
   }
 }
 
 // record sizes in doubles: cell = id + the records of the phase; leaf = id + occ x particle record
 struct LetLayout { int cell_dbl, part_dbl, leaf_dbl, occ, phase, quad; };
 
-__global__ void k_let_pack(DevicePtrs d, LetLayout lay, int nranks, int self, const int *cnt, const int *cells, const int *leaves,
-                           size_t cellcap, size_t leafcap, const long long *off /* [nranks] doubles */, double *send)
+// pack / unpack: a thread moves ONE double of one record (cell records: up to 34 doubles; leaf records: id + occ particle
+// records), so that consecutive threads touch consecutive words of the message and of the 32-byte packs
+__device__ __forceinline__ const double *let_cell_word(const DevicePtrs &d, int n, int w, bool dens)
+{
+  // word w >= 1 of a cell record: CellBox [1, 9), then (force phases) CellH [9, 17), CellGeo [17, 25), CellCom [25, 29), CellQuad [29, 34)
+  if (w < 9) return (const double*) &d.cbox[n] + (w - 1);
+  if (w < 17) return (const double*) &d.ch[n] + (w - 9);
+  if (w < 25) return (const double*) &d.cgeo[n] + (w - 17);
+  if (w < 29) return (const double*) &d.ccom[n] + (w - 25);
+  return (const double*) &d.cquad[n] + (w - 29);
+}
+__global__ __launch_bounds__(256) void k_let_pack(DevicePtrs d, LetLayout lay, int nranks, int self, const int *cnt, const int *cells, const int *leaves,
+                                                  size_t cellcap, size_t leafcap, const long long *off /* [nranks] doubles */, double *send)
 {
   const int r = blockIdx.y;
   if (r == self) return;
   const int nc = cnt[2*r], nl = cnt[2*r + 1];
   double *base = send + off[r];
-  for (int e = blockIdx.x*blockDim.x + threadIdx.x; e < nc + nl; e += gridDim.x*blockDim.x) {
-    if (e < nc) {
-      const int n = cells[(size_t) r*cellcap + e];
-      double *o = base + (size_t) e*lay.cell_dbl;
-      o[0] = (double) n;
-      const double *b = (const double*) &d.cbox[n];
-      for (int k = 0; k < 8; k++) o[1 + k] = b[k];
-      if (lay.phase != GH_HALO_DENSITY) {
-        const double *h = (const double*) &d.ch[n], *g = (const double*) &d.cgeo[n], *c = (const double*) &d.ccom[n];
-        for (int k = 0; k < 8; k++) { o[9 + k] = h[k]; o[17 + k] = g[k]; }
-        for (int k = 0; k < 4; k++) o[25 + k] = c[k];
-        if (lay.quad) { const double *qq = (const double*) &d.cquad[n]; for (int k = 0; k < 5; k++) o[29 + k] = qq[k]; }
-      }
+  const long long ncw = (long long) nc*lay.cell_dbl, tot = ncw + (long long) nl*lay.leaf_dbl;
+  for (long long e = (long long) blockIdx.x*blockDim.x + threadIdx.x; e < tot; e += (long long) gridDim.x*blockDim.x) {
+    if (e < ncw) {
+      const int c = (int) (e/lay.cell_dbl), w = (int) (e - (long long) c*lay.cell_dbl);
+      const int n = cells[(size_t) r*cellcap + c];
+      base[e] = w == 0 ? (double) n : *let_cell_word(d, n, w, lay.phase == GH_HALO_DENSITY);
     }
     else {
-      const int n = leaves[(size_t) r*leafcap + (e - nc)];
-      double *o = base + (size_t) nc*lay.cell_dbl + (size_t) (e - nc)*lay.leaf_dbl;
-      o[0] = (double) n;
-      const int first = d.cfirst[n], cn = d.cN[n];
-      for (int t = 0; t < lay.occ; t++) {
-        double *po = o + 1 + (size_t) t*lay.part_dbl;
-        if (t < cn) {
-          const double *pm = (const double*) &d.posm[first + t];
-          for (int k = 0; k < 4; k++) po[k] = pm[k];
-          if (lay.phase != GH_HALO_DENSITY) {
-            const double *hr = (const double*) &d.hrec[4*(size_t) (first + t)];
-            for (int k = 0; k < 16; k++) po[4 + k] = hr[k];
-          }
-        }
+      const long long q = e - ncw;
+      const int c = (int) (q/lay.leaf_dbl), w = (int) (q - (long long) c*lay.leaf_dbl);
+      const int n = leaves[(size_t) r*leafcap + c];
+      double val = 0.0;
+      if (w == 0) val = (double) n;
+      else {
+        const int t = (w - 1)/lay.part_dbl, k = (w - 1) - t*lay.part_dbl;
+        const int first = d.cfirst[n], cn = d.cN[n];
+        if (t < cn) val = k < 4 ? ((const double*) &d.posm[first + t])[k] : ((const double*) &d.hrec[4*(size_t) (first + t)])[k - 4];
       }
+      base[e] = val;
     }
   }
 }
 
-__global__ void k_let_unpack(DevicePtrs d, LetLayout lay, int nranks, int self, const int *rcnt, const long long *roff, const double *recv)
+__global__ __launch_bounds__(256) void k_let_unpack(DevicePtrs d, LetLayout lay, int nranks, int self, const int *rcnt, const long long *roff, const double *recv)
 {
   const int r = blockIdx.y;
   if (r == self) return;
   const int nc = rcnt[2*r], nl = rcnt[2*r + 1];
   const double *base = recv + roff[r];
-  for (int e = blockIdx.x*blockDim.x + threadIdx.x; e < nc + nl; e += gridDim.x*blockDim.x) {
-    if (e < nc) {
-      const double *o = base + (size_t) e*lay.cell_dbl;
-      const int n = (int) o[0];
-      double *b = (double*) &d.cbox[n];
-      for (int k = 0; k < 8; k++) b[k] = o[1 + k];
-      if (lay.phase != GH_HALO_DENSITY) {
-        double *h = (double*) &d.ch[n], *g = (double*) &d.cgeo[n], *c = (double*) &d.ccom[n];
-        for (int k = 0; k < 8; k++) { h[k] = o[9 + k]; g[k] = o[17 + k]; }
-        for (int k = 0; k < 4; k++) c[k] = o[25 + k];
-        if (lay.quad) { double *qq = (double*) &d.cquad[n]; for (int k = 0; k < 5; k++) qq[k] = o[29 + k]; }
-      }
+  const long long ncw = (long long) nc*lay.cell_dbl, tot = ncw + (long long) nl*lay.leaf_dbl;
+  for (long long e = (long long) blockIdx.x*blockDim.x + threadIdx.x; e < tot; e += (long long) gridDim.x*blockDim.x) {
+    if (e < ncw) {
+      const int c = (int) (e/lay.cell_dbl), w = (int) (e - (long long) c*lay.cell_dbl);
+      if (w == 0) continue;
+      const int n = (int) base[(long long) c*lay.cell_dbl];
+      *const_cast<double*>(let_cell_word(d, n, w, lay.phase == GH_HALO_DENSITY)) = base[e];
     }
     else {
-      const double *o = base + (size_t) nc*lay.cell_dbl + (size_t) (e - nc)*lay.leaf_dbl;
-      const int n = (int) o[0];
+      const long long q = e - ncw;
+      const int c = (int) (q/lay.leaf_dbl), w = (int) (q - (long long) c*lay.leaf_dbl);
+      if (w == 0) continue;
+      const int n = (int) base[ncw + (long long) c*lay.leaf_dbl];
+      const int t = (w - 1)/lay.part_dbl, k = (w - 1) - t*lay.part_dbl;
       const int first = d.cfirst[n], cn = d.cN[n];
-      for (int t = 0; t < cn; t++) {
-        const double *po = o + 1 + (size_t) t*lay.part_dbl;
-        double *pm = (double*) &d.posm[first + t];
-        for (int k = 0; k < 4; k++) pm[k] = po[k];
-        if (lay.phase != GH_HALO_DENSITY) {
-          double *hr = (double*) &d.hrec[4*(size_t) (first + t)];
-          for (int k = 0; k < 16; k++) hr[k] = po[4 + k];
-        }
+      if (t < cn) {
+        if (k < 4) ((double*) &d.posm[first + t])[k] = base[e];
+        else ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
       }
     }
   }
@@ -730,8 +929,9 @@ void gh_dd_free(gh_ctx *ctx)
   if (!D) return;
   void *ptrs[] = {D->topcell, D->cells, D->hist, D->hist_all, D->cand, D->cand_all, D->box6, D->box6_all, D->mig_cnt, D->mig_slot,
                   D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->comb_send, D->comb_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
-                  D->let_send, D->let_recv, D->dt_all};
+                  D->let_send, D->let_recv, D->dt_all, D->let_vis, D->let_work, D->spl_prev, D->spl_win, D->spl_kd, D->wins, D->wnd, D->wnd_all};
   for (void *p : ptrs) if (p) (void) hipFree(p);
+  for (void *p : {(void*) D->h_cnt, (void*) D->h_off, (void*) D->h_all}) if (p) (void) hipHostFree(p);
   delete D;
   ctx->dd = nullptr;
 }
@@ -750,6 +950,19 @@ static int dd_alloc(gh_ctx *ctx)
   GH_CHECK(ctx, hipMalloc((void**) &D->cand, sizeof(DDCand)*(size_t) half*(1 + DD_CAPL)));
   GH_CHECK(ctx, hipMalloc((void**) &D->cand_all, sizeof(DDCand)*(size_t) W*half*(1 + DD_CAPL)));
   GH_CHECK(ctx, hipMalloc((void**) &D->box6, sizeof(double)*8));
+  GH_CHECK(ctx, hipMalloc((void**) &D->spl_prev, sizeof(double)*W));
+  GH_CHECK(ctx, hipMalloc((void**) &D->spl_win, sizeof(double)*W));
+  GH_CHECK(ctx, hipMalloc((void**) &D->spl_kd, sizeof(int)*(W + 2)));
+  D->spl_fail = D->spl_kd + W;
+  GH_CHECK(ctx, hipMemset(D->spl_prev, 0, sizeof(double)*W));
+  GH_CHECK(ctx, hipMemset(D->spl_win, 0, sizeof(double)*W));
+  GH_CHECK(ctx, hipMemset(D->spl_kd, 0, sizeof(int)*(W + 2)));
+  GH_CHECK(ctx, hipMalloc((void**) &D->wins, sizeof(DDWin)*GH_MAX_RANKS));
+  GH_CHECK(ctx, hipMalloc((void**) &D->wnd, sizeof(DDCand)*(DD_WHDR + (size_t) half*(1 + DD_WCAP))));
+  GH_CHECK(ctx, hipMalloc((void**) &D->wnd_all, sizeof(DDCand)*(DD_WHDR + (size_t) half*(1 + DD_WCAP))*W));
+  GH_CHECK(ctx, hipHostMalloc((void**) &D->h_cnt, sizeof(int)*2*GH_MAX_RANKS));
+  GH_CHECK(ctx, hipHostMalloc((void**) &D->h_off, sizeof(long long)*2*GH_MAX_RANKS));
+  GH_CHECK(ctx, hipHostMalloc((void**) &D->h_all, sizeof(int)*GH_MAX_RANKS*(2*GH_MAX_RANKS + 2)));
   GH_CHECK(ctx, hipMalloc((void**) &D->box6_all, sizeof(double)*8*W));
   GH_CHECK(ctx, hipMalloc((void**) &D->mig_cnt, sizeof(int)*(4*GH_MAX_RANKS)));
   GH_CHECK(ctx, hipMalloc((void**) &D->mig_slot, sizeof(int)*n));
@@ -774,28 +987,25 @@ static int dd_alloc(gh_ctx *ctx)
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cells, sizeof(int)*D->let_cellcap*W));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_leaves, sizeof(int)*D->let_leafcap*W));
   GH_CHECK(ctx, hipMalloc((void**) &D->dt_all, sizeof(double)*(W + 2)));
+  D->vis_stride = ((size_t) 2*(ctx->gtot >> ctx->L) + 255) & ~(size_t) 255;
+  GH_CHECK(ctx, hipMalloc((void**) &D->let_vis, D->vis_stride*(size_t) W));
+  GH_CHECK(ctx, hipMalloc((void**) &D->let_work, sizeof(LetWork)*((size_t) W << (D->P + D->F))));
   return GH_OK;
 }
 
 // the L shared top levels and the migration (see the header comment); leaves dbbmin/dbbmax of this rank's cell set
-int gh_dd_decompose(gh_ctx *ctx)
+static int dd_levels_exact(gh_ctx *ctx)
 {
   gh_dd *D = ctx->dd;
-  if (!D) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: gh_comm_init was not called");
-  int rc = dd_alloc(ctx);
-  if (rc) return rc;
   const int W = ctx->nranks, L = ctx->L;
   hipStream_t s = ctx->stream;
   const int pn = (int) ctx->own_count;
   const int nb = cdiv(pn, 256);
   DevicePtrs own = gh_dev_own(ctx);
-
   // global root box
-  gh_rootbox_local(ctx, (1 << L) - 1 + ctx->rank);
   hipLaunchKernelGGL(k_dd_box_pack, dim3(1), dim3(64), 0, s, ctx->dbbmin, ctx->dbbmax, D->box6);
   DD_OP(ctx, dd_allgather(ctx, D->box6, D->box6_all, sizeof(double)*6));
   hipLaunchKernelGGL(k_dd_box_merge, dim3(1), dim3(64), 0, s, D->box6_all, W, ctx->dbbmin, ctx->dbbmax);
-
   // level by level: exact medians over all ranks' particles
   GH_CHECK(ctx, hipMemsetAsync(D->topcell, 0, sizeof(int)*(size_t) pn, s));
   for (int l = 0; l < L; l++) {
@@ -810,28 +1020,94 @@ int gh_dd_decompose(gh_ctx *ctx)
     GH_CHECK(ctx, hipMemsetAsync(D->cand, 0, sizeof(DDCand)*(size_t) nc*(1 + DD_CAPL), s));
     hipLaunchKernelGGL(k_dd_collect, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells, D->cand, ctx->d_flags);
     DD_OP(ctx, dd_allgather(ctx, D->cand, D->cand_all, sizeof(DDCand)*(size_t) nc*(1 + DD_CAPL)));
-    hipLaunchKernelGGL(k_dd_select, dim3(nc), dim3(1024), 0, s, D->cells, D->cand_all, nc, W, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->d_flags);
+    hipLaunchKernelGGL(k_dd_select, dim3(nc), dim3(1024), 0, s, D->cells, D->cand_all, nc, W, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->d_flags,
+                       D->spl_prev, D->spl_win, D->spl_kd);
     hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells);
   }
+  return GH_OK;
+}
 
-  // migration: topcell is now the destination rank
-  GH_CHECK(ctx, hipMemsetAsync(D->mig_cnt, 0, sizeof(int)*4*GH_MAX_RANKS, s));
-  hipLaunchKernelGGL(k_mig_count, dim3(nb), dim3(256), 0, s, pn, D->topcell, ctx->rank, D->mig_cnt, D->mig_slot, D->mig_hole);
-  // counts: leavers per destination -> every rank learns its arrivals per source
-  DD_OP(ctx, dd_allgather(ctx, D->mig_cnt, D->hist_all, sizeof(int)*GH_MAX_RANKS));
-  std::vector<int> all((size_t) W*GH_MAX_RANKS);
-  GH_CHECK(ctx, hipMemcpyAsync(all.data(), D->hist_all, sizeof(int)*all.size(), hipMemcpyDeviceToHost, s));
-  GH_CHECK(ctx, hipStreamSynchronize(s));
+// the same splits from windows around last step's medians: one collective per level, none for the root box
+static int dd_levels_speculative(gh_ctx *ctx)
+{
+  gh_dd *D = ctx->dd;
+  const int W = ctx->nranks, L = ctx->L;
+  hipStream_t s = ctx->stream;
+  const int pn = (int) ctx->own_count;
+  const int nb = cdiv(pn, 256);
+  DevicePtrs own = gh_dev_own(ctx);
+  GH_CHECK(ctx, hipMemsetAsync(D->topcell, 0, sizeof(int)*(size_t) pn, s));
+  GH_CHECK(ctx, hipMemsetAsync(D->spl_fail, 0, sizeof(int), s));
+  for (int l = 0; l < L; l++) {
+    const int nc = 1 << l;
+    const size_t stride = DD_WHDR + (size_t) nc*(1 + DD_WCAP);
+    hipLaunchKernelGGL(k_dd_win_init, dim3(1), dim3(64), 0, s, D->cells, D->wins, l, ctx->dbbmin, ctx->dbbmax, ctx->cN, ctx->ndim,
+                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail);
+    GH_CHECK(ctx, hipMemsetAsync(D->wnd, 0, sizeof(DDCand)*stride, s));
+    if (l == 0) hipLaunchKernelGGL(k_dd_win_box, dim3(1), dim3(64), 0, s, ctx->dbbmin, ctx->dbbmax, D->wnd);   // this rank's extent (gh_rootbox_local)
+    hipLaunchKernelGGL(k_dd_window, dim3(nb), dim3(256), 0, s, own, D->topcell, D->wins, nc, D->wnd, D->spl_fail);
+    DD_OP(ctx, dd_allgather(ctx, D->wnd, D->wnd_all, sizeof(DDCand)*stride));
+    hipLaunchKernelGGL(k_dd_wselect, dim3(nc), dim3(1024), 0, s, D->cells, D->wnd_all, stride, l, W, ctx->ndim, ctx->dbbmin, ctx->dbbmax, ctx->kdiv,
+                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail);
+    hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells);
+  }
+  return GH_OK;
+}
+
+__global__ void k_mig_status(int *mig_cnt, const int *fail) { mig_cnt[GH_MAX_RANKS] = fail ? *fail : 0; }
+
+int gh_dd_decompose(gh_ctx *ctx)
+{
+  gh_dd *D = ctx->dd;
+  if (!D) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: gh_comm_init was not called");
+  int rc = dd_alloc(ctx);
+  if (rc) return rc;
+  const int W = ctx->nranks, L = ctx->L;
+  hipStream_t s = ctx->stream;
+  const int pn = (int) ctx->own_count;
+  const int nb = cdiv(pn, 256);
+  DevicePtrs own = gh_dev_own(ctx);
+
+  // this rank's extent of r -/+ kernrange*h; every own particle starts in this rank's cell
+  gh_rootbox_local(ctx, (1 << L) - 1 + ctx->rank);
+  bool spec = D->have_splits && !getenv("GH_DD_EXACT");
+  std::vector<int> all((size_t) W*(GH_MAX_RANKS + 1));
+  for (;;) {
+    if ((rc = spec ? dd_levels_speculative(ctx) : dd_levels_exact(ctx))) return rc;
+    // migration: topcell is now the destination rank.  Leavers per destination -> every rank learns its arrivals per
+    // source; the status word of the speculative splits rides along (identical on all ranks: it is computed from
+    // gathered data only - the OR over the ranks below is belt and braces)
+    GH_CHECK(ctx, hipMemsetAsync(D->mig_cnt, 0, sizeof(int)*4*GH_MAX_RANKS, s));
+    hipLaunchKernelGGL(k_mig_count, dim3(nb), dim3(256), 0, s, pn, D->topcell, ctx->rank, D->mig_cnt, D->mig_slot, D->mig_hole);
+    hipLaunchKernelGGL(k_mig_status, dim3(1), dim3(1), 0, s, D->mig_cnt, spec ? D->spl_fail : nullptr);
+    DD_OP(ctx, dd_allgather(ctx, D->mig_cnt, D->hist_all, sizeof(int)*(GH_MAX_RANKS + 1)));
+    GH_CHECK(ctx, hipMemcpyAsync(all.data(), D->hist_all, sizeof(int)*all.size(), hipMemcpyDeviceToHost, s));
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    int failed = 0;
+    for (int r = 0; r < W; r++) failed |= all[(size_t) r*(GH_MAX_RANKS + 1) + GH_MAX_RANKS];
+    if (spec && failed) { spec = false; continue; }       // collective decision: every rank sees the same words
+    break;
+  }
+  if (spec) D->n_spec++; else D->n_exact++;
+  D->have_splits = true;
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   MigTab tab;
   long long nsend = 0, nrecv = 0;
   for (int r = 0; r < W; r++) {
-    const int out = all[(size_t) ctx->rank*GH_MAX_RANKS + r], in = all[(size_t) r*GH_MAX_RANKS + ctx->rank];
+    const int out = all[(size_t) ctx->rank*(GH_MAX_RANKS + 1) + r], in = all[(size_t) r*(GH_MAX_RANKS + 1) + ctx->rank];
     tab.off[r] = (int) nsend;
     sb[r] = (int64_t) out*DD_REC*sizeof(double); rb[r] = (int64_t) in*DD_REC*sizeof(double);
     nsend += out; nrecv += in;
   }
-  if (nsend != nrecv) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: unbalanced migration (equal coordinates at a top-level split?)");
+  // every rank's particle count is static, so leavers and arrivals balance on EVERY rank or on none: a split that left a
+  // cell with the wrong count (equal coordinates beyond DD_CAPL) shows up on all ranks, and all of them stop here together
+  bool unbalanced = false;
+  for (int r = 0; r < W; r++) {
+    long long o = 0, in = 0;
+    for (int q = 0; q < W; q++) { o += all[(size_t) r*(GH_MAX_RANKS + 1) + q]; in += all[(size_t) q*(GH_MAX_RANKS + 1) + r]; }
+    if (o != in) unbalanced = true;
+  }
+  if (unbalanced) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: unbalanced migration (equal coordinates at a top-level split?)");
   for (int f = 0; f < DD_REC - 1; f++) tab.fld[f] = own.f[f];
   static_assert(DD_REC - 1 == D_COUNT_BASE, "migration record = the fields of a global-timestep run + iorig");
   if (nsend > 0) hipLaunchKernelGGL(k_mig_pack, dim3(nb), dim3(256), 0, s, tab, own.iorig, pn, D->topcell, ctx->rank, D->mig_slot, D->mig_send);
@@ -907,23 +1183,52 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   hipStream_t s = ctx->stream;
   DevicePtrs d = gh_dev(ctx);
   const double kr = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0;
-  if (((size_t) 1 << (ctx->ltot - (L + P))) > (size_t) DD_VIS)
-    return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU: more than DD_VIS leaves below a published cell (k_let_mark keeps one visit flag per cell of a level in LDS)");
   if (phase == GH_HALO_DENSITY && widen != D->fine_widen) { const int rc = dd_publish_fine(ctx, widen); if (rc) return rc; }
   hipLaunchKernelGGL(k_let_invalidate, dim3(cdiv(ctx->Ncell, 256)), dim3(256), 0, s, d, L, P, ctx->rank, ctx->Ncell);
   GH_CHECK(ctx, hipMemsetAsync(D->let_cnt, 0, sizeof(int)*8*GH_MAX_RANKS, s));
-  const dim3 grid(1 << P, W);
+  GH_CHECK(ctx, hipMemsetAsync(D->let_vis, 0, D->vis_stride*(size_t) W, s));
   LetPeriod per;
-  for (int k = 0; k < 3; k++)
+  bool anyper = false;
+  for (int k = 0; k < 3; k++) {
     per.len[k] = (k < ctx->ndim && ctx->cfg.boundary_lhs[k] == GH_BOUNDARY_PERIODIC) ? ctx->cfg.boxmax[k] - ctx->cfg.boxmin[k] : 0.0;
-  if (phase == GH_HALO_DENSITY) hipLaunchKernelGGL((k_let_mark<GH_HALO_DENSITY>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
-  else if (phase == GH_HALO_HYDRO) hipLaunchKernelGGL((k_let_mark<GH_HALO_HYDRO>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
-  else hipLaunchKernelGGL((k_let_mark<GH_HALO_GRAVITY>), grid, dim3(1024), 0, s, d, L, P, D->F, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags, per);
-  // counts to everybody (2 ints per pair), then sizes on the host
-  DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*2*GH_MAX_RANKS));
-  std::vector<int> all((size_t) W*2*GH_MAX_RANKS);
-  GH_CHECK(ctx, hipMemcpyAsync(all.data(), D->hist_all, sizeof(int)*all.size(), hipMemcpyDeviceToHost, s));
+    anyper = anyper || per.len[k] > 0.0;
+  }
+  {
+    const int PF = P + D->F;
+    int *nwork = D->let_cnt + 6*GH_MAX_RANKS, *head = nwork + 1;       // zeroed with let_cnt above
+    const int nthr = W << PF;
+    int nwaves = 256*16, var = 0;                          // persistent marking waves: what the device holds of them
+    if (const char *e = getenv("GH_LW_WAVES")) nwaves = 256*atoi(e);
+    if (const char *e = getenv("GH_LW_VAR")) var = atoi(e);
+#define LW_LAUNCH(PH, PR) { \
+    hipLaunchKernelGGL((k_let_prepass<PH, PR>), dim3(cdiv(nthr, 256)), dim3(256), 0, s, d, L, P, PF, ctx->rank, W, kr, widen, D->fine_base, D->fine_stride, per, D->let_work, nwork); \
+    if (var == 1) hipLaunchKernelGGL((k_let_walk<PH, PR, 2, 2048>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); \
+    else if (var == 2) hipLaunchKernelGGL((k_let_walk<PH, PR, 1, 1024>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); \
+    else hipLaunchKernelGGL((k_let_walk<PH, PR, 1, 2048>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); }
+    if (anyper) { if (phase == GH_HALO_DENSITY) LW_LAUNCH(GH_HALO_DENSITY, true) else if (phase == GH_HALO_HYDRO) LW_LAUNCH(GH_HALO_HYDRO, true) else LW_LAUNCH(GH_HALO_GRAVITY, true) }
+    else { if (phase == GH_HALO_DENSITY) LW_LAUNCH(GH_HALO_DENSITY, false) else if (phase == GH_HALO_HYDRO) LW_LAUNCH(GH_HALO_HYDRO, false) else LW_LAUNCH(GH_HALO_GRAVITY, false) }
+#undef LW_LAUNCH
+  }
+  {
+    const int nloc = 2*(ctx->gtot >> L) - 1;              // cells of this rank's subtree
+    hipLaunchKernelGGL(k_let_compact, dim3(std::min(cdiv(nloc, 256), 512), W), dim3(256), 0, s, L, ctx->rank, D->let_vis, D->vis_stride, nloc,
+                       D->let_cnt, D->let_cells, D->let_leaves, D->let_cellcap, D->let_leafcap, ctx->d_flags);
+  }
+  // counts to everybody (2 ints per pair), then sizes on the host.  The miss counter of a density pass whose check was
+  // deferred (gh_step: the force-phase exchange is the next collective anyway) rides in the same block.
+  const int CW = 2*GH_MAX_RANKS + 2;
+  const bool check_miss = phase != GH_HALO_DENSITY && ctx->dd_miss_pending;
+  if (check_miss) GH_CHECK(ctx, hipMemcpyAsync(D->let_cnt + 2*GH_MAX_RANKS, ctx->d_blk + 12, sizeof(int), hipMemcpyDeviceToDevice, s));
+  DD_OP(ctx, dd_allgather(ctx, D->let_cnt, D->hist_all, sizeof(int)*CW));
+  int *all = D->h_all;
+  GH_CHECK(ctx, hipMemcpyAsync(all, D->hist_all, sizeof(int)*(size_t) W*CW, hipMemcpyDeviceToHost, s));
   GH_CHECK(ctx, hipStreamSynchronize(s));
+  if (check_miss) {
+    ctx->dd_miss_pending = false;
+    int any = 0;
+    for (int r = 0; r < W; r++) any |= all[(size_t) r*CW + 2*GH_MAX_RANKS];
+    if (any) return GH_DD_REDO_DENSITY;                    // collective decision; the caller widens the density import and redoes those groups
+  }
   LetLayout lay;
   lay.phase = phase; lay.quad = ctx->cquad ? 1 : 0; lay.occ = ctx->leafocc;
   lay.cell_dbl = phase == GH_HALO_DENSITY ? 9 : (lay.quad ? 34 : 29);
@@ -931,10 +1236,10 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   lay.leaf_dbl = 1 + lay.occ*lay.part_dbl;
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   long long soff[GH_MAX_RANKS], roff[GH_MAX_RANKS], stot = 0, rtot = 0, nimp = 0;
-  int rcnt[2*GH_MAX_RANKS];
+  int *rcnt = D->h_cnt;
   for (int r = 0; r < W; r++) {
-    const int oc = r == ctx->rank ? 0 : all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r], ol = r == ctx->rank ? 0 : all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r + 1];
-    const int ic = r == ctx->rank ? 0 : all[(size_t) r*2*GH_MAX_RANKS + 2*ctx->rank], il = r == ctx->rank ? 0 : all[(size_t) r*2*GH_MAX_RANKS + 2*ctx->rank + 1];
+    const int oc = r == ctx->rank ? 0 : all[(size_t) ctx->rank*CW + 2*r], ol = r == ctx->rank ? 0 : all[(size_t) ctx->rank*CW + 2*r + 1];
+    const int ic = r == ctx->rank ? 0 : all[(size_t) r*CW + 2*ctx->rank], il = r == ctx->rank ? 0 : all[(size_t) r*CW + 2*ctx->rank + 1];
     soff[r] = stot; roff[r] = rtot;
     const long long sd = (long long) oc*lay.cell_dbl + (long long) ol*lay.leaf_dbl, rd = (long long) ic*lay.cell_dbl + (long long) il*lay.leaf_dbl;
     sb[r] = sd*8; rb[r] = rd*8; stot += sd; rtot += rd;
@@ -945,7 +1250,7 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   if (getenv("GH_DD_DEBUG")) {
     fprintf(stderr, "[dd] rank %d phase %d widen %.1f:", ctx->rank, phase, widen);
     for (int r = 0; r < W; r++) if (r != ctx->rank) fprintf(stderr, "  to %d: %d cells %d leaves | from %d: %d cells %d leaves", r,
-        all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r], all[(size_t) ctx->rank*2*GH_MAX_RANKS + 2*r + 1], r, rcnt[2*r], rcnt[2*r + 1]);
+        all[(size_t) ctx->rank*CW + 2*r], all[(size_t) ctx->rank*CW + 2*r + 1], r, rcnt[2*r], rcnt[2*r + 1]);
     fprintf(stderr, "  (subtree: %d cells, %d leaves)\n", 2*(ctx->gtot >> L) - 1, ctx->gtot >> L);
   }
   auto grow = [&](char **p, size_t *have, size_t need) -> hipError_t {
@@ -959,17 +1264,17 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   };
   GH_CHECK(ctx, grow(&D->let_send, &D->let_send_bytes, (size_t) stot*8 + 8));
   GH_CHECK(ctx, grow(&D->let_recv, &D->let_recv_bytes, (size_t) rtot*8 + 8));
-  // received counts and block offsets (in doubles) for the pack / unpack kernels
-  GH_CHECK(ctx, hipMemcpyAsync(D->let_cnt + 2*GH_MAX_RANKS, rcnt, sizeof(int)*2*GH_MAX_RANKS, hipMemcpyHostToDevice, s));
-  long long hoff[2*GH_MAX_RANKS];
+  // received counts and block offsets (in doubles) for the pack / unpack kernels: staged in pinned host memory that
+  // lives as long as the decomposition (the next exchange synchronises before it rewrites them)
+  GH_CHECK(ctx, hipMemcpyAsync(D->let_cnt + 4*GH_MAX_RANKS, rcnt, sizeof(int)*2*GH_MAX_RANKS, hipMemcpyHostToDevice, s));
+  long long *hoff = D->h_off;
   for (int r = 0; r < GH_MAX_RANKS; r++) { hoff[r] = r < W ? soff[r] : 0; hoff[GH_MAX_RANKS + r] = r < W ? roff[r] : 0; }
   long long *d_offs = D->let_off;
-  GH_CHECK(ctx, hipMemcpyAsync(d_offs, hoff, sizeof(hoff), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_let_pack, dim3(256, W), dim3(256), 0, s, d, lay, W, ctx->rank, D->let_cnt, D->let_cells, D->let_leaves,
+  GH_CHECK(ctx, hipMemcpyAsync(d_offs, hoff, sizeof(long long)*2*GH_MAX_RANKS, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_let_pack, dim3(1024, W), dim3(256), 0, s, d, lay, W, ctx->rank, D->let_cnt, D->let_cells, D->let_leaves,
                      D->let_cellcap, D->let_leafcap, d_offs, (double*) D->let_send);
   DD_OP(ctx, D->ops.alltoallv(D->ops.user, D->let_send, sb, D->let_recv, rb, (void*) s));
-  hipLaunchKernelGGL(k_let_unpack, dim3(256, W), dim3(256), 0, s, d, lay, W, ctx->rank, D->let_cnt + 2*GH_MAX_RANKS, d_offs + GH_MAX_RANKS, (const double*) D->let_recv);
-  GH_CHECK(ctx, hipStreamSynchronize(s));                // hoff / rcnt are stack arrays of this call
+  hipLaunchKernelGGL(k_let_unpack, dim3(1024, W), dim3(256), 0, s, d, lay, W, ctx->rank, D->let_cnt + 4*GH_MAX_RANKS, d_offs + GH_MAX_RANKS, (const double*) D->let_recv);
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }

@@ -878,7 +878,7 @@ void gh_shard_groups(const gh_ctx *ctx, int rank, int &g0, int &g1)
   g1 = (int) (ng*(rank + 1)/ctx->nranks);
 }
 
-int gh_density_impl(gh_ctx *ctx, bool count)
+int gh_density_impl(gh_ctx *ctx, bool count, bool redo_only)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_density: no tree (call gh_build_tree)");
   DevicePtrs d = gh_dev(ctx);
@@ -917,10 +917,10 @@ int gh_density_impl(gh_ctx *ctx, bool count)
   P.fbout = G.fb;
   P.miss_count = (unsigned int*) (ctx->d_blk + 12);
   const bool dd = ctx->nranks > 1;
-  if (dd) GH_CHECK(ctx, hipMemsetAsync(P.miss_count, 0, sizeof(unsigned int), s));
-  if (dd && fused_only) GH_CHECK(ctx, hipMemsetAsync(G.fb, 0, sizeof(int)*(size_t) ctx->ngroups, s));
+  if (dd && !redo_only) GH_CHECK(ctx, hipMemsetAsync(P.miss_count, 0, sizeof(unsigned int), s));
+  if (dd && fused_only && !redo_only) GH_CHECK(ctx, hipMemsetAsync(G.fb, 0, sizeof(int)*(size_t) ctx->ngroups, s));
   gh_phase_begin(ctx, GH_T_SPH_PROPERTIES);
-  if (nblocks > 0 && !fused_only) {
+  if (nblocks > 0 && !fused_only && !redo_only) {
 #define LAUNCH(ND_, KT_)                                                                                      \
     hipLaunchKernelGGL((k_dens_walk<ND_, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_flags);        \
     if (count) hipLaunchKernelGGL((k_dens_eval<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags); \
@@ -933,16 +933,17 @@ int gh_density_impl(gh_ctx *ctx, bool count)
     if (stale) hipLaunchKernelGGL((k_density<ND_, false, KT_, true>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
     else if (count) hipLaunchKernelGGL((k_density<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags); \
     else hipLaunchKernelGGL((k_density<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, ctx->d_stats, ctx->d_flags);
-  if (nblocks > 0) { GH_DISPATCH(ctx, LAUNCH) }
-  if (dd) {
+  if (nblocks > 0 && !redo_only) { GH_DISPATCH(ctx, LAUNCH) }
+  if (dd && ctx->dd_defer_miss && !redo_only) ctx->dd_miss_pending = true;      // checked with the force-phase halo counts
+  else if (dd) {
     // multi-GPU: groups whose walk left the imported halo stored nothing; widen the import and redo just those (the
     // h iteration may grow a smoothing length past any margin fixed in advance - e.g. the first pass from a guessed h).
     // The decision is collective: every rank takes part in every widened exchange.
     P.only_if = G.fb; P.only_val = 2;
     double widen = 1.0;
     for (int attempt = 0; ; attempt++) {
-      int any = 0;
-      int rc = gh_dd_any(ctx, P.miss_count, &any);        // sum over ranks of the miss counters (synchronises)
+      int any = 1, rc = 0;                                // redo_only: the deferred check already found a miss
+      if (!(redo_only && attempt == 0)) rc = gh_dd_any(ctx, P.miss_count, &any);        // sum over ranks of the miss counters (synchronises)
       if (rc) return rc;
       if (!any) break;
       if (attempt >= 24) return gh_fail(ctx, GH_ERR_CAPACITY, "gh_update_density: halo import did not converge");

@@ -603,6 +603,20 @@ static void fill_force_params(gh_ctx *ctx, ForceParams &P)
   P.stale = ctx->tree_stale ? 1 : 0;
 }
 
+// force records of the own particles (k_pack_hydro), then the import of the halo the walks of `phase` need.  In gh_step
+// the density pass leaves its "did a walk leave the imported halo" check to this exchange's count block; if some rank
+// did miss, all ranks widen the density import, redo those groups and the cells' hmax, and come back here.
+int gh_force_halo(gh_ctx *ctx, int phase)
+{
+  for (;;) {
+    hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx));
+    int rc = gh_dd_exchange(ctx, phase);
+    if (rc != GH_DD_REDO_DENSITY) return rc;
+    if ((rc = gh_density_impl(ctx, false, true))) return rc;
+    if ((rc = gh_update_hmax_impl(ctx))) return rc;
+  }
+}
+
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
 {
   if (!ctx->tree_valid) return gh_fail(ctx, GH_ERR_INVALID, "gh_update_hydro_forces: no tree");
@@ -613,8 +627,7 @@ int gh_hydro_forces_impl(gh_ctx *ctx, bool count)
   gh_shard_groups(ctx, ctx->rank, g0, g1);
   const int nblocks = g1 - g0;
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, s, gh_dev_own(ctx));
-  { const int rc = gh_dd_exchange(ctx, GH_HALO_HYDRO); if (rc) return rc; }
+  { const int rc = gh_force_halo(ctx, GH_HALO_HYDRO); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   if (nblocks > 0) {
 #define LAUNCH(ND_, KT_)                                                                                            \
@@ -676,13 +689,12 @@ int gh_all_forces_impl(gh_ctx *ctx, bool count)
   if ((1 << (ctx->ltot - ctx->lgroup)) > GH_MAXLEAF) return gh_fail(ctx, GH_ERR_INVALID, "group has too many leaves");
   {
     // default: walk + evaluation kernels with the interaction lists in HBM (gravity.hip);
-    // GH_GRAV_FUSED=1 (or leaves wider than the evaluation kernel handles) selects the single fused kernel
+    // GH_GRAV_FUSED=1 selects the single fused kernel (leaves wider than 6 particles: the evaluation kernel takes them in chunks)
     const char *fused = getenv("GH_GRAV_FUSED");
-    if (!(fused && fused[0] == '1') && ctx->leafocc <= 6 && !cd_grav) return gh_grav_lists_impl(ctx, count);
+    if (!(fused && fused[0] == '1') && !cd_grav) return gh_grav_lists_impl(ctx, count);
   }
   if (quad) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multipole=quadrupole / gravity_mac=gadget2 need the list kernels (Nleafmax <= 6)");
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx));
-  { const int rc = gh_dd_exchange(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
+  { const int rc = gh_force_halo(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
   int rc = gh_grav_fused_launch(ctx, count, nullptr);
   gh_phase_end(ctx, GH_T_SPH_FORCES);

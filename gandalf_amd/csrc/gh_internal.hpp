@@ -206,6 +206,9 @@ struct gh_ctx {
   int64_t own_first = 0, own_count = 0;
   int iota_p0 = -1;
   struct gh_dd *dd = nullptr;
+  // gh_step: the check "did any rank's density walk leave its imported halo" is deferred to the count exchange of the
+  // force-phase halo (one collective and one host synchronisation less per step)
+  bool dd_defer_miss = false, dd_miss_pending = false;
 };
 
 #define GH_MAX_RANKS 16
@@ -268,7 +271,7 @@ int gh_leaf_active_counters(gh_ctx *ctx);   // KDTree::UpdateActiveParticleCount
 int gh_tree_restock_impl(gh_ctx *ctx);   // KDTree::StockTree: same cells and particle order, properties from the current r, h
 int gh_update_hmax_impl(gh_ctx *ctx);
 // the *_impl functions only enqueue work on ctx->stream (no host synchronisation)
-int gh_density_impl(gh_ctx *ctx, bool count);
+int gh_density_impl(gh_ctx *ctx, bool count, bool redo_only = false);   // redo_only: just the groups a deferred miss check found
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count);
 int gh_all_forces_impl(gh_ctx *ctx, bool count);
 int gh_grav_lists_impl(gh_ctx *ctx, bool count);   // two-kernel gravity with interaction lists in HBM
@@ -301,6 +304,8 @@ void gh_shard_groups(const gh_ctx *ctx, int rank, int &g0, int &g1);
 // multi-GPU (comm.hip); all no-ops on one rank
 int gh_dd_exchange(gh_ctx *ctx, int phase);    // halo / locally-essential-tree import for the walks of `phase`
 int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen);   // ... with the density search radius widened
+#define GH_DD_REDO_DENSITY 1000                 /* gh_dd_exchange: a deferred density miss was found - not an error, see gh_force_halo */
+int gh_force_halo(gh_ctx *ctx, int phase);     // forces.hip: force records of the own particles, then the halo of `phase` (redoes a deferred density miss)
 int gh_dd_any(gh_ctx *ctx, const unsigned int *count_dev, int *any);   // any rank's counter non-zero? (collective, synchronises)
 int gh_dd_min_dt(gh_ctx *ctx);                 // time[1] = min over ranks
 void gh_dd_free(gh_ctx *ctx);

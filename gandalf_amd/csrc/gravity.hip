@@ -428,9 +428,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const unsigned long long dbg_t0 = wall_clock64();
 #endif
   const int node = (d.gtot - 1) + gl;
-  const int first = d.cfirst[node], Nt = d.cN[node];
-  if (Nt == 0) return;
-  if (Nt > MAXOCC) { if (lane == 0) atomicOr(flags, FLAG_ILIST_OVERFLOW); return; }
+  // leaves wider than MAXOCC particles (Nleafmax > 6; the reference's bossbodenheimer.dat ships 8) are evaluated in
+  // chunks of MAXOCC targets, one wave per chunk (blockIdx.y), each against the leaf's whole interaction list
+  const int first = d.cfirst[node] + (int) blockIdx.y*MAXOCC, Nt = min(MAXOCC, d.cN[node] - (int) blockIdx.y*MAXOCC);
+  if (Nt <= 0) return;
   const int occ = d.leafocc;
   // block timesteps (Nlevels > 1, wave-uniform flag): a leaf without active particles has no work
   // (Tree::ComputeActiveCellList, Tree.cpp:91-115); otherwise all of its particles are evaluated, the active ones stored
@@ -1021,8 +1022,7 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   const int ngroups = g1 - g0;
   const int nl = 1 << (ctx->ltot - ctx->lgroup);
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pack_hydro, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, s, gh_dev_own(ctx));
-  { const int rc = gh_dd_exchange(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
+  { const int rc = gh_force_halo(ctx, GH_HALO_GRAVITY); if (rc) return rc; }
   gh_phase_begin(ctx, GH_T_GRAV_WALK);
   if (ngroups > 0) {
 #define LAUNCH(ND_, KT_) \
@@ -1034,14 +1034,15 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   }
   gh_phase_end(ctx, GH_T_GRAV_WALK);
   gh_phase_begin(ctx, GH_T_SPH_FORCES);
+  const int nchunk = cdiv(ctx->leafocc, ctx->leafocc <= 4 ? 4 : GH_MAXOCC);      // waves per leaf: 1 unless Nleafmax > 6
   if (ngroups > 0) {
 #define LAUNCHM(ND_, KT_, MP_)                                                                                   \
     if (ctx->leafocc <= 4) { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, 4, KT_, MP_>), dim3(ngroups*nl, nchunk), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, 4, KT_, MP_>), dim3(ngroups*nl, nchunk), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     } else { \
-      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
-      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      if (count) hipLaunchKernelGGL((k_grav_eval<ND_, true, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl, nchunk), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
+      else hipLaunchKernelGGL((k_grav_eval<ND_, false, GH_MAXOCC, KT_, MP_>), dim3(ngroups*nl, nchunk), dim3(64), 0, s, d, P, G, g0*nl, ctx->d_stats, ctx->d_flags); \
     }
 #define LAUNCH(ND_, KT_) if (mpole == GH_MULTIPOLE_QUADRUPOLE) { LAUNCHM(ND_, KT_, 1) } else if (mpole == GH_MULTIPOLE_FAST_MONOPOLE || mpole == GH_MULTIPOLE_FAST_QUADRUPOLE) { LAUNCHM(ND_, KT_, 2) } else { LAUNCHM(ND_, KT_, 0) }
     GH_DISPATCH(ctx, LAUNCH)

@@ -207,7 +207,9 @@ int gh_sinks_potmin(gh_ctx *ctx)
   const double krs = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 9.0 : 4.0;
   // scratch: candidate list and redo list in the (otherwise idle) sort-value buffer, two counters behind the block clock
   int *list = ctx->P[0][0], *redo = ctx->P[0][1], *cnt = ctx->d_blk + 16;
-  if (!list || !redo || getenv("GH_POTMIN_SERIAL")) {
+  // k_potmin_wave takes its candidates 8 leaves x 8 slots at a time: leaves wider than 8 particles (Nleafmax up to 32 is
+  // accepted) go through the serial kernel, which walks every slot of a leaf
+  if (!list || !redo || ctx->leafocc > 8 || getenv("GH_POTMIN_SERIAL")) {
     hipLaunchKernelGGL(k_potmin, dim3(cdiv(ctx->N, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, krs);
     return GH_OK;
   }

@@ -840,7 +840,8 @@ __global__ __launch_bounds__(1 << GH_STOCK_NLEV) void k_stock_bottom(DevicePtrs 
 
 // levels ltop .. 0 in one launch of one workgroup: the top of the tree is latency, not bandwidth.  Levels
 // wider than 128 cells hand their results on through global memory, the rest through LDS.
-__global__ __launch_bounds__(1024) void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only)
+// levels lbase + ltop .. lbase of the subtree below cell `sub` of level lbase (the whole tree: lbase = sub = 0)
+__global__ __launch_bounds__(1024) void k_stock_top(DevicePtrs d, int ltop, double thetamaxsqd, int hmax_only, int lbase, int sub)
 {
   __shared__ SRec s_a[128];
   __shared__ SRec s_b[64];
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(1024) void k_stock_top(DevicePtrs d, int ltop, doub
     const bool out_lds = nc <= 128;
     SRec *o_buf = in_lds ? dst : s_a;
     for (int j = threadIdx.x; j < nc; j += blockDim.x) {
-      const int n = nc - 1 + j;
+      const int n = (1 << (lbase + level)) - 1 + (sub << level) + j;
       SRec r1, r2, o;
       if (in_lds) { r1 = src[2*j]; r2 = src[2*j + 1]; }
       else { srec_load(d, 2*n + 1, hmax_only, r1); srec_load(d, 2*n + 2, hmax_only, r2); }
@@ -925,8 +926,9 @@ int gh_alloc_tree(gh_ctx *ctx)
   for (int g = 0; g < gtot; g++) occ = std::max(occ, ctx->h_cN[gtot - 1 + g]);
   ctx->leafocc = occ;
   // a group = the subtree whose particles one wavefront handles: as many leaves as fit 64 lanes
+  // ... and at most 16 (the gravity walk keeps a 16-bit leaf mask per stack entry): Nleafmax < 4 leaves lanes idle
   int G = 0;
-  while (G < ltot && occ*(2 << G) <= GH_WAVE) G++;
+  while (G < ltot && G < 4 && occ*(2 << G) <= GH_WAVE) G++;
   ctx->lgroup = ltot - G;
   ctx->ngroups = 1 << ctx->lgroup;
   // first level whose cells all fit the LDS-resident subtree kernel
@@ -1004,7 +1006,7 @@ int gh_dd_publish(gh_ctx *ctx, int hmax_only);      // comm.hip: all-gather of t
 void gh_stock_top_levels(gh_ctx *ctx, int ltop, int hmax_only)
 {
   if (ltop >= 0)
-    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, gh_dev(ctx), ltop, ctx->cfg.thetamaxsqd, hmax_only);
+    hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, gh_dev(ctx), ltop, ctx->cfg.thetamaxsqd, hmax_only, 0, 0);
 }
 
 static int stock_tree(gh_ctx *ctx, int hmax_only)
@@ -1018,9 +1020,12 @@ static int stock_tree(gh_ctx *ctx, int hmax_only)
                      ctx->cfg.thetamaxsqd, hmax_only, nlev, ctx->rank*nblk);
   const int lnext = ctx->ltot - nlev - 1;        // highest level not stocked yet
   if (ctx->nranks > 1) {
-    for (int l = lnext; l >= L; l--)
+    const int ltoprel = std::min(lnext - L, 9);    // the top levels of the rank's own subtree in one launch
+    for (int l = lnext; l > L + ltoprel; l--)
       hipLaunchKernelGGL(k_stock_level, dim3(cdiv(1 << (l - L), 256)), dim3(256), 0, ctx->stream, d, l,
                          ctx->cfg.thetamaxsqd, hmax_only, ctx->rank << (l - L), 1 << (l - L));
+    if (ltoprel >= 0)
+      hipLaunchKernelGGL(k_stock_top, dim3(1), dim3(1024), 0, ctx->stream, d, ltoprel, ctx->cfg.thetamaxsqd, hmax_only, L, ctx->rank);
     return gh_dd_publish(ctx, hmax_only);          // remote subtree tops, then the shared levels above the ranks' cells
   }
   const int ltop = std::min(lnext, 9);

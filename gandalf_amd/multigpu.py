@@ -142,18 +142,64 @@ class CommOps:
             out[ro[r]:ro[r + 1]] = buf
 
 
+class RcclOps:
+    """gh_comm_ops bound to RCCL inside libgandalf_hip.so (csrc/rccl_comm.hip): ncclAllGather and grouped
+    ncclSend / ncclRecv on the library's own stream - no collective of the stepped loop comes back into Python.
+    torch.distributed is only the launcher's rendezvous here: rank 0's ncclUniqueId (128 bytes) reaches the other ranks
+    through `dist.broadcast_object_list` (any backend), like MPI_Bcast in a C++ host."""
+
+    def __init__(self, rank, world, device):
+        from . import capi
+        self.lib = capi.load_library()
+        err = self.lib.gh_rccl_load_error()
+        if err:
+            raise RuntimeError(err.decode())
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            if self.lib.gh_rccl_unique_id(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            ident = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self.rank, self.world = rank, world
+        self.handle = C.c_void_p()
+        rc = self.lib.gh_rccl_create(C.byref(self.handle), rank, world, C.create_string_buffer(ident[0], 128), int(device))
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed (rank %d of %d)" % (rank, world))
+        self.ptr = self.lib.gh_rccl_ops(self.handle)
+        self.last_error = None
+
+    def counters(self, reset=False):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.gh_rccl_counters(self.handle, C.byref(a), C.byref(b), C.byref(c), int(reset))
+        return {"allgather": a.value, "alltoallv": b.value, "bytes": c.value}
+
+    def error(self):
+        return self.lib.gh_rccl_last_error(self.handle).decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.gh_rccl_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class DistributedRunner:
     """setup() / steps(n) of a gandalf_amd.host.Simulation on `world` ranks (rank r owns top-level KD cell r).
     world == 1 is the plain single-GPU run."""
 
-    def __init__(self, sim, rank=0, world=1):
+    def __init__(self, sim, rank=0, world=1, transport="torch", device=0):
+        """transport: "rccl" = the library's own RCCL binding (RcclOps; what bench.py uses on real multi-GPU nodes),
+        "torch" = torch.distributed callbacks (CommOps; gloo for several ranks on one GPU and for the CPU tests)"""
         self.sim, self.rank, self.world = sim, rank, world
+        self.transport, self.device = transport, device
         self.ops = None
         self.dev = None
 
     def setup(self):
+        if self.world > 1 or self.transport == "rccl":
+            self.ops = RcclOps(self.rank, self.world, self.device) if self.transport == "rccl" else CommOps("device")
         if self.world > 1:
-            self.ops = CommOps("device")
             self.sim.init_comm(self.rank, self.world, self.ops.ptr)
         self.sim.post_ic_setup()
         self.dev = self.sim.device()

@@ -283,6 +283,24 @@ typedef struct gh_comm_ops {
  * every rank and keeps this rank's share; gh_download / gh_upload_field touch only this rank's own particles.
  * gh_build_tree, gh_update_density, gh_update_*_forces, gh_setup and gh_step are collective calls from then on. */
 int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops *ops);
+/* ---- native RCCL transport (gandalf_amd/csrc/rccl_comm.hip): a ready-made gh_comm_ops ---------------------------
+ * replaces the MPI calls of the reference's hot path one for one: MPI_Allgather (src/Mpi/MpiControl.cpp:329-337) ->
+ * ncclAllGather; MPI_Alltoallv (:1073-1150) and the pruned-tree MPI_Isend / MPI_Irecv (src/Tree/HydroTree.cpp:1044-1230)
+ * -> one group of ncclSend / ncclRecv pairs (a direct xGMI link per pair).  RCCL is dlopen'ed at the first call.
+ * One process per GPU: rank 0 calls gh_rccl_unique_id and hands the 128 bytes to the other ranks by whatever launched
+ * them (MPI_Bcast gandalf.cpp-style, a torch.distributed store, a file); every rank then calls gh_rccl_create - a
+ * collective, like MPI_Init + MPI_Comm_rank (src/Common/gandalf.cpp:51-103).  One process driving several GPUs with a
+ * thread per GPU: gh_rccl_create_all (ncclCommInitAll).  gh_rccl_ops(c) is what gh_comm_init takes. */
+typedef struct gh_rccl gh_rccl;
+int gh_rccl_unique_id(void *id128);
+int gh_rccl_create(gh_rccl **out, int rank, int nranks, const void *id128, int device);
+int gh_rccl_create_all(gh_rccl **out /* [ndev] */, int ndev, const int *devices);
+const gh_comm_ops *gh_rccl_ops(gh_rccl *c);
+const char *gh_rccl_last_error(gh_rccl *c);
+const char *gh_rccl_load_error(void);          /* "" when RCCL could be loaded */
+/* collectives issued through this communicator since the last reset (bench.py reports them per step) */
+int gh_rccl_counters(gh_rccl *c, int64_t *n_allgather, int64_t *n_alltoallv, int64_t *bytes, int reset);
+void gh_rccl_destroy(gh_rccl *c);
 /* halo import for the tree walks of one phase; gh_update_density / gh_update_*_forces / gh_step call it themselves */
 enum { GH_HALO_DENSITY = 0 /* cell boxes + (r, m) */, GH_HALO_HYDRO = 1, GH_HALO_GRAVITY = 2 /* all cell records + force records */ };
 int gh_exchange_halo(gh_ctx *ctx, int phase);

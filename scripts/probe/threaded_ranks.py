@@ -27,6 +27,10 @@ class Shared:
     def __init__(self, world):
         self.world = world
         self.barrier = threading.Barrier(world)
+        # THR_SERIAL=1: only the rank that holds the token enqueues GPU work between two collectives, so that a kernel trace
+        # of the run shows every kernel with the duration it has on a GPU of its own (profiles/r03_multirank_*)
+        self.token = threading.Lock() if os.environ.get("THR_SERIAL") else None
+        self.ncoll = 0
         self.send = [0]*world
         self.sbytes = [None]*world
         self.errors = []
@@ -51,12 +55,18 @@ class ThreadOps:
             sh, W = self.sh, self.sh.world
             torch.cuda.synchronize()
             sh.send[self.rank] = int(send)
+            if sh.token:
+                sh.token.release()
+            if self.rank == 0:
+                sh.ncoll += 1
             sh.barrier.wait()
             out = dev_view(recv, nbytes*W)
             for r in range(W):
                 out[r*nbytes:(r + 1)*nbytes].copy_(dev_view(sh.send[r], nbytes))
             torch.cuda.synchronize()
             sh.barrier.wait()
+            if sh.token:
+                sh.token.acquire()
             return 0
         except Exception as e:          # noqa: BLE001
             self.sh.errors.append(e)
@@ -69,6 +79,10 @@ class ThreadOps:
             sh.send[self.rank] = int(send)
             sh.sbytes[self.rank] = [int(send_bytes[r]) for r in range(W)]
             rb = [int(recv_bytes[r]) for r in range(W)]
+            if sh.token:
+                sh.token.release()
+            if self.rank == 0:
+                sh.ncoll += 1
             sh.barrier.wait()
             out = dev_view(recv, sum(rb))
             ro = 0
@@ -81,6 +95,8 @@ class ThreadOps:
                 ro += rb[r]
             torch.cuda.synchronize()
             sh.barrier.wait()
+            if sh.token:
+                sh.token.acquire()
             return 0
         except Exception as e:          # noqa: BLE001
             self.sh.errors.append(e)
@@ -108,24 +124,53 @@ def run(world, N, nsteps, params):
         try:
             torch.cuda.set_device(0)
             sim = sims[r]
+            if shared.token:
+                shared.token.acquire()
             if world > 1:
                 sim.init_comm(r, world, ops[r].ptr)
             sim.post_ic_setup()
             if nsteps > 0:
                 torch.cuda.synchronize()
                 if world > 1:
+                    if shared.token:
+                        shared.token.release()
                     shared.barrier.wait()
+                    if r == 0:           # sentinel kernels ("flip") bracket the timed steps in a kernel trace
+                        torch.arange(7, device="cuda").flip(0)
+                        torch.cuda.synchronize()
+                        shared.ncoll = 0
+                    shared.barrier.wait()
+                    if shared.token:
+                        shared.token.acquire()
                 t0 = time.perf_counter()
                 sim.main_loop(nsteps)
                 torch.cuda.synchronize()
                 wall[r] = (time.perf_counter() - t0)/nsteps
+                if world > 1:
+                    if shared.token:
+                        shared.token.release()
+                    shared.barrier.wait()
+                    if r == 0:
+                        torch.arange(7, device="cuda").flip(0)
+                        torch.cuda.synchronize()
+                        print("world %d: %d collectives in %d steps = %.1f per step" % (world, shared.ncoll, nsteps, shared.ncoll/nsteps))
+                    shared.barrier.wait()
+                    if shared.token:
+                        shared.token.acquire()
             dev = sim.device()
             out[r] = {k: np.nan_to_num(dev.download(k), nan=0.0) for k in ("h", "rho", "a", "gpot", "dudt")}
             out[r]["info"] = dev.comm_info()
+            if shared.token:
+                shared.token.release()
         except Exception as e:          # noqa: BLE001
             fail.append((r, e))
             try:
                 shared.barrier.abort()
+            except Exception:           # noqa: BLE001
+                pass
+            try:
+                if shared.token:
+                    shared.token.release()
             except Exception:           # noqa: BLE001
                 pass
 

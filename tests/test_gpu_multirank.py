@@ -182,3 +182,41 @@ def test_comm_ops_on_rccl(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
     out = subprocess.run([sys.executable, str(wf), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NCCL_OPS_OK" in out.stdout, out.stderr[-2000:]
+
+
+RCCL_WORKER = r'''
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, sys.argv[1])
+from gandalf_amd.multigpu import RcclOps, _OpsStruct
+torch.cuda.set_device(0)
+ops = RcclOps(0, 1, 0)                            # ncclGetUniqueId + ncclCommInitRank inside libgandalf_hip.so
+st = _OpsStruct.from_address(ops.ptr)
+side = torch.cuda.Stream()
+a = torch.arange(1000, dtype=torch.float64, device="cuda")
+b = torch.zeros(1000, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+rc = st.allgather(st.user, a.data_ptr(), b.data_ptr(), a.numel()*8, side.cuda_stream)
+side.synchronize()
+assert rc == 0, ops.error()
+assert torch.equal(a, b)
+c = torch.zeros(1000, dtype=torch.float64, device="cuda")
+n = (C.c_int64*1)(777*8)
+rc = st.alltoallv(st.user, a.data_ptr(), n, c.data_ptr(), n, side.cuda_stream)
+side.synchronize()
+assert rc == 0, ops.error()
+assert torch.equal(c[:777], a[:777]) and float(c[777:].abs().sum()) == 0.0
+assert ops.counters() == {"allgather": 1, "alltoallv": 1, "bytes": 8000 + 777*8}
+ops.close()
+print("RCCL_NATIVE_OK")
+'''
+
+
+def test_native_rccl_ops(tmp_path):
+    """csrc/rccl_comm.hip: the library's own RCCL binding (what bench.py --gpus N uses), with the one rank a one-GPU box
+    allows: communicator from ncclGetUniqueId / ncclCommInitRank, ncclAllGather and the send / receive group on a foreign
+    stream"""
+    wf = tmp_path/"rccl_worker.py"
+    wf.write_text(RCCL_WORKER)
+    out = subprocess.run([sys.executable, str(wf), ROOT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_NATIVE_OK" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]

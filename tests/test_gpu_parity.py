@@ -11,7 +11,9 @@ from conftest import PARAMS, load_golden
 pytestmark = pytest.mark.gpu
 
 CASES = ["box3d_4k", "plummer_4k", "adsod_1d", "plummer_4k_quintic", "plummer_4k_quadrupole", "box3d_4k_tab", "plummer_4k_tab", "adsod_1d_wadsley2008", "adsod_1d_price2008", "plummer_4k_gadget2", "plummer_4k_eigenmac", "plummer_4k_quintic_tab", "adsod_1d_mm97", "box3d_4k_mm97", "plummer_4k_mm97", "adsod_mirror", "plummer_4k_fastmono", "plummer_4k_fastquad", "adsod_1d_cd2010", "box3d_4k_cd2010", "plummer_4k_cd2010", "box3d_4k_isothermal", "plummer_4k_barotropic",
-         "lattice3d_cubic_grav", "lattice3d_hex_grav"]   # 16^3 lattices: equal coordinates at every median - the reference's quick-select tie order
+         "lattice3d_cubic_grav", "lattice3d_hex_grav",   # 16^3 lattices: equal coordinates at every median - the reference's quick-select tie order
+         # Nleafmax away from the default 6 (the reference's bossbodenheimer.dat ships 8): leaf width 1, 8 (also with quadrupoles), 16
+         "plummer_4k_nl1", "plummer_4k_nl8", "plummer_4k_nl16", "plummer_4k_nl8_quadrupole", "box3d_4k_nl8"]
 
 
 def make(case):
