@@ -953,35 +953,46 @@ extern "C" int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, 
 // point gather query (Tree::ComputeGatherNeighbourList(part, rp, rsearch, ...), Tree.cpp:208-280): ids of the particles
 // with |r - rp|^2 < rsearch^2.  Cells are opened on |rcell - rp|^2 < (rsearch + rmax)^2 like the reference; one wave.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gather_at(DevicePtrs d, double px, double py, double pz, double rsearch, int cap, int *out, int *count, int *flags)
+__global__ __launch_bounds__(64) void k_gather_at(DevicePtrs d, Domain dom, double px, double py, double pz, double rsearch, int cap, int *out, int *count, int *flags)
 {
   __shared__ WalkLDS<int> L;
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
   const double rp[3] = {px, py, pz};
   const double rs2 = rsearch*rsearch;
+  // periodic / mirror domains: the reference also searches its ghost tree (HydroTree::GetGatherNeighbourList,
+  // HydroTree.cpp:451-471) and callers map a ghost to its real parent - here the images are made on the fly and the
+  // parent's id is what comes back
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) { lo[k] = rp[k] - rsearch; hi[k] = rp[k] + rsearch; }
+  const unsigned int codes = image_codes(dom, d.ndim, lo, hi);
   int n_out = 0;
   auto cls = [&](int n, int code, bool &open, bool &emit, int &first, int &c) {
     const CellGeo g = d.cgeo[n];
     if (n >= d.gtot - 1 && g.N == 0) return;
+    double sg[3], sh[3];
+    code_xform(dom, code, sg, sh);
     double dd = 0.0;
-    for (int k = 0; k < d.ndim; k++) { const double dx = g.rcell[k] - rp[k]; dd += dx*dx; }
+    for (int k = 0; k < d.ndim; k++) { const double dx = sg[k]*g.rcell[k] + sh[k] - rp[k]; dd += dx*dx; }
     if (!(dd < (rsearch + g.rmax)*(rsearch + g.rmax))) return;
     if (n >= d.gtot - 1) { emit = true; first = g.first; c = g.N; }
     else open = true;
   };
-  auto tile = [&](bool valid, int j, int) {
+  auto tile = [&](bool valid, int j, int code) {
     bool in = false;
     if (valid) {
+      double sg[3], sh[3];
+      code_xform(dom, code, sg, sh);
       double dd = 0.0;
-      for (int k = 0; k < d.ndim; k++) { const double dx = d.f[D_RX + k][j] - rp[k]; dd += dx*dx; }
+      for (int k = 0; k < d.ndim; k++) { const double dx = sg[k]*d.f[D_RX + k][j] + sh[k] - rp[k]; dd += dx*dx; }
       in = dd < rs2;
+      if (in && d.sinks && ((int) d.f[D_FLAGS][j] & GH_FLAG_DEAD)) in = false;       // "!partdata[i].flags.is_dead()", Tree.cpp:252
     }
     const unsigned long long m = __ballot(in);
     if (in) { const int pos = n_out + __popcll(m & lt); if (pos < cap) out[pos] = d.iorig[j]; }
     n_out += __popcll(m);
   };
-  walk_dfs_stream(d, L, 1u, cls, tile, flags);
+  walk_dfs_stream(d, L, codes, cls, tile, flags);
   if (lane == 0) *count = n_out;
 }
 
@@ -995,13 +1006,18 @@ extern "C" int gh_gather_neighbours_at(gh_ctx *ctx, const double *rp, double rse
   struct Scratch { int *&a, *&b; ~Scratch() { if (a) (void) hipFree(a); if (b) (void) hipFree(b); } } scratch{d_out, d_cnt};
   GH_CHECK(ctx, hipMalloc((void**) &d_out, sizeof(int)*(size_t) cap));
   GH_CHECK(ctx, hipMalloc((void**) &d_cnt, sizeof(int)));
-  hipLaunchKernelGGL(k_gather_at, dim3(1), dim3(64), 0, ctx->stream, gh_dev(ctx), rp[0], ctx->ndim > 1 ? rp[1] : 0.0, ctx->ndim > 2 ? rp[2] : 0.0,
+  Domain dom;
+  gh_fill_domain(ctx, dom);
+  hipLaunchKernelGGL(k_gather_at, dim3(1), dim3(64), 0, ctx->stream, gh_dev(ctx), dom, rp[0], ctx->ndim > 1 ? rp[1] : 0.0, ctx->ndim > 2 ? rp[2] : 0.0,
                      rsearch, (int) cap, d_out, d_cnt, ctx->d_flags);
   int rc = gh_sync_collect(ctx, "gh_gather_neighbours_at");
   if (rc) return rc;
   int cnt = 0;
   GH_CHECK(ctx, hipMemcpy(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost));
-  if (cnt > cap) return -1;                              // the reference's "buffer too small" answer (Tree.cpp:263-265)
+  // the reference's "buffer too small" answer: it refuses a leaf cell unless Nneib + Nleafmax < Nneibmax (Tree.cpp:247,
+  // 263-265) - which leaf trips that depends on its walk order, so the answer here is -1 whenever the complete list
+  // leaves less headroom than one leaf cell (callers double the buffer and ask again, GradhSphTree.cpp:172-185)
+  if (cnt + ctx->cfg.Nleafmax >= cap) return -1;
   GH_CHECK(ctx, hipMemcpy(list, d_out, sizeof(int)*(size_t) cnt, hipMemcpyDeviceToHost));
   return cnt;
 }

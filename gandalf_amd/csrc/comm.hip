@@ -744,13 +744,18 @@ __global__ __launch_bounds__(64) void k_let_walk(DevicePtrs d, int L, int P, int
       for (int k = 0; k < NPL; k++) {
         bool push = false;
         if (open[k]) {
-          if (depth == 0) v[let_loc(n[k], L, self)] = 2;   // the published bottom cell is a leaf: its particles travel
+          if (depth == 0) v[1 + let_loc(n[k], L, self)] = 2;   // the published bottom cell is a leaf: its particles travel
           else {
             // a visited leaf travels with its particles whether or not they would be touched (a leaf with one particle enters
             // the gravity lists as a particle, Tree.cpp:713): no walk below the last-but-one level
+            // (the two children's flags are one aligned 16-bit word - the array is shifted by a byte; most visits find
+            // them set already by another entry's walk and skip the store: the byte stores of thousands of walks into
+            // the same few cache lines were what this kernel waited for)
             const bool childleaf = 31 - __clz(n[k] + 1) + 1 == d.ltot;
             const int l1 = let_loc(2*n[k] + 1, L, self);
-            v[l1] = childleaf ? 3 : 1; v[l1 + 1] = childleaf ? 3 : 1;
+            const unsigned short val = childleaf ? 0x0303 : 0x0101;
+            unsigned short *pv = (unsigned short*) (v + 1 + l1);
+            if (*pv != val) *pv = val;
             push = !childleaf;
           }
         }
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(256) void k_let_compact(int L, int self, const unsi
   const unsigned long long below = (1ull << lanei) - 1ull;
   for (int l0 = blockIdx.x*blockDim.x; l0 < nloc; l0 += gridDim.x*blockDim.x) {
     const int loc = l0 + threadIdx.x;
-    const unsigned char val = loc < nloc ? vis[(size_t) r*vis_stride + loc] : 0;
+    const unsigned char val = loc < nloc ? vis[(size_t) r*vis_stride + 1 + loc] : 0;
     int n = 0;
     if (val) { const int rl = 31 - __clz(loc + 1); n = (1 << (L + rl)) - 1 + (self << rl) + (loc - ((1 << rl) - 1)); }
     const unsigned long long cm = __ballot(val & 1);
@@ -987,7 +992,7 @@ static int dd_alloc(gh_ctx *ctx)
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cells, sizeof(int)*D->let_cellcap*W));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_leaves, sizeof(int)*D->let_leafcap*W));
   GH_CHECK(ctx, hipMalloc((void**) &D->dt_all, sizeof(double)*(W + 2)));
-  D->vis_stride = ((size_t) 2*(ctx->gtot >> ctx->L) + 255) & ~(size_t) 255;
+  D->vis_stride = ((size_t) 2*(ctx->gtot >> ctx->L) + 2 + 255) & ~(size_t) 255;     // flags of cell `loc` at byte 1 + loc
   GH_CHECK(ctx, hipMalloc((void**) &D->let_vis, D->vis_stride*(size_t) W));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_work, sizeof(LetWork)*((size_t) W << (D->P + D->F))));
   return GH_OK;
@@ -1197,14 +1202,11 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
     const int PF = P + D->F;
     int *nwork = D->let_cnt + 6*GH_MAX_RANKS, *head = nwork + 1;       // zeroed with let_cnt above
     const int nthr = W << PF;
-    int nwaves = 256*16, var = 0;                          // persistent marking waves: what the device holds of them
-    if (const char *e = getenv("GH_LW_WAVES")) nwaves = 256*atoi(e);
-    if (const char *e = getenv("GH_LW_VAR")) var = atoi(e);
+    const int nwaves = 256*16;                             // persistent marking waves: what the device holds of them
+    // (nodes per lane and round 1 / 2, stack 1024 / 2048 entries, 16 / 28 waves per CU all measured the same 220 us)
 #define LW_LAUNCH(PH, PR) { \
     hipLaunchKernelGGL((k_let_prepass<PH, PR>), dim3(cdiv(nthr, 256)), dim3(256), 0, s, d, L, P, PF, ctx->rank, W, kr, widen, D->fine_base, D->fine_stride, per, D->let_work, nwork); \
-    if (var == 1) hipLaunchKernelGGL((k_let_walk<PH, PR, 2, 2048>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); \
-    else if (var == 2) hipLaunchKernelGGL((k_let_walk<PH, PR, 1, 1024>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); \
-    else hipLaunchKernelGGL((k_let_walk<PH, PR, 1, 2048>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); }
+    hipLaunchKernelGGL((k_let_walk<PH, PR, 1, 2048>), dim3(nwaves), dim3(64), 0, s, d, L, P, ctx->rank, kr, widen, D->fine_base, D->fine_stride, D->let_vis, D->vis_stride, per, D->let_work, nwork, head); }
     if (anyper) { if (phase == GH_HALO_DENSITY) LW_LAUNCH(GH_HALO_DENSITY, true) else if (phase == GH_HALO_HYDRO) LW_LAUNCH(GH_HALO_HYDRO, true) else LW_LAUNCH(GH_HALO_GRAVITY, true) }
     else { if (phase == GH_HALO_DENSITY) LW_LAUNCH(GH_HALO_DENSITY, false) else if (phase == GH_HALO_HYDRO) LW_LAUNCH(GH_HALO_HYDRO, false) else LW_LAUNCH(GH_HALO_GRAVITY, false) }
 #undef LW_LAUNCH

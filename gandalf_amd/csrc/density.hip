@@ -37,6 +37,21 @@ struct DensityParams {
 };
 
 #define DB 4      /* candidate tiles per phase-2 batch */
+#define GH_DENS_NQ 4        /* quarter-groups per particle group (<= 16 targets each): the unit of the evaluation kernel */
+#define GH_DENS_QSHIFT 27   /* range entries: count in the low 27 bits of .y, quarter mask above */
+// quarter-group (0 .. nq-1) of particle i of group node gnode: nq = min(GH_DENS_NQ, leaves per group) subtrees
+__device__ __forceinline__ int dens_quarter(const DevicePtrs &d, int gnode, int i)
+{
+  const int nleaf = 1 << (d.ltot - d.lgroup);
+  int n = gnode, qq = 0;
+  for (int nq = min(GH_DENS_NQ, nleaf); nq > 1; nq >>= 1) {
+    const int c2 = 2*n + 2;
+    const bool right = i >= d.cfirst[c2];
+    n = right ? c2 : 2*n + 1;
+    qq = 2*qq + (right ? 1 : 0);
+  }
+  return qq;
+}
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // normalise and store the converged sums of one particle (GradhSph.cpp:262-317)
@@ -87,7 +102,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 
   const int lane = threadIdx.x;
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
-  if (P.only_if && P.only_if[q] != P.only_val) return;
+  if (P.only_if) {                                       // fallback launch: quarter-groups the split path flagged, nothing else
+    bool any = false;
+    for (int k = 0; k < GH_DENS_NQ; k++) any = any || P.only_if[GH_DENS_NQ*q + k] == P.only_val;
+    if (!any) return;
+  }
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
   if (gN == 0) return;
@@ -97,6 +116,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #endif
   // block timesteps: only the active particles are targets (GradhSphTree.cpp:128-131)
   bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  // (the evaluation kernel has stored the other quarter-groups' results already: their particles are not targets here -
+  // the reference's unit of a retry is the leaf cell, and a quarter-group is a set of whole leaf cells)
+  if (P.only_if && act) act = P.only_if[GH_DENS_NQ*q + dens_quarter(d, gnode, gfirst + lane)] == P.only_val;
   if (STALE && d.leafact) {
     // ... of the cells the reference still has on its active list (cell.Nactive of the last stocking, see k_leaf_nactive)
     const int ip = gfirst + (lane < gN ? lane : 0);
@@ -377,7 +399,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     else walk_dfs_stream(d, L, codes, cls, tile, flags);
     process_batch();
     if (__any(miss)) {                                     // incomplete sums: store nothing, the host widens the import
-      if (lane == 0) { P.fbout[q] = 2; atomicAdd(P.miss_count, 1u); }
+      if (lane == 0) atomicAdd(P.miss_count, 1u);
+      // (a fallback launch keeps the flags of quarter-groups it was not asked to do)
+      if (lane < GH_DENS_NQ && (!P.only_if || P.only_if[GH_DENS_NQ*q + lane] == P.only_val)) P.fbout[GH_DENS_NQ*q + lane] = 2;
       return;
     }
 
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     o[7] = d.ch[gnode].hmax;
   }
 #endif
-  if (P.only_if && lane == 0) P.fbout[q] = 0;
+  if (P.only_if && lane < GH_DENS_NQ && P.only_if[GH_DENS_NQ*q + lane] == P.only_val) P.fbout[GH_DENS_NQ*q + lane] = 0;
   // ---- normalise and store (GradhSph.cpp:262-317)
   if (act && !(hmaxl < hfloor)) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo, invhsqd, hmaxl);
   if (COUNT) {
@@ -450,9 +474,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 // (device-side decision, no host round trip); the evaluation kernel leaves such a group untouched.
 // ================================================================================================
 struct DensLists {
-  int2 *rl;          // [ngroups][rcap]: (first | image code << GH_NODE_BITS, count)
+  int2 *rl;          // [ngroups][rcap]: (first | image code << GH_NODE_BITS, count | quarter mask << GH_DENS_QSHIFT)
   int *rlen;         // [ngroups]
-  int *fb;           // [ngroups]: 1 = the fused kernel redoes this group
+  int *fb;           // [ngroups][GH_DENS_NQ]: 1 = the fused kernel redoes this quarter-group, 2 = ... after a wider halo import
   int rcap;
 };
 
@@ -462,15 +486,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
   __shared__ double s_lb[16][6], s_lhs[16];
+  __shared__ double s_qb[GH_DENS_NQ][6], s_qh[GH_DENS_NQ];      // quarter-groups: box of their target leaves, search h
 
   const int lane = threadIdx.x;
   const unsigned long long lt = lanemask_lt();
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
   const int gnode = (1 << d.lgroup) - 1 + q;
   const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
-  if (lane == 0) { G.rlen[q] = 0; G.fb[q] = 0; }
+  if (lane == 0) G.rlen[q] = 0;
+  if (lane < GH_DENS_NQ) G.fb[GH_DENS_NQ*q + lane] = 0;
   if (gN == 0) return;
   const int nleaf = 1 << (d.ltot - d.lgroup);
+  const int nq = min(GH_DENS_NQ, nleaf), lpq = nleaf/nq;      // quarter-groups of this group, leaves per quarter
   const int leafnode0 = (d.gtot - 1) + q*nleaf;
   // per leaf: bounding box and search h = 1.05 * hmax(leaf); 0 for leaves without a target particle
   double hl = 0.0;
@@ -488,6 +515,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }
   const double hs = wave_max(hl), hmn = wave_min(hl > 0.0 ? hl : 1e300);
   if (!(hs > 0.0)) return;
+  __syncthreads();
+  if (lane < nq) {
+    double qh = 0.0, b[6] = {1e300, 1e300, 1e300, -1e300, -1e300, -1e300};
+    for (int l = lane*lpq; l < (lane + 1)*lpq; l++) {
+      if (s_lhs[l] > 0.0) {
+        qh = fmax(qh, s_lhs[l]);
+        for (int k = 0; k < 3; k++) { b[k] = fmin(b[k], s_lb[l][k]); b[3 + k] = fmax(b[3 + k], s_lb[l][3 + k]); }
+      }
+    }
+    for (int k = 0; k < 6; k++) s_qb[lane][k] = b[k];
+    s_qh[lane] = qh;
+  }
   const CellBox gb = d.cbox[gnode];
   double lo[3], hi[3];
   double extmax = 0.0;
@@ -521,6 +560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int newtop = top - p;
     bool open = false, emit = false;
     int n = 0, code = 0, first = 0, cnt = 0;
+    unsigned int qm = 0;
     if (lane < p) {
       const int e = s_stack[top - 1 - lane];
       n = e & GH_NODE_MASK; code = e >> GH_NODE_BITS;
@@ -559,7 +599,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           inside = false;      // whole-subtree emission is a group-box shortcut: descend to the leaves instead
         }
         if (keep) {
-          if (inside || n >= d.gtot - 1) { emit = true; first = b.first; cnt = b.N; }
+          if (inside || n >= d.gtot - 1) {
+            // which quarter-groups can have a particle of theirs within kernrange * h of this range?  (the evaluation
+            // kernel runs per quarter and expands only the ranges that carry its bit)
+            for (int qq = 0; qq < nq; qq++) {
+              const double hq = s_qh[qq];
+              if (hq > 0.0) {
+                double g2 = 0.0;
+                for (int k = 0; k < ND; k++) {
+                  const double gk = fmax(fmax(bmin[k] - s_qb[qq][3 + k], s_qb[qq][k] - bmax[k]), 0.0);
+                  g2 += gk*gk;
+                }
+                const double rq = K::kernrange*hq;
+                if (g2 <= rq*rq*(1.0 + 1e-12)) qm |= 1u << qq;
+              }
+            }
+            if (qm) { emit = true; first = b.first; cnt = b.N; }
+          }
           else open = true;
         }
       }
@@ -577,7 +633,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
     if (emit) {
       const int pos = nout + __popcll(em & lt);
-      if (pos < G.rcap) rl[pos] = make_int2(first | (code << GH_NODE_BITS), cnt);
+      if (pos < G.rcap) rl[pos] = make_int2(first | (code << GH_NODE_BITS), cnt | (int) (qm << GH_DENS_QSHIFT));
     }
     nout += __popcll(em);
     __syncthreads();
@@ -585,40 +641,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if (nout > G.rcap) overflow = true;
   const bool anymiss = __any(miss);
   if (lane == 0) {
-    G.rlen[q] = (overflow || anymiss) ? 0 : nout; G.fb[q] = anymiss ? 2 : (overflow ? 1 : 0);
+    G.rlen[q] = (overflow || anymiss) ? 0 : nout;
     if (anymiss) atomicAdd(P.miss_count, 1u);
   }
+  if (lane < GH_DENS_NQ) G.fb[GH_DENS_NQ*q + lane] = anymiss ? 2 : (overflow ? 1 : 0);
 }
 
 #define GH_DENS_RCAP 512   /* candidate ranges per group held by the split path */
-#define DBE 2     /* candidate tiles per phase-2 batch of the evaluation kernel */
-#define GH_DENS_ICAP 1536   /* candidate slots of one group held in LDS as particle indices */
+#define GH_DENS_ICAP 1536   /* candidate slots of one quarter-group held in LDS as particle indices */
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-template <int ND, bool COUNT, int KT>
+// Evaluation: one wavefront per QUARTER-group (<= 64/S target particles: 16 for the usual 16-leaf group, S = 4), S
+// sub-lanes per target.  A 64-particle group culls ~1 000 candidate slots per particle to keep ~70 (its search box is 9
+// interparticle spacings wide, a kernel 5); a quarter-group's box is 7.5 wide - ~420 slots, the ranges the walk tagged
+// with the quarter's bit - and the S sub-lanes of a target share them: lane (t, s) tests the candidate pairs s, s + S, ...
+// of a tile in packed fp32 and evaluates the survivors in fp64; the three sums are added over the sub-lanes (two
+// xor-shuffles) at the end of an h iteration, after which all sub-lanes take the same decision.  Per 64 targets that is
+// 2.4 x fewer cull tests, and the fp64 work of a target (whose neighbours come in runs of consecutive slots: leaves) is
+// dealt round-robin to its sub-lanes.  S = 2 / 1: groups of 2 / 1 leaves (Nleafmax 16 / 32).
+template <int ND, bool COUNT, int KT, int S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
                                                                                        unsigned long long *stats, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
+  constexpr int TC = 64/S;                                 // targets per wave
+  constexpr int PPT = 32/S;                                // candidate pairs per tile and lane
+  constexpr int NB = S;                                    // tiles per batch: NB * 2 * PPT = 64 mask bits per lane
   __shared__ int s_idx[GH_DENS_ICAP];                      // particle index | image code << GH_NODE_BITS, -1 = padding
-  __shared__ double s_x[DBE*64], s_y[DBE*64], s_z[DBE*64], s_m[DBE*64];
-  __shared__ unsigned long long s_mask[DBE][64];
-  // current tile in fp32, relative to the group centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
+  __shared__ double s_x[NB*64], s_y[NB*64], s_z[NB*64], s_m[NB*64];
+  // current tile in fp32, relative to the quarter's centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
   // records: one 16-byte + one 8-byte LDS read feed two packed-fp32 distance evaluations)
   __shared__ __attribute__((aligned(16))) float s_f[32][8];
 
   const int lane = threadIdx.x;
+  const int tl = lane & (TC - 1), sl = lane/TC;            // target slot, sub-lane
   const int q = P.group0 + block_to_group(blockIdx.x, gridDim.x);
+  const int qq = blockIdx.y;
   const int gnode = (1 << d.lgroup) - 1 + q;
-  const int gfirst = d.cfirst[gnode], gN = d.cN[gnode];
-  if (gN == 0 || G.fb[q]) return;
+  if (d.cN[gnode] == 0 || G.fb[GH_DENS_NQ*q + qq]) return;
+  const int nleaf = 1 << (d.ltot - d.lgroup);
+  const int nq = min(GH_DENS_NQ, nleaf);
+  if (qq >= nq) return;
+  int lq = 0;
+  while ((1 << lq) < nq) lq++;
+  const int qnode = (1 << (d.lgroup + lq)) - 1 + q*nq + qq;
+  const int qfirst = d.cfirst[qnode], qN = d.cN[qnode];
+  if (qN == 0) return;
+  if (qN > TC) { if (lane == 0) G.fb[GH_DENS_NQ*q + qq] = 1; return; }      // (cannot happen with balanced median splits)
   const int nr = G.rlen[q];
-  const bool act = lane < gN && (!d.levels || ((int) d.f[D_FLAGS][gfirst + lane] & 1));
+  const bool act = tl < qN && (!d.levels || ((int) d.f[D_FLAGS][qfirst + tl] & 1));
   if (!__any(act)) return;
 
-  // ---- the group's candidate ranges are expanded into a flat index list in LDS, GH_DENS_ICAP slots at a time: the
-  //      tile loop then knows every address in advance (the next tile's records are in flight while the current one
-  //      is culled).  Most groups fit in one fill, which is then kept for all h iterations.
+  // ---- the candidate ranges that carry this quarter's bit are expanded into a flat index list in LDS, GH_DENS_ICAP slots
+  //      at a time: the tile loop then knows every address in advance (the next tile's records are in flight while the
+  //      current one is culled).  Most quarters fit in one fill, which is then kept for all h iterations.
   const int2 *rl = G.rl + (size_t) q*G.rcap;
   int c0 = 0, ntot = 0;
   bool whole = false;
@@ -631,7 +707,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
       const int e = c0 + lane;
       int2 ent = make_int2(0, 0);
       if (e < nr) ent = rl[e];
-      const int first = ent.x & GH_NODE_MASK, code = ent.x >> GH_NODE_BITS, cnt = ent.y;
+      const int first = ent.x & GH_NODE_MASK, code = ent.x >> GH_NODE_BITS;
+      const int cnt = ((ent.y >> (GH_DENS_QSHIFT + qq)) & 1) ? (ent.y & ((1 << GH_DENS_QSHIFT) - 1)) : 0;
       int inc = cnt;
       for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
       const int excl = inc - cnt, tot = __shfl(inc, 63, 64);
@@ -658,19 +735,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     return true;
   };
 
-  const int i = gfirst + (act ? lane : 0);
+  const int i = qfirst + (act ? tl : 0);
   const double invndim = 1.0/(double) ND;
   double ri[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < ND; k++) ri[k] = d.f[D_RX + k][i];
   const double mi = d.f[D_M][i];
   double ui = d.f[D_U][i];
-  const CellBox gb = d.cbox[gnode];
+  const CellBox gb = d.cbox[qnode];
   double gc[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < ND; k++) gc[k] = 0.5*(gb.bbmin[k] + gb.bbmax[k]);
   float tf[3] = {0.f, 0.f, 0.f};
   for (int k = 0; k < ND; k++) tf[k] = (float) (ri[k] - gc[k]);
   // the lane's leaf cell: hmax = 1.05 * cell.hmax bounds its iterates (first try of GradhSphTree.cpp:141-226)
-  int leafn = gnode;
+  int leafn = qnode;
   while (leafn < d.gtot - 1) { const int c2 = 2*leafn + 2; leafn = (i >= d.cfirst[c2]) ? c2 : 2*leafn + 1; }
   const double hmaxl = 1.05*d.ch[leafn].hmax;
   const double h0 = d.f[D_H][i];
@@ -682,7 +759,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   double invh = 0.0, hfactor = 0.0, invhsqd = 0.0;
   unsigned long long n_iter = 0, n_cand = 0, n_tested = 0;
   const double cullsqd = K::kernrangesqd*hmaxl*hmaxl;
-  double Rmax = 0.0;                                       // largest |coordinate - group centre| a candidate can have
+  double Rmax = 0.0;                                       // largest |coordinate - quarter centre| a candidate in reach can have
   {
     double hs = wave_max(act ? hmaxl : 0.0);
     for (int k = 0; k < ND; k++) Rmax = fmax(Rmax, 0.5*(gb.bbmax[k] - gb.bbmin[k]) + K::kernrange*hs);
@@ -698,20 +775,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
       invh = 1.0/h;
       hfactor = powN<ND>(invh);
       invhsqd = invh*invh;
-      rho = 0.0; omg = 0.0; zet = 0.0;
     }
+    double prho = 0.0, pomg = 0.0, pzet = 0.0;            // this lane's share of the three sums
     // fp32 cull threshold: a superset of {invhsqd*r2 < kernrangesqd} (see k_density)
     const float thr = running ? (float) ((K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(1.0 + 1e-6)) : -1.0f;
     int nb = 0;
+    unsigned long long mk = 0ull;                          // bit (tile of the batch)*2*PPT + 2*(own pair) + (member of the pair)
     auto process_batch = [&]() {
-      int b = 0;
-      unsigned long long mask = nb > 0 ? s_mask[0][lane] : 0ull;
-      for (;;) {
-        while (mask == 0ull && b + 1 < nb) mask = s_mask[++b][lane];
-        if (!__any(mask != 0ull)) break;
-        if (mask != 0ull) {
-          const int c = b*64 + __ffsll((long long) mask) - 1;
-          mask &= mask - 1ull;
+      while (__any(mk != 0ull)) {
+        if (mk != 0ull) {
+          const int p = __ffsll((long long) mk) - 1;
+          mk &= mk - 1ull;
+          const int b = p/(2*PPT), u = p - b*(2*PPT);
+          const int c = b*64 + 2*(sl + (u >> 1)*S) + (u & 1);
           double dr[3] = {0.0, 0.0, 0.0};
           dr[0] = s_x[c] - ri[0];
           if (ND > 1) dr[1] = s_y[c] - ri[1];
@@ -725,9 +801,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
             const double s2 = invhsqd*r2;                              // w0_s2(ssqd) etc., GradhSph.cpp:200-203
             double kw0, kwom, kwz;
             K::t_dens3(s2, P.ktab, kw0, kwom, kwz);
-            rho += mj*kw0;
-            omg += mj*invh*kwom;
-            zet += mj*kwz;
+            prho += mj*kw0;
+            pomg += mj*invh*kwom;
+            pzet += mj*kwz;
           }
         }
       }
@@ -740,7 +816,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
       if (!whole || ntot == 0) {
         __syncthreads();
         if (!fill()) {
-          if (lane == 0) G.fb[q] = 1;
+          if (lane == 0) G.fb[GH_DENS_NQ*q + qq] = 1;
           return;
         }
       }
@@ -772,51 +848,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         }
         __syncthreads();
         // support mask in packed fp32: dd = |r_c - r_i|^2 - thr from three packed FMAs per candidate pair; its sign bit
-        // (set = inside the conservative threshold) is shifted into the mask by one v_alignbit_b32 per candidate, so
-        // candidate c lands in bit 31 - (c & 31) of word c >> 5: the words are bit-reversed at the end.
-        unsigned int mlo = 0, mhi = 0;
+        // (set = inside the conservative threshold) is shifted into the mask by one v_alignbit_b32 per candidate: own pair k
+        // (candidates 2*(sl + k*S), + 1) lands in bits 31 - 2k, 30 - 2k of the word, which is bit-reversed at the end.
+        unsigned int mw = 0;
         {
           const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]}, nthr = {-thr, -thr};
-          auto pairbits = [&](int c2, unsigned int m) -> unsigned int {
+#pragma unroll
+          for (int k = 0; k < PPT; k++) {
+            const int c2 = sl + k*S;
             const float4_t xy = *((const float4_t*) &s_f[c2][0]);
             const float2_t zz = *((const float2_t*) &s_f[c2][4]);
             const float2_t dx = (float2_t) {xy.x, xy.y} - tx;
             float2_t dd = __builtin_elementwise_fma(dx, dx, nthr);
             if (ND > 1) { const float2_t dy = (float2_t) {xy.z, xy.w} - ty; dd = __builtin_elementwise_fma(dy, dy, dd); }
             if (ND > 2) { const float2_t dz = zz - tz; dd = __builtin_elementwise_fma(dz, dz, dd); }
-            m = __builtin_amdgcn_alignbit(m, __float_as_uint(dd.x), 31);
-            return __builtin_amdgcn_alignbit(m, __float_as_uint(dd.y), 31);
-          };
-#pragma unroll
-          for (int c2 = 0; c2 < 16; c2++) mlo = pairbits(c2, mlo);
-#pragma unroll
-          for (int c2 = 16; c2 < 32; c2++) mhi = pairbits(c2, mhi);
-          mlo = __brev(mlo); mhi = __brev(mhi);
+            if constexpr (S == 1) { if (k == 16) { mk |= (unsigned long long) __brev(mw); mw = 0; } }       // S = 1: 64 bits in two words
+            mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(dd.x), 31);
+            mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(dd.y), 31);
+          }
         }
-        s_mask[nb][lane] = (unsigned long long) mlo | ((unsigned long long) mhi << 32);
+        // after PPT pairs the word holds 2*PPT bits, first pair on top: reversed, pair k sits at bits 2k, 2k + 1
+        if constexpr (S == 1) mk |= (unsigned long long) __brev(mw) << 32;
+        else mk |= (unsigned long long) (__brev(mw) >> (32 - 2*PPT)) << (nb*2*PPT);
         if (COUNT) {
           if (running) {
-            for (int c = 0; c < 64; c++) {
+            for (int k = 0; k < 2*PPT; k++) {
+              const int c = o + 2*(sl + (k >> 1)*S) + (k & 1);
               double r2 = 0.0;
-              { const double dx = s_x[o + c] - ri[0]; r2 = dx*dx; }
-              if (ND > 1) { const double dy = s_y[o + c] - ri[1]; r2 += dy*dy; }
-              if (ND > 2) { const double dz = s_z[o + c] - ri[2]; r2 += dz*dz; }
+              { const double dx = s_x[c] - ri[0]; r2 = dx*dx; }
+              if (ND > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
+              if (ND > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
               if (r2 + GH_SMALL <= cullsqd) n_cand++;
             }
-            n_tested += 64;
+            n_tested += 2*PPT;
           }
         }
         nb++;
-        if (nb == DBE) process_batch();
+        if (nb == NB) process_batch();
         else __syncthreads();
       }
       if (whole) break;
     }
     process_batch();
+    // the S sub-lanes of a target add their partial sums (lanes tl + TC*s): all of them then hold the same three numbers
+    for (int off = TC; off < 64; off <<= 1) { prho += __shfl_xor(prho, off, 64); pomg += __shfl_xor(pomg, off, 64); pzet += __shfl_xor(pzet, off, 64); }
 
     bool failed = false;
     if (running) {
-      rho *= hfactor; omg *= hfactor; zet *= invhsqd;
+      rho = prho*hfactor; omg = pomg*hfactor; zet = pzet*invhsqd;
       const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
       if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
       else {
@@ -835,16 +914,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
       }
     }
     // the reference now redoes the leaf cell with hmax*1.05 - a search volume the list does not cover: hand the
-    // whole group to the fused kernel (nothing has been stored yet)
+    // quarter-group (whole leaf cells; nothing of it has been stored yet) to the fused kernel
     if (__any(failed)) {
-      if (lane == 0) G.fb[q] = 1;
+      if (lane == 0) G.fb[GH_DENS_NQ*q + qq] = 1;
       return;
     }
   }
 
-  if (act && !(hmaxl < hfloor)) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo, invhsqd, hmaxl);
+  if (act && sl == 0 && !(hmaxl < hfloor)) density_store<ND, K>(d, P, i, mi, ui, rho, omg, zet, hlo, invhsqd, hmaxl);
   if (COUNT) {
-    const unsigned long long a = wave_sum_u64(act ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0);
+    const unsigned long long a = wave_sum_u64(act && sl == 0 ? n_iter : 0), b = wave_sum_u64(act ? n_cand : 0);
     const unsigned long long t = wave_sum_u64(act ? n_tested : 0);
     if (lane == 0) { atomicAdd(&stats[ST_ITER], a); atomicAdd(&stats[ST_CAND], b); atomicAdd(&stats[ST_PAIRS], t); }
   }
@@ -909,8 +988,8 @@ int gh_density_impl(gh_ctx *ctx, bool count, bool redo_only)
     for (void *p : {(void*) ctx->dl_rl, (void*) ctx->dl_rlen}) if (p) (void) hipFree(p);
     ctx->dl_rl = nullptr; ctx->dl_rlen = nullptr; ctx->dl_groups = 0;
     GH_CHECK(ctx, hipMalloc((void**) &ctx->dl_rl, sizeof(int2)*(size_t) ctx->ngroups*G.rcap));
-    GH_CHECK(ctx, hipMalloc((void**) &ctx->dl_rlen, sizeof(int)*2*(size_t) ctx->ngroups));
-    GH_CHECK(ctx, hipMemset(ctx->dl_rlen, 0, sizeof(int)*2*(size_t) ctx->ngroups));
+    GH_CHECK(ctx, hipMalloc((void**) &ctx->dl_rlen, sizeof(int)*(1 + GH_DENS_NQ)*(size_t) ctx->ngroups));
+    GH_CHECK(ctx, hipMemset(ctx->dl_rlen, 0, sizeof(int)*(1 + GH_DENS_NQ)*(size_t) ctx->ngroups));
     ctx->dl_groups = ctx->ngroups;
   }
   G.rl = (int2*) ctx->dl_rl; G.rlen = ctx->dl_rlen; G.fb = ctx->dl_rlen + ctx->ngroups;
@@ -918,13 +997,17 @@ int gh_density_impl(gh_ctx *ctx, bool count, bool redo_only)
   P.miss_count = (unsigned int*) (ctx->d_blk + 12);
   const bool dd = ctx->nranks > 1;
   if (dd && !redo_only) GH_CHECK(ctx, hipMemsetAsync(P.miss_count, 0, sizeof(unsigned int), s));
-  if (dd && fused_only && !redo_only) GH_CHECK(ctx, hipMemsetAsync(G.fb, 0, sizeof(int)*(size_t) ctx->ngroups, s));
+  if (dd && fused_only && !redo_only) GH_CHECK(ctx, hipMemsetAsync(G.fb, 0, sizeof(int)*GH_DENS_NQ*(size_t) ctx->ngroups, s));
   gh_phase_begin(ctx, GH_T_SPH_PROPERTIES);
+  // evaluation: one wave per quarter-group (min(4, leaves per group) subtrees of <= 64/S particles, S sub-lanes per target)
+  const int nqg = std::min(GH_DENS_NQ, 1 << (ctx->ltot - ctx->lgroup));
+#define LAUNCH_EVAL(ND_, KT_, S_) \
+    if (count) hipLaunchKernelGGL((k_dens_eval<ND_, true, KT_, S_>), dim3(nblocks, nqg), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags); \
+    else hipLaunchKernelGGL((k_dens_eval<ND_, false, KT_, S_>), dim3(nblocks, nqg), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags);
   if (nblocks > 0 && !fused_only && !redo_only) {
 #define LAUNCH(ND_, KT_)                                                                                      \
     hipLaunchKernelGGL((k_dens_walk<ND_, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_flags);        \
-    if (count) hipLaunchKernelGGL((k_dens_eval<ND_, true, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags); \
-    else hipLaunchKernelGGL((k_dens_eval<ND_, false, KT_>), dim3(nblocks), dim3(64), 0, s, d, P, G, ctx->d_stats, ctx->d_flags);
+    if (nqg == 4) { LAUNCH_EVAL(ND_, KT_, 4) } else if (nqg == 2) { LAUNCH_EVAL(ND_, KT_, 2) } else { LAUNCH_EVAL(ND_, KT_, 1) }
     GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
     P.only_if = G.fb;        // the fused kernel redoes what the split path flagged (early exit per group otherwise)

@@ -238,8 +238,8 @@ __global__ __launch_bounds__(64) void k_hydro_forces(DevicePtrs d, ForceParams P
 #define STAMP_ADD(slot, t0)
 #endif
 
-// near-list entry: first particle (27 bits) | count << 27
-__device__ __forceinline__ int near_entry(int first, int n) { return first | (n << 27); }
+// near-list entry: first particle (26 bits, like GH_NODE_BITS) | count << 26 (6 bits: leaves of up to 32 particles, Nleafmax <= 32)
+__device__ __forceinline__ int near_entry(int first, int n) { return first | (int) ((unsigned int) n << 26); }
 
 template <int ND, bool COUNT, int KT, bool TDAV = false>
 __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P, unsigned long long *stats, int *flags, const int *only_if)
@@ -259,7 +259,9 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   // own lists of near leaves and every lane streams exactly its leaf's particles.
   __shared__ int s_ndir[GH_MAXLEAF][GH_NDCAP], s_nhyd[GH_MAXLEAF][GH_NHCAP];
   __shared__ int s_nlen[2][GH_MAXLEAF];
-  __shared__ unsigned int s_sphbits[(GH_NHCAP*6 + 31)/32][64];   // per lane: which streamed candidates are SPH neighbours
+  // per lane: which streamed candidates are SPH neighbours.  2 048 (entry, slot) bits: the near lists are flushed before
+  // (pending entries + 64) * leaf width can exceed them (hthr below; leaves of up to 32 particles)
+  __shared__ unsigned int s_sphbits[64][64];
   __shared__ double s_lrc[GH_MAXLEAF][3], s_lrmax[GH_MAXLEAF], s_lhr[GH_MAXLEAF];
 
   const int lane = threadIdx.x;
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   A.gpot = (d.f[D_M][i]/d.f[D_H][i])*K::t_wpot0(P.ktab);      // self term, GradhSphTree.cpp:512
   unsigned long long n_pairs = 0, n_direct = 0, n_cells = 0;
   const int occ = d.leafocc;
+  const int hthr = min(GH_NHCAP - 64, 2048/occ - 64);   // near lists are flushed beyond this many pending hydro entries
 
   int maxlen_d = 0, maxlen_h = 0;                     // wave-uniform maxima of the near-list lengths
   int len_d[GH_MAXLEAF], len_h[GH_MAXLEAF];
@@ -348,10 +351,13 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
     // direct-only leaves: Newtonian particle terms                  (GradhSph.cpp:671-686).
     // Software pipeline: the records of entry e+1 are in flight while entry e is evaluated.
     {
-      auto dload = [&](int e, double4 (&v)[6], int &cnt) {
+      // (unit = six consecutive slots of an entry's leaf: leaves wider than 6 particles take nck units per entry)
+      const int nck = (occ + 5)/6;
+      auto dload = [&](int u, double4 (&v)[6], int &cnt) {
+        const int e = u/nck, k0 = (u - e*nck)*6;
         const int ent = e < Ld ? s_ndir[myleaf][e] : 0;
-        const int first = ent & 0x7ffffff;
-        cnt = act ? (ent >> 27) & 0xf : 0;
+        const int first = (ent & 0x3ffffff) + k0;
+        cnt = act ? max((int) ((unsigned int) ent >> 26) - k0, 0) : 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) { v[k].x = 1e30; v[k].y = 1e30; v[k].z = 1e30; v[k].w = 0.0; if (k < cnt) v[k] = d.posm[first + k]; }
       };
@@ -360,16 +366,17 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
         for (int k = 0; k < 6; k++) {
           if (k < occ) point_mass<ND>(ti, A, v[k].x, v[k].y, v[k].z, v[k].w);
         }
-        if (COUNT) n_direct += cnt;
+        if (COUNT) n_direct += min(cnt, 6);
       };
       double4 va[6], vb[6];
       int ca = 0, cb = 0;
-      if (maxd > 0) dload(0, va, ca);
-      for (int e = 0; e < maxd; e += 2) {
+      const int maxu = maxd*nck;
+      if (maxu > 0) dload(0, va, ca);
+      for (int e = 0; e < maxu; e += 2) {
         dload(e + 1, vb, cb);
         dcomp(va, ca);
         dload(e + 2, va, ca);
-        if (e + 1 < maxd) dcomp(vb, cb);
+        if (e + 1 < maxu) dcomp(vb, cb);
       }
     }
     STAMP_ADD(2, tn0);
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
       auto hload = [&](int t, double4 &q0, double &hr2, bool &valid) {
         const int e = t/occ, k = t - e*occ;
         const int ent = e < Lh ? s_nhyd[myleaf][e] : 0;
-        const int first = ent & 0x7ffffff, cnt = act ? (ent >> 27) & 0xf : 0;
+        const int first = ent & 0x3ffffff, cnt = act ? (int) ((unsigned int) ent >> 26) : 0;
         valid = k < cnt;
         q0.x = 1e30; q0.y = 1e30; q0.z = 1e30; q0.w = 0.0; hr2 = 0.0;
         if (valid) { const double4 *r = d.hrec + 4*(size_t) (first + k); q0 = r[0]; hr2 = r[1].w; }
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
           const int t = w*32 + __ffs((int) bits) - 1;
           bits &= bits - 1u;
           const int e = t/occ, k = t - e*occ;
-          const int first = s_nhyd[myleaf][e] & 0x7ffffff;
+          const int first = s_nhyd[myleaf][e] & 0x3ffffff;
           const double4 *r = d.hrec + 4*(size_t) (first + k);
           const double4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
           Neib nb;
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(64) void k_grav_forces(DevicePtrs d, ForceParams P,
   const int leaf0 = d.gtot - 1;
   while (top > 0) {
     if (ncell > 64) flush_cells();
-    if (maxlen_d > GH_NDCAP - 64 || maxlen_h > GH_NHCAP - 64) flush_near();
+    if (maxlen_d > GH_NDCAP - 64 || maxlen_h > hthr) flush_near();
     STAMP(tw0);
     const int p = pop_width(top);
     const int newtop = top - p;

@@ -28,7 +28,7 @@ int gh_grav_fused_launch(gh_ctx *ctx, bool count, const int *only_if);
 #define GH_SPHCAP 448        /* SPH neighbours of one particle held in LDS (SURVEY: max 393 at 4k Plummer) */
 
 struct GravLists {
-  int *cells, *dirl;         // [gtot][cap_*]: node ids / (first | N << 27) leaf entries
+  int *cells, *dirl;         // [gtot][cap_*]: node ids / (first | N << 26) leaf entries
   int *gcells;               // [ngroups][cap_g]: cells accepted by EVERY leaf of a group (stored once)
   int *glen;                 // [ngroups]
   int2 *hydl;                // [gtot][cap_h]: (first, count) particle ranges - a leaf, or a whole subtree
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_grav_walk(DevicePtrs d, ForceParams P, G
       top = top + 2*__popcll(om);
       if (top > GH_SCAP) { overflow = true; top = GH_SCAP; }
       if (anycell | anynear) {
-        const int nent = g.first | (g.N << 27);
+        const int nent = g.first | (int) ((unsigned int) g.N << 26);
 #pragma unroll
         for (int l = 0; l < GH_MAXLEAF; l++) {
           if (l < nl) {
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   for (int c0 = 0; c0 < lend; c0 += 64) {
     const int e = c0 + lane;
     const int ent = dirl[e < lend ? e : lend - 1];
-    const int pf = ent & 0x7ffffff, pn = e < lend ? ((ent >> 27) & 0xf) : 0;
+    const int pf = ent & 0x3ffffff, pn = e < lend ? (int) ((unsigned int) ent >> 26) : 0;
     // particle k of the entry's leaf; clamped unconditional loads, one ahead of the arithmetic
     double4 v = d.posm[pf];
     int kmax = pn;

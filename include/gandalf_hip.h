@@ -242,7 +242,10 @@ int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep);
 int gh_gather_neighbours(gh_ctx *ctx, int64_t cap, int64_t *offsets, int32_t *ids);
 /* replaces: NeighbourSearch::GetGatherNeighbourList(rp, rsearch, ...) -> Tree::ComputeGatherNeighbourList (NeighbourSearch.h:82,
  * Tree.cpp:208-280; the sink search uses it): caller-order ids of the particles with |r - rp|^2 < rsearch^2 around an arbitrary
- * point rp[ndim].  Returns the count (>= 0), -1 if more than `cap` were found (the reference's overflow answer), or
+ * point rp[ndim].  Periodic / mirror domains: particles also count through their images (the reference finds those in its ghost
+ * tree, HydroTree.cpp:451-471; the id returned is the real particle's).  Sink runs: accreted (dead) particles are left out
+ * (Tree.cpp:252).  Returns the count (>= 0); -1 = the reference's overflow answer, given whenever the complete list leaves
+ * less than Nleafmax free slots of `cap` (the reference refuses a leaf cell unless Nneib + Nleafmax < Nneibmax, Tree.cpp:247);
  * GH_ERR_HIP / GH_ERR_UNSUPPORTED (bad arguments, no tree, more than one rank). */
 int gh_gather_neighbours_at(gh_ctx *ctx, const double *rp, double rsearch, int32_t *list, int32_t cap);
 /* device time (ms) spent in each phase since the last call to gh_reset_timers, reference block

@@ -84,7 +84,13 @@ clean:
 
 # ---- compile + link check of the reference-side binding (include/reference_shell/HipSphTree.h) against the reference's
 #      headers and libgandalf_hip.so.  Build container only; the binary is never run.
-hipshell: $(OUT)/hipshell_check
+hipshell: $(OUT)/hipshell_check $(OUT)/ref_hipshell
+# ... and the driver that EXECUTES it: ref_dump with the reference's GradhSphSimulation running on HipSphTree ("hipsteps" etc.;
+# tests/test_gpu_boundary.py).  The run path is relative, so the binary finds libgandalf_hip.so on the GPU box too.
+$(OUT)/ref_hipshell: oracle/ref_dump.cpp include/reference_shell/HipSphTree.h include/gandalf_hip.h gandalf_amd/csrc/libgandalf_hip.so $(OUT)/libgandalf_ref.a
+	$(CXX) $(CXXFLAGS) -fexceptions -DREF_HIPSHELL -Iinclude -Iinclude/reference_shell oracle/ref_dump.cpp -o $@ \
+	    -Wl,--whole-archive $(OUT)/libgandalf_ref.a -Wl,--no-whole-archive -Lgandalf_amd/csrc -lgandalf_hip \
+	    -Wl,-rpath,'$$ORIGIN/../../gandalf_amd/csrc' -Wl,--unresolved-symbols=ignore-in-shared-libs
 $(OUT)/hipshell_check: oracle/hipshell_check.cpp include/reference_shell/HipSphTree.h include/gandalf_hip.h gandalf_amd/csrc/libgandalf_hip.so | $(OUT)/obj
 	$(CXX) -O0 -fno-exceptions -DGANDALF_DOUBLE_PRECISION -I$(REF)/src/Headers -I$(REF)/src/Common -Iinclude -Iinclude/reference_shell -w \
 	  oracle/hipshell_check.cpp -o $@ -Lgandalf_amd/csrc -lgandalf_hip -L$(OUT) -lgandalf_ref -fopenmp -Wl,-rpath,$(abspath gandalf_amd/csrc) -Wl,--unresolved-symbols=ignore-in-shared-libs

@@ -54,6 +54,11 @@
 #include "NeighbourSearch.h"
 #include "SphNeighbourSearch.h"
 #include "Sinks.h"
+#ifdef REF_HIPSHELL
+// the reference-side binding of libgandalf_hip (include/reference_shell/HipSphTree.h): ref_hipshell = this driver with
+// the reference's own GradhSphSimulation running on a HipSphTree instead of its KD-tree (modes prefixed "hip")
+#include "HipSphTree.h"
+#endif
 
 using namespace std;
 
@@ -148,6 +153,7 @@ static void dump_tree(Dump &out, Simulation<ndim> *sim)
 {
   typedef KDTree<ndim, GradhSphParticle, KDTreeCell> TreeT;
   TreeT *tree = static_cast<TreeT*>(sim->sphneib->GetTree());
+  if (!tree) return;                                  // HipSphTree: the tree lives on the device
   KDTreeCell<ndim> *cd = tree->celldata;
   const int Nc = tree->Ncell;
   { vector<int> v; v.push_back(tree->Ncell); v.push_back(tree->ltot); v.push_back(tree->gtot); v.push_back(tree->Ntot); v.push_back(tree->Nleafmax); out.i("tree_Ncell_ltot_gtot_Ntot_Nleafmax", v); }
@@ -197,10 +203,30 @@ static void set_all_active(Simulation<ndim> *sim)
 }
 
 template <int ndim>
-static int run(const string &mode, Parameters *params, SimulationBase *simbase, int argc, char **argv)
+static int run(const string &mode_in, Parameters *params, SimulationBase *simbase, int argc, char **argv)
 {
+  const bool hip = mode_in.compare(0, 3, "hip") == 0;          // hipsteps, hippasses, hiptime: the same modes through HipSphTree
+  const string mode = hip ? mode_in.substr(3) : mode_in;
+#ifndef REF_HIPSHELL
+  if (hip) { fprintf(stderr, "ref_dump: hip* modes need the ref_hipshell build (make -f oracle/ref.mk hipshell)\n"); return 1; }
+#endif
   Simulation<ndim> *sim = static_cast<Simulation<ndim>*>(simbase);
   Sph<ndim> *sph;
+#ifdef REF_HIPSHELL
+  if (hip) {
+    // SimulationBase::SetupSimulation (Simulation.cpp:639-694) call for call, with the neighbour-search object the
+    // parameter processing made (GradhSphSimulation.cpp:232-246) replaced by the HIP binding before the IC is generated:
+    // PostInitialConditionsSetup and every MainLoop then run the reference's own code against libgandalf_hip.so
+    sim->ProcessParameters();
+    HipSphTree<ndim> *shell = new HipSphTree<ndim>(sim->simparams, &sim->simbox, static_cast<Sph<ndim>*>(sim->hydro));
+    sim->sphneib = shell; sim->neib = shell;
+    sim->GenerateIC();
+    if (sim->simparams->intparams["com_frame"] == 1) sim->SetComFrame();
+    sim->PostInitialConditionsSetup();
+    sim->Output();
+  }
+  else
+#endif
   sim->SetupSimulation();
   sph = static_cast<Sph<ndim>*>(sim->hydro);
 

@@ -415,3 +415,21 @@ def test_point_gather_query_matches_brute_force():
         want = np.nonzero(((r - rp)**2).sum(axis=1) < rs*rs)[0]
         assert ids is not None and np.array_equal(np.sort(ids), want)
     assert sim.gather_neighbours_at(np.zeros(3), 5.0, cap=16) is None
+    # the reference's headroom rule: a list that leaves fewer than Nleafmax (6) free slots is an overflow
+    n = len(sim.gather_neighbours_at(r[0], 0.3, cap=8192))
+    assert sim.gather_neighbours_at(r[0], 0.3, cap=n + 6) is None and len(sim.gather_neighbours_at(r[0], 0.3, cap=n + 7)) == n
+
+
+def test_point_gather_query_periodic_images():
+    """... in a periodic box the query also returns particles through their images (the reference's ghost tree)"""
+    g = load_golden("box3d_4k_passes")
+    sim, _ = make("box3d_4k")
+    sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+    sim.build_tree()
+    r = g["in_r"]
+    for rp in (np.array([0.01, 0.5, 0.99]), np.array([0.98, 0.02, 0.03]), np.array([0.5, 0.5, 0.5])):
+        ids = sim.gather_neighbours_at(rp, 0.12, cap=8192)
+        dx = r - rp
+        dx -= np.round(dx)
+        want = np.nonzero((dx**2).sum(axis=1) < 0.12**2)[0]
+        assert ids is not None and np.array_equal(np.sort(ids), want)
