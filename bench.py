@@ -85,6 +85,8 @@ def cpu_baseline(workload, sim=None):
         pf = os.path.join(tmp, "p.dat")
         open(pf, "w").write(src)
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+        if "ic = file" in src:
+            env["REF_H_PROVIDED"] = "1"       # the su reader reads h but does not say so (only the sf reader does, SimulationIO.hpp:794)
         t0 = time.time()
         out = subprocess.run([exe, "time", pf, str(steps), str(warm)], cwd=tmp, env=env, capture_output=True, text=True)
         wall = time.time() - t0

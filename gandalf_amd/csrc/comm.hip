@@ -33,6 +33,7 @@
 #define DD_G 2048            /* histogram bins per refinement of a median search */
 #define DD_CAPL 2048         /* candidates per rank and cell gathered in the final bin */
 #define DD_WCAP 512          /* speculative splits: candidates per rank and cell inside the window around last step's median */
+#define DD_WLDS 2048         /* ... candidates of one cell ranked out of LDS (more: out of the gathered blocks) */
 #define DD_WHDR 4            /* ... header slots of a rank's block (the rank's particle extent rides in them) */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
 #define DD_FMAX 6            /* halo selection: 2^F fine geometry entries per published bottom cell */
@@ -387,14 +388,29 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
     while (r + 1 < nranks && e >= s_off[r + 1]) r++;
     return all[(size_t) r*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP) + 1 + (e - s_off[r])];
   };
+  // rank of every candidate among all of them: the candidates (a few hundred as a rule) are first copied to LDS, where
+  // the ntot^2 comparisons are broadcast reads
+  __shared__ double s_key[DD_WLDS];
+  __shared__ int s_id[DD_WLDS];
+  const bool inlds = ntot <= DD_WLDS;
+  if (!s_bad && want >= 0 && want < ntot && inlds) {
+    for (int e = threadIdx.x; e < ntot; e += blockDim.x) { const DDCand me = entry(e); s_key[e] = me.key; s_id[e] = me.id; }
+  }
+  __syncthreads();
   if (!s_bad && want >= 0 && want < ntot) {
     for (int e = threadIdx.x; e < ntot; e += blockDim.x) {
-      const DDCand me = entry(e);
       long long rank = 0;
-      for (int r = 0; r < nranks; r++) {
-        const DDCand *p = all + (size_t) r*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP) + 1;
-        const int nr = s_off[r + 1] - s_off[r];
-        for (int t = 0; t < nr; t++) { const DDCand o = p[t]; if (o.key < me.key || (o.key == me.key && o.id < me.id)) rank++; }
+      if (inlds) {
+        const double mk = s_key[e]; const int mi = s_id[e];
+        for (int t = 0; t < ntot; t++) { const double ok = s_key[t]; if (ok < mk || (ok == mk && s_id[t] < mi)) rank++; }
+      }
+      else {
+        const DDCand me = entry(e);
+        for (int r = 0; r < nranks; r++) {
+          const DDCand *p = all + (size_t) r*stride + DD_WHDR + (size_t) c*(1 + DD_WCAP) + 1;
+          const int nr = s_off[r + 1] - s_off[r];
+          for (int t = 0; t < nr; t++) { const DDCand o = p[t]; if (o.key < me.key || (o.key == me.key && o.id < me.id)) rank++; }
+        }
       }
       if (rank == want) s_found = e;
     }

@@ -648,7 +648,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 #define GH_DENS_RCAP 512   /* candidate ranges per group held by the split path */
-#define GH_DENS_ICAP 1536   /* candidate slots of one quarter-group held in LDS as particle indices */
+#ifndef GH_DENS_WPE
+#define GH_DENS_WPE 4
+#endif
+#define GH_DENS_ICAP 1024   /* candidate slots of one quarter-group held in LDS as particle indices */
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // Evaluation: one wavefront per QUARTER-group (<= 64/S target particles: 16 for the usual 16-leaf group, S = 4), S
@@ -660,7 +663,7 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 // 2.4 x fewer cull tests, and the fp64 work of a target (whose neighbours come in runs of consecutive slots: leaves) is
 // dealt round-robin to its sub-lanes.  S = 2 / 1: groups of 2 / 1 leaves (Nleafmax 16 / 32).
 template <int ND, bool COUNT, int KT, int S>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE, 8))) void k_dens_eval(DevicePtrs d, DensityParams P, DensLists G,
                                                                                        unsigned long long *stats, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
@@ -668,10 +671,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   constexpr int PPT = 32/S;                                // candidate pairs per tile and lane
   constexpr int NB = S;                                    // tiles per batch: NB * 2 * PPT = 64 mask bits per lane
   __shared__ int s_idx[GH_DENS_ICAP];                      // particle index | image code << GH_NODE_BITS, -1 = padding
-  __shared__ double s_x[NB*64], s_y[NB*64], s_z[NB*64], s_m[NB*64];
-  // current tile in fp32, relative to the quarter's centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
-  // records: one 16-byte + one 8-byte LDS read feed two packed-fp32 distance evaluations)
-  __shared__ __attribute__((aligned(16))) float s_f[32][8];
+  // a tile in fp32, relative to the quarter's centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
+  // records: one 16-byte + one 8-byte LDS read feed two packed-fp32 distance evaluations); two buffers - tile t + 1 is
+  // staged while tile t is culled.  The fp64 records of the survivors are read again from the (x, y, z, m) pack - L2
+  // hits, the tile's lanes have just loaded them - rather than staged in LDS: 5 KB of LDS per wave instead of 15.
+  __shared__ __attribute__((aligned(16))) float s_f[2][32][8];
 
   const int lane = threadIdx.x;
   const int tl = lane & (TC - 1), sl = lane/TC;            // target slot, sub-lane
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     double prho = 0.0, pomg = 0.0, pzet = 0.0;            // this lane's share of the three sums
     // fp32 cull threshold: a superset of {invhsqd*r2 < kernrangesqd} (see k_density)
     const float thr = running ? (float) ((K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(K::kernrange*h*(1.0 + 1e-6) + 2e-6*Rmax)*(1.0 + 1e-6)) : -1.0f;
-    int nb = 0;
+    int nb = 0, tbase = 0;                                 // tiles in the current batch, first tile of the batch
     unsigned long long mk = 0ull;                          // bit (tile of the batch)*2*PPT + 2*(own pair) + (member of the pair)
     auto process_batch = [&]() {
       while (__any(mk != 0ull)) {
@@ -787,12 +791,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
           const int p = __ffsll((long long) mk) - 1;
           mk &= mk - 1ull;
           const int b = p/(2*PPT), u = p - b*(2*PPT);
-          const int c = b*64 + 2*(sl + (u >> 1)*S) + (u & 1);
+          const int id = s_idx[(tbase + b)*64 + 2*(sl + (u >> 1)*S) + (u & 1)];
+          double4 v = d.posm[id & GH_NODE_MASK];
+          if (images) {
+            double sg[3], sh[3];
+            code_xform(P.dom, id >> GH_NODE_BITS, sg, sh);
+            v.x = sg[0]*v.x + sh[0]; v.y = sg[1]*v.y + sh[1]; v.z = sg[2]*v.z + sh[2];
+          }
           double dr[3] = {0.0, 0.0, 0.0};
-          dr[0] = s_x[c] - ri[0];
-          if (ND > 1) dr[1] = s_y[c] - ri[1];
-          if (ND > 2) dr[2] = s_z[c] - ri[2];
-          const double mj = s_m[c];
+          dr[0] = v.x - ri[0];
+          if (ND > 1) dr[1] = v.y - ri[1];
+          if (ND > 2) dr[2] = v.z - ri[2];
+          const double mj = v.w;
           double r2 = dr[0]*dr[0];
           if (ND > 1) r2 += dr[1]*dr[1];
           if (ND > 2) r2 += dr[2]*dr[2];
@@ -807,7 +817,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
           }
         }
       }
-      __syncthreads();
       nb = 0;
     };
     // software pipeline over the tiles: record of tile t+1 loaded while tile t is staged and culled
@@ -821,43 +830,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         }
       }
       const int ntiles = (ntot + 63) >> 6;
-      int idn = s_idx[lane];
-      double4 vn = d.posm[idn < 0 ? 0 : (idn & GH_NODE_MASK)];
-      for (int t = 0; t < ntiles; t++) {
-        const int id = idn;
-        double4 v = vn;
-        if (t + 1 < ntiles) {
-          idn = s_idx[(t + 1)*64 + lane];
-          vn = d.posm[idn < 0 ? 0 : (idn & GH_NODE_MASK)];
-        }
-        const int o = nb*64;
-        {
-          double x = 1e30, y = 1e30, z = 1e30, m = 0.0;
-          if (id >= 0) {
-            x = v.x; y = v.y; z = v.z; m = v.w;
-            if (images) {
-              double sg[3], sh[3];
-              code_xform(P.dom, id >> GH_NODE_BITS, sg, sh);
-              x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2];
-            }
+      // stage(t): tile t's candidates, one per lane, as fp32 offsets from the quarter's centre
+      auto stage = [&](int t) {
+        const int id = s_idx[t*64 + lane];
+        double x = 1e30, y = 1e30, z = 1e30;
+        if (id >= 0) {
+          const double4 v = d.posm[id & GH_NODE_MASK];
+          x = v.x; y = v.y; z = v.z;
+          if (images) {
+            double sg[3], sh[3];
+            code_xform(P.dom, id >> GH_NODE_BITS, sg, sh);
+            x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2];
           }
-          s_x[o + lane] = x; s_y[o + lane] = y; s_z[o + lane] = z; s_m[o + lane] = m;
-          s_f[lane >> 1][lane & 1] = (float) (x - gc[0]);
-          s_f[lane >> 1][2 + (lane & 1)] = ND > 1 ? (float) (y - gc[1]) : 0.f;
-          s_f[lane >> 1][4 + (lane & 1)] = ND > 2 ? (float) (z - gc[2]) : 0.f;
         }
-        __syncthreads();
+        float (*f)[8] = s_f[t & 1];
+        f[lane >> 1][lane & 1] = (float) (x - gc[0]);
+        f[lane >> 1][2 + (lane & 1)] = ND > 1 ? (float) (y - gc[1]) : 0.f;
+        f[lane >> 1][4 + (lane & 1)] = ND > 2 ? (float) (z - gc[2]) : 0.f;
+      };
+      stage(0);
+      __syncthreads();
+      tbase = 0;
+      for (int t = 0; t < ntiles; t++) {
+        if (t + 1 < ntiles) stage(t + 1);                  // into the other buffer
         // support mask in packed fp32: dd = |r_c - r_i|^2 - thr from three packed FMAs per candidate pair; its sign bit
         // (set = inside the conservative threshold) is shifted into the mask by one v_alignbit_b32 per candidate: own pair k
         // (candidates 2*(sl + k*S), + 1) lands in bits 31 - 2k, 30 - 2k of the word, which is bit-reversed at the end.
         unsigned int mw = 0;
         {
+          const float (*f)[8] = s_f[t & 1];
           const float2_t tx = {tf[0], tf[0]}, ty = {tf[1], tf[1]}, tz = {tf[2], tf[2]}, nthr = {-thr, -thr};
 #pragma unroll
           for (int k = 0; k < PPT; k++) {
             const int c2 = sl + k*S;
-            const float4_t xy = *((const float4_t*) &s_f[c2][0]);
-            const float2_t zz = *((const float2_t*) &s_f[c2][4]);
+            const float4_t xy = *((const float4_t*) &f[c2][0]);
+            const float2_t zz = *((const float2_t*) &f[c2][4]);
             const float2_t dx = (float2_t) {xy.x, xy.y} - tx;
             float2_t dd = __builtin_elementwise_fma(dx, dx, nthr);
             if (ND > 1) { const float2_t dy = (float2_t) {xy.z, xy.w} - ty; dd = __builtin_elementwise_fma(dy, dy, dd); }
@@ -873,20 +880,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         if (COUNT) {
           if (running) {
             for (int k = 0; k < 2*PPT; k++) {
-              const int c = o + 2*(sl + (k >> 1)*S) + (k & 1);
-              double r2 = 0.0;
-              { const double dx = s_x[c] - ri[0]; r2 = dx*dx; }
-              if (ND > 1) { const double dy = s_y[c] - ri[1]; r2 += dy*dy; }
-              if (ND > 2) { const double dz = s_z[c] - ri[2]; r2 += dz*dz; }
-              if (r2 + GH_SMALL <= cullsqd) n_cand++;
+              const int id = s_idx[t*64 + 2*(sl + (k >> 1)*S) + (k & 1)];
+              if (id >= 0) {
+                double4 v = d.posm[id & GH_NODE_MASK];
+                if (images) {
+                  double sg[3], sh[3];
+                  code_xform(P.dom, id >> GH_NODE_BITS, sg, sh);
+                  v.x = sg[0]*v.x + sh[0]; v.y = sg[1]*v.y + sh[1]; v.z = sg[2]*v.z + sh[2];
+                }
+                double r2 = 0.0;
+                { const double dx = v.x - ri[0]; r2 = dx*dx; }
+                if (ND > 1) { const double dy = v.y - ri[1]; r2 += dy*dy; }
+                if (ND > 2) { const double dz = v.z - ri[2]; r2 += dz*dz; }
+                if (r2 + GH_SMALL <= cullsqd) n_cand++;
+              }
             }
             n_tested += 2*PPT;
           }
         }
         nb++;
-        if (nb == NB) process_batch();
-        else __syncthreads();
+        if (nb == NB) { process_batch(); tbase = t + 1; }
+        __syncthreads();                                   // tile t + 1 is staged, tile t's buffer is free again
       }
+      if (nb > 0) process_batch();                         // before the next fill replaces the index list
       if (whole) break;
     }
     process_batch();
