@@ -72,6 +72,16 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
     GH_CHECK(ctx, hipMemcpy(tie, ctx->d_blk + 13, sizeof(tie), hipMemcpyDeviceToHost));
     if (tie[0] | tie[1]) ctx->exact_armed = true;
   }
+  if (ctx->nranks > 1 && ctx->tree_valid) {
+    // equal coordinates at a median split (lattice initial conditions): on one rank the tree is then rebuilt with the
+    // reference's own quick-select order; across ranks the shared levels order ties by particle id, which is not the
+    // reference's tree.  Every rank has the flag of every other (it travels with the subtree tops): all stop here.
+    int tie[2] = {0, 0};
+    GH_CHECK(ctx, hipMemcpy(tie, ctx->d_blk + 13, sizeof(tie), hipMemcpyDeviceToHost));
+    if (tie[0] | tie[1])
+      return gh_fail(ctx, GH_ERR_UNSUPPORTED, std::string(where) + ": multi-GPU: a median split separates particles with equal coordinates (lattice "
+                     "initial conditions?) - the reference's quick-select tie order is reproduced on one rank only");
+  }
   if (flags) {
     GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
     std::string m = std::string(where) + ":";
@@ -159,6 +169,15 @@ extern "C" int gh_create(const gh_config *cfg, gh_ctx **out)
   if (cfg->sink_particles && (cfg->ntreebuildstep > 1 || !cfg->self_gravity || cfg->ndim != 3 || (cfg->Nlevels > 1 && cfg->sph_single_timestep)))
     return gh_fail(ctx, GH_ERR_UNSUPPORTED, "sink runs: 3-D, self_gravity = 1, tree rebuilt every step (ntreebuildstep = 1), no sph_single_timestep");
   if (cfg->sink_particles && !(cfg->rho_sink > 0.0)) return gh_fail(ctx, GH_ERR_INVALID, "sink_particles = 1 needs rho_sink > 0");
+  // extrapolated trees (ntreestockstep > 1) are searched the reference's way - per leaf cell against the drifted boxes,
+  // losing the neighbours the reference loses (walk_dfs_stream_masked) - for open boundaries and the density / force
+  // walks only; what is not restated is refused here rather than computed differently from the reference
+  if (cfg->ntreestockstep > 1) {
+    bool images = false;
+    for (int k = 0; k < cfg->ndim; k++) images = images || cfg->boundary_lhs[k] != GH_BOUNDARY_OPEN || cfg->boundary_rhs[k] != GH_BOUNDARY_OPEN;
+    if (images) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "ntreestockstep > 1 (extrapolated trees): open boundaries only - the reference's search of a drifted tree through periodic / mirror images is not restated");
+    if (cfg->avisc == GH_AVISC_MON97CD2010) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "ntreestockstep > 1 (extrapolated trees): not with time_dependent_avisc = cd2010 - its gather pass is not restated for a drifted tree");
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return gh_fail(ctx, GH_ERR_HIP, "no HIP device: libgandalf_hip has no CPU path");

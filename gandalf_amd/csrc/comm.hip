@@ -214,7 +214,7 @@ __global__ void k_dd_collect(DevicePtrs d, const int *topcell, const DDCell *cel
 // children's inherited boxes follow (KDTree.cpp:508-527)
 __global__ __launch_bounds__(1024) void k_dd_select(DDCell *cells, const DDCand *cand_all, int ncells, int nranks,
                                                     double *dbbmin, double *dbbmax, int *kdiv, int *flags,
-                                                    double *spl_prev, double *spl_win, int *spl_kd)
+                                                    double *spl_prev, double *spl_win, int *spl_kd, int *tie)
 {
   const int c = blockIdx.x;
   __shared__ int s_off[GH_MAX_RANKS + 1];
@@ -248,7 +248,12 @@ __global__ __launch_bounds__(1024) void k_dd_select(DDCell *cells, const DDCand 
   if (threadIdx.x == 0) {
     DDCell w = q;
     const int n = q.node, c1 = 2*n + 1, c2 = 2*n + 2, kd = q.kd;
-    if (s_found >= 0) { const DDCand m = entry(s_found); w.rdiv = m.key; w.rdiv_id = m.id; }
+    if (s_found >= 0) {
+      const DDCand m = entry(s_found); w.rdiv = m.key; w.rdiv_id = m.id;
+      // equal coordinates on both sides of the split: which of them go left is decided here by particle id, in the
+      // reference by the dynamics of its quick-select (KDTree.cpp:682-750) - reported, see gh_sync_collect
+      for (int e = 0; e < ntot; e++) { const DDCand o = entry(e); if (o.key == m.key && o.id < m.id) { atomicOr(tie, 1); break; } }
+    }
     else if (ntot > 0 || q.target > 0) atomicOr(flags, FLAG_DD_SPLIT);       // the bracket lost the median: never expected
     // what next step's speculative split starts from: the median, the axis, and a window that holds ~256 candidates at
     // the density of the final bin (ntot candidates in a bin of width 1/scB)
@@ -339,7 +344,7 @@ __global__ void k_dd_win_box(const double *dbbmin, const double *dbbmax, DDCand 
 
 // one workgroup per cell of the level: exact median among the gathered window candidates
 __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand *all, size_t stride /* DDCand per rank */, int level, int nranks, int ndim,
-                                                     double *dbbmin, double *dbbmax, int *kdiv, double *spl_prev, double *spl_win, int *spl_kd, int *fail)
+                                                     double *dbbmin, double *dbbmax, int *kdiv, double *spl_prev, double *spl_win, int *spl_kd, int *fail, int *tie)
 {
   const int c = blockIdx.x;
   __shared__ int s_off[GH_MAX_RANKS + 1];
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
     if (s_found >= 0) {
       const DDCand m = entry(s_found);
       w.rdiv = m.key; w.rdiv_id = m.id;
+      for (int e = 0; e < ntot; e++) { const DDCand o = entry(e); if (o.key == m.key && o.id < m.id) { atomicOr(tie, 1); break; } }     // see k_dd_select
       const double wold = spl_win[n], shift = fabs(m.key - spl_prev[n]);
       double wnew = fmax(4.0*shift, 256.0*wold/(double) ntot);
       wnew = fmin(wnew, 0.25*(dbbmax[n*3 + kd] - dbbmin[n*3 + kd]));
@@ -563,7 +569,9 @@ __global__ __launch_bounds__(256) void k_pub_fine(DevicePtrs d, int L, int PF, i
   }
 }
 
-__global__ void k_pub_pack(DevicePtrs d, int L, int P, int rank, PubRec *out)
+// (the spare word of the first record carries this rank's "a median split separated equal coordinates" flag, so that
+// every rank learns of a tie anywhere and all of them stop together in gh_sync_collect)
+__global__ void k_pub_pack(DevicePtrs d, int L, int P, int rank, PubRec *out, const int *tie)
 {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   const int ncell = (2 << P) - 1;
@@ -575,10 +583,11 @@ __global__ void k_pub_pack(DevicePtrs d, int L, int P, int rank, PubRec *out)
   PubRec r;
   r.b = d.cbox[n]; r.h = d.ch[n]; r.g = d.cgeo[n]; r.c = d.ccom[n];
   if (d.cquad) r.q = d.cquad[n]; else { for (int k = 0; k < 5; k++) r.q.q[k] = 0.0; for (int k = 0; k < 3; k++) r.q.pad[k] = 0.0; }
+  if (e == 0) r.q.pad[0] = (tie[0] | tie[1]) ? 1.0 : 0.0;
   out[e] = r;
 }
 
-__global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, const char *all, size_t stride)
+__global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, const char *all, size_t stride, int *tie)
 {
   const int ncell = (2 << P) - 1;
   const int t = blockIdx.x*blockDim.x + threadIdx.x;
@@ -591,7 +600,8 @@ __global__ void k_pub_unpack(DevicePtrs d, int L, int P, int self, int nranks, c
   const int n = (1 << (L + p)) - 1 + (r << p) + j;
   const PubRec &q = ((const PubRec*) (all + (size_t) r*stride))[e];
   d.cbox[n] = q.b; d.ch[n] = q.h; d.cgeo[n] = q.g; d.ccom[n] = q.c;
-  if (d.cquad) d.cquad[n] = q.q;
+  if (e == 0 && q.q.pad[0] != 0.0) atomicOr(&tie[1], 1);
+  if (d.cquad) { CellQuad cq = q.q; cq.pad[0] = 0.0; d.cquad[n] = cq; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1042,7 +1052,7 @@ static int dd_levels_exact(gh_ctx *ctx)
     hipLaunchKernelGGL(k_dd_collect, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells, D->cand, ctx->d_flags);
     DD_OP(ctx, dd_allgather(ctx, D->cand, D->cand_all, sizeof(DDCand)*(size_t) nc*(1 + DD_CAPL)));
     hipLaunchKernelGGL(k_dd_select, dim3(nc), dim3(1024), 0, s, D->cells, D->cand_all, nc, W, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, ctx->d_flags,
-                       D->spl_prev, D->spl_win, D->spl_kd);
+                       D->spl_prev, D->spl_win, D->spl_kd, ctx->d_blk + 13);
     hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells);
   }
   return GH_OK;
@@ -1069,7 +1079,7 @@ static int dd_levels_speculative(gh_ctx *ctx)
     hipLaunchKernelGGL(k_dd_window, dim3(nb), dim3(256), 0, s, own, D->topcell, D->wins, nc, D->wnd, D->spl_fail);
     DD_OP(ctx, dd_allgather(ctx, D->wnd, D->wnd_all, sizeof(DDCand)*stride));
     hipLaunchKernelGGL(k_dd_wselect, dim3(nc), dim3(1024), 0, s, D->cells, D->wnd_all, stride, l, W, ctx->ndim, ctx->dbbmin, ctx->dbbmax, ctx->kdiv,
-                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail);
+                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail, ctx->d_blk + 13);
     hipLaunchKernelGGL(k_dd_assign, dim3(nb), dim3(256), 0, s, own, D->topcell, D->cells);
   }
   return GH_OK;
@@ -1163,11 +1173,11 @@ int gh_dd_publish(gh_ctx *ctx, int hmax_only)
   // subtree tops and fine geometry tables travel in ONE all-gather: per rank [PubRec x ncell | LetGeom x 2^(P+F)]
   const int PF = P + D->F;
   const size_t fine_bytes = sizeof(LetGeomF)*((size_t) 1 << PF), blk = D->pub_bytes + fine_bytes;
-  hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->comb_send);
+  hipLaunchKernelGGL(k_pub_pack, dim3(cdiv(ncell, 64)), dim3(64), 0, ctx->stream, d, L, P, ctx->rank, (PubRec*) D->comb_send, ctx->d_blk + 13);
   hipLaunchKernelGGL(k_pub_fine, dim3(1 << PF), dim3(256), 0, ctx->stream, d, L, PF, ctx->rank, kr, 1.0, (LetGeomF*) (D->comb_send + D->pub_bytes));
   DD_OP(ctx, dd_allgather(ctx, D->comb_send, D->comb_recv, blk));
   D->fine_widen = 1.0; D->fine_base = D->comb_recv + D->pub_bytes; D->fine_stride = blk;
-  hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, D->comb_recv, blk);
+  hipLaunchKernelGGL(k_pub_unpack, dim3(cdiv(ncell*W, 256)), dim3(256), 0, ctx->stream, d, L, P, ctx->rank, W, D->comb_recv, blk, ctx->d_blk + 13);
   gh_stock_top_levels(ctx, L - 1, hmax_only);
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;

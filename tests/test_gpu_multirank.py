@@ -144,6 +144,25 @@ def test_ranks_hold_only_their_share(tmp_path):
             assert _relerr(a, b) <= 1e-13, k
 
 
+def test_lattice_ties_are_refused_on_more_than_one_rank(tmp_path):
+    """16^3 cubic lattice (equal coordinates at every median): one rank rebuilds the tree with the reference's own
+    quick-select tie order (lattice3d_cubic_grav fixture); across ranks the shared top levels order ties by particle id,
+    which would be a different tree than the reference's - every rank learns of the tie (the flag travels with the subtree
+    tops) and all of them stop with the same error instead of computing on."""
+    wf = tmp_path/"worker.py"
+    wf.write_text(WORKER)
+    port = _port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(wf), ROOT, "lattice3d_cubic_grav", str(tmp_path/"l.npz"), "1", "{}"], env=env,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode != 0
+        assert "equal coordinates" in err, err[-1500:]
+
+
 NCCL_WORKER = r'''
 import ctypes as C, os, sys
 import numpy as np

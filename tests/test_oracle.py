@@ -3,10 +3,12 @@
 tests/golden/*.npz were written by scripts/make_golden.py from the compiled reference (oracle/ref.mk +
 oracle/ref_dump.cpp); the restatement must reproduce them BIT FOR BIT: tree (cells, linked lists),
 densities, neighbour lists, forces, and three full steps."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import PARAMS, load_golden
+from conftest import PARAMS, ROOT, load_golden
 from gandalf_amd.params import read_params_file
 from oracle.pyoracle import Oracle
 
@@ -340,3 +342,22 @@ def test_hybrid_setup_bitwise():
         assert np.array_equal(o.get(k), s(k)), k
     for k in ["a", "adot", "gpot", "a0"]:
         assert np.array_equal(nb.get(k), s("star_" + k)), "star " + k
+
+
+def test_reference_octtree_cannot_run(tmp_path):
+    """SURVEY 8(f) rank 4 names the oct-tree option.  The reference's own build of it (OctTree.cpp:210-440) computes the
+    particles' extent into locals (:253-263) but never stores it in the root cell, whose unset box it then halves (:285-288):
+    with sim = gradhsph it stops with "reached maximum oct-tree level" (:425-428) on the Plummer sphere and on the periodic
+    box alike.  There is nothing to pin an oct-tree against; the host shell refuses the option with that explanation.
+    (Runs the compiled reference: build container only.)"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_dump not built")
+    for case in ("plummer_4k", "box3d_4k"):
+        src = open(os.path.join(PARAMS, case + ".dat")).read().replace("neib_search = kdtree", "neib_search = octtree")
+        pf = tmp_path/(case + "_oct.dat")
+        pf.write_text(src)
+        out = subprocess.run([exe, "time", str(pf), "1", "0"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert "reached maximum oct-tree level" in out.stdout + out.stderr
+        assert "particle_steps_per_s" not in out.stdout
