@@ -70,6 +70,7 @@ SYMBOLS = {
     "gh_download": (C.c_int, [_CTX, C.c_int, _PD]),
     "gh_num_particles": (C.c_int64, [_CTX]),
     "gh_build_tree": (C.c_int, [_CTX]),
+    "gh_build_tree_scheduled": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "gh_tree_size": (C.c_int, [_CTX, _PI, _PI, _PI]),
     "gh_export_tree": (C.c_int, [_CTX, _PI, _PI, _PI, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PI]),
     "gh_update_density": (C.c_int, [_CTX, C.POINTER(Stats)]),

@@ -325,7 +325,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   std::vector<int> ids(n);
   for (size_t i = 0; i < n; i++) ids[i] = (int) i;
   GH_CHECK(ctx, hipMemcpy(ctx->iorig[0], ids.data(), sizeof(int)*n, hipMemcpyHostToDevice));
-  ctx->tree_valid = false;
+  ctx->tree_valid = false; ctx->tree_valid_once = false;
   ctx->n = 0; ctx->Nsteps = 0; ctx->t = 0.0; ctx->timestep = 0.0;
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
   ctx->rebuild_tree = true;
@@ -389,6 +389,27 @@ extern "C" int gh_build_tree(gh_ctx *ctx)
   int rc = gh_tree_build_checked(ctx);
   if (rc) return rc;
   return gh_sync_collect(ctx, "gh_build_tree");
+}
+
+int gh_tree_restock_impl(gh_ctx *ctx);
+// HydroTree::BuildTree with its own arguments (HydroTree.cpp:310-372): rebuild when n % ntreebuildstep == 0 or rebuild_tree,
+// re-stock when n % ntreestockstep == 0, otherwise let the cells drift by their mean velocity times `timestep`
+extern "C" int gh_build_tree_scheduled(gh_ctx *ctx, int rebuild_tree, int n, int ntreebuildstep, int ntreestockstep, double timestep)
+{
+  if (!ctx || ctx->N <= 0 || ntreebuildstep < 1 || ntreestockstep < 1) return GH_ERR_INVALID;
+  if (ctx->nranks > 1 && (ntreebuildstep > 1)) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: the tree is rebuilt every step (ntreebuildstep = 1)");
+  int rc;
+  if (n%ntreebuildstep == 0 || rebuild_tree || !ctx->tree_valid_once || ctx->tree_layout_N != ctx->N) rc = gh_tree_build_checked(ctx);
+  else if (n%ntreestockstep == 0) rc = gh_tree_restock_impl(ctx);
+  else {
+    ctx->timestep = timestep;
+    double tt[2] = {ctx->t, timestep};
+    GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
+    rc = gh_tree_extrapolate_impl(ctx);
+  }
+  if (rc) return rc;
+  ctx->tree_valid_once = true;
+  return gh_sync_collect(ctx, "gh_build_tree_scheduled");
 }
 
 extern "C" int gh_tree_size(gh_ctx *ctx, int32_t *Ncell, int32_t *ltot, int32_t *gtot)

@@ -164,6 +164,12 @@ int64_t gh_num_particles(const gh_ctx *ctx);
  * (HydroTree.cpp:310-372, KDTree.cpp:220-313, 442-595, 808-1083).  Reorders the device copy of the
  * particles into tree order. */
 int gh_build_tree(gh_ctx *ctx);
+/* replaces: HydroTree::BuildTree with its own arguments (HydroTree.cpp:310-372) for callers that keep the reference's MainLoop
+ * (include/reference_shell/HipSphTree.h): rebuild when n % ntreebuildstep == 0 or rebuild_tree (KDTree::BuildTree), re-stock the
+ * existing cells when n % ntreestockstep == 0 (KDTree::StockTree, :760-1083), otherwise let the cells drift with their stocked
+ * mean velocities over `timestep` (Tree::ExtrapolateCellProperties, Tree.cpp:172-198).  Positions / h uploaded since the last
+ * call are what is stocked.  (gh_step applies the same schedule itself from gh_config.) */
+int gh_build_tree_scheduled(gh_ctx *ctx, int rebuild_tree, int n, int ntreebuildstep, int ntreestockstep, double timestep);
 /* tree export for parity tests, in the reference's pre-order cell numbering (KDTree.cpp:362-433).
  * Any pointer may be NULL.  Ncell = 2*gtot-1.  cell_first/cell_N index the `order` array:
  * order[cell_first[c] .. +cell_N[c]) are the caller-order ids of the particles of cell c. */

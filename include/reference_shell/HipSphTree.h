@@ -37,6 +37,8 @@ class HipSphTree : public SphNeighbourSearch<ndim>
   Sph<ndim> *sph0;
   MAC_Type mac;
   bool uploaded;
+  int Nlevels;                                      // > 1: block timesteps - the integrator's level / active state goes down, levelneib comes back
+  int avisc;                                        // GH_AVISC_*: time-dependent viscosity needs alpha on the device
   std::vector<double> r, v, m, h, u, buf;           // SoA staging in the caller's (iorig) order
 
   void raise() { ExceptionHandler::getIstance().raise(std::string(gh_last_error(ctx))); }   // Exception.cpp:50-70
@@ -63,6 +65,37 @@ class HipSphTree : public SphNeighbourSearch<ndim>
       check(gh_upload_field(ctx, GH_F_R, &r[0])); check(gh_upload_field(ctx, GH_F_V, &v[0]));
       check(gh_upload_field(ctx, GH_F_H, &h[0])); check(gh_upload_field(ctx, GH_F_U, &u[0]));
     }
+    UploadLevels(hydro);
+  }
+  // what the block-timestep integrator decides on the host (SphLeapfrogKDK::AdvanceParticles / CheckTimesteps,
+  // Simulation::ComputeBlockTimesteps): active flag, level, levelneib - the device masks its passes with them
+  void UploadLevels(Hydrodynamics<ndim> *hydro) {
+    if (Nlevels <= 1) return;
+    GradhSphParticle<ndim> *p = parts(hydro);
+    const int N = hydro->Nhydro;
+    buf.resize(N);
+    for (int i=0; i<N; i++) buf[i] = (double) ((p[i].flags.check(active) ? 1 : 0) | (p[i].flags.check(end_timestep) ? 2 : 0));
+    check(gh_upload_field(ctx, GH_F_FLAGS, &buf[0]));
+    for (int i=0; i<N; i++) buf[i] = (double) p[i].level;
+    check(gh_upload_field(ctx, GH_F_LEVEL, &buf[0]));
+    for (int i=0; i<N; i++) buf[i] = (double) p[i].levelneib;
+    check(gh_upload_field(ctx, GH_F_LEVELNEIB, &buf[0]));
+  }
+  // what MainLoop refreshes on the host for ALL particles between the density and the force pass (pressure and sound
+  // speed of the drifted inactive neighbours, SphSimulation.cpp:665-679), and alpha of the time-dependent viscosities
+  void UploadThermal(Hydrodynamics<ndim> *hydro) {
+    if (Nlevels <= 1 && avisc == GH_AVISC_MON97) return;
+    GradhSphParticle<ndim> *p = parts(hydro);
+    const int N = hydro->Nhydro;
+    buf.resize(N);
+    if (Nlevels > 1) {
+      for (int i=0; i<N; i++) buf[i] = p[i].u;         check(gh_upload_field(ctx, GH_F_U, &buf[0]));
+      for (int i=0; i<N; i++) buf[i] = p[i].sound;     check(gh_upload_field(ctx, GH_F_SOUND, &buf[0]));
+      for (int i=0; i<N; i++) buf[i] = p[i].pressure;  check(gh_upload_field(ctx, GH_F_PRESSURE, &buf[0]));
+    }
+    if (avisc != GH_AVISC_MON97 && avisc != GH_AVISC_NONE) {
+      for (int i=0; i<N; i++) buf[i] = p[i].alpha;     check(gh_upload_field(ctx, GH_F_ALPHA, &buf[0]));
+    }
   }
   // one scalar / vector field back into the AoS array
   void DownloadScalar(Hydrodynamics<ndim> *hydro, int field, FLOAT GradhSphParticle<ndim>::*member) {
@@ -82,7 +115,7 @@ class HipSphTree : public SphNeighbourSearch<ndim>
 
  public:
 
-  HipSphTree(Parameters *params, DomainBox<ndim> *box, Sph<ndim> *sph) : ctx(0), sph0(sph), mac(geometric), uploaded(false)
+  HipSphTree(Parameters *params, DomainBox<ndim> *box, Sph<ndim> *sph) : ctx(0), sph0(sph), mac(geometric), uploaded(false), Nlevels(1), avisc(0)
   {
     std::map<std::string, int> &ip = params->intparams;
     std::map<std::string, double> &fp = params->floatparams;
@@ -126,16 +159,16 @@ class HipSphTree : public SphNeighbourSearch<ndim>
       ExceptionHandler::getIstance().raise(msg);
     }
     mac = c.gravity_mac == GH_MAC_GADGET2 ? gadget2 : (c.gravity_mac == GH_MAC_EIGENMAC ? eigenmac : geometric);
+    Nlevels = c.Nlevels; avisc = c.avisc;
   }
   virtual ~HipSphTree() { gh_destroy(ctx); }
 
   // ---- NeighbourSearch<ndim> --------------------------------------------------------------------------------------
-  // HydroTree::BuildTree (HydroTree.cpp:310-372).  The rebuild / re-stock / extrapolate schedule (n, ntreebuildstep,
-  // ntreestockstep) is the one gh_config carries; with the AoS array authoritative the particles were just uploaded in
-  // a new order of motion, so this shell always asks for the full build - gh_step applies the schedule itself.
+  // HydroTree::BuildTree (HydroTree.cpp:310-372): the particles the integrator has just moved go down, then the
+  // reference's own schedule - rebuild / re-stock / extrapolate - with the reference's own arguments
   virtual void BuildTree(const bool rebuild_tree, const int n, const int ntreebuildstep, const int ntreestockstep,
                          const FLOAT timestep, Hydrodynamics<ndim> *hydro)
-  { (void) rebuild_tree; (void) n; (void) ntreebuildstep; (void) ntreestockstep; (void) timestep; Upload(hydro); check(gh_build_tree(ctx)); }
+  { Upload(hydro); check(gh_build_tree_scheduled(ctx, rebuild_tree ? 1 : 0, n, ntreebuildstep, ntreestockstep, timestep)); }
   // periodic / mirror images are made on the fly inside gh_update_density / gh_update_*_forces: no ghost particles, no ghost tree
   virtual void BuildGhostTree(const bool, const int, const int, const int, const FLOAT, Hydrodynamics<ndim> *) {}
   virtual void SearchBoundaryGhostParticles(FLOAT, const DomainBox<ndim> &, Hydrodynamics<ndim> *) {}
@@ -150,7 +183,9 @@ class HipSphTree : public SphNeighbourSearch<ndim>
     for (int j=0; j<n; j++) neiblist[j] = ids[j];
     return n;
   }
-  virtual void UpdateActiveParticleCounters(Hydrodynamics<ndim> *) {}    // the device keeps its own active flags (gh_step, Nlevels > 1)
+  // KDTree::UpdateActiveParticleCounters (KDTree.cpp:1217): MainLoop calls it when CheckTimesteps has woken particles for
+  // another pass (SphSimulation.cpp:663) - the new active flags go down
+  virtual void UpdateActiveParticleCounters(Hydrodynamics<ndim> *hydro) { UploadLevels(hydro); }
   virtual void UpdateAllStarGasForces(Hydrodynamics<ndim> *, Nbody<ndim> *nbody, DomainBox<ndim> &, Ewald<ndim> *)
   {
     // HydroTree::UpdateAllStarGasForces (HydroTree.cpp:552-657): gh_set_stars with the stars' r, m, h, then gh_star_gas_forces
@@ -213,10 +248,16 @@ class HipSphTree : public SphNeighbourSearch<ndim>
     DownloadScalar(sph, GH_F_DUDT, &GradhSphParticle<ndim>::dudt);        DownloadScalar(sph, GH_F_DIV_V, &GradhSphParticle<ndim>::div_v);
     DownloadScalar(sph, GH_F_GPOT, &GradhSphParticle<ndim>::gpot);        DownloadScalar(sph, GH_F_GPOT_HYDRO, &GradhSphParticle<ndim>::gpot_hydro);
     DownloadScalar(sph, GH_F_DALPHADT, &GradhSphParticle<ndim>::dalphadt);
+    if (Nlevels > 1) {                                                    // levelneib: raised by active neighbours (GradhSph.cpp:455, 569)
+      GradhSphParticle<ndim> *p = parts(sph);
+      buf.resize(sph->Nhydro);
+      check(gh_download(ctx, GH_F_LEVELNEIB, &buf[0]));
+      for (int i = 0; i < sph->Nhydro; i++) p[i].levelneib = (int) buf[i];
+    }
   }
   virtual void UpdateAllSphHydroForces(Sph<ndim> *sph, Nbody<ndim> *, DomainBox<ndim> &)              // GradhSphTree.cpp:280-435
-  { check(gh_zero_accelerations(ctx)); check(gh_update_hydro_forces(ctx, 0)); DownloadForces(sph); }
+  { UploadThermal(sph); check(gh_zero_accelerations(ctx)); check(gh_update_hydro_forces(ctx, 0)); DownloadForces(sph); }
   virtual void UpdateAllSphForces(Sph<ndim> *sph, Nbody<ndim> *, DomainBox<ndim> &, Ewald<ndim> *)    // GradhSphTree.cpp:444-657
-  { check(gh_zero_accelerations(ctx)); check(gh_update_all_forces(ctx, 0)); DownloadForces(sph); }
+  { UploadThermal(sph); check(gh_zero_accelerations(ctx)); check(gh_update_all_forces(ctx, 0)); DownloadForces(sph); }
 };
 #endif

@@ -70,3 +70,26 @@ def test_reference_mainloop_on_hip_tree(case, tmp_path):
             got = set(ids[off[i]:off[i + 1]].tolist())
             edge = {j for j in want ^ got if abs(d2[j] - (2.0*h[i])**2) > 1e-9*d2[j]}
             assert not edge, (i, sorted(edge))
+
+
+@pytest.mark.parametrize("case", ["plummer_4k_levels", "box3d_4k_levels", "adsod_1d_ts3_levels", "plummer_4k_tb4"])
+def test_reference_mainloop_on_hip_tree_levels_and_schedules(case, tmp_path):
+    """Block timesteps (Nlevels = 5) and the tree schedule through the seam: the reference's integrator decides levels and
+    active flags on the host (they go down before every pass: HipSphTree::UploadLevels / UpdateActiveParticleCounters),
+    the device raises levelneib (comes back after the force pass), HydroTree::BuildTree's rebuild / re-stock / extrapolate
+    schedule reaches the device with its own arguments (gh_build_tree_scheduled; adsod_1d_ts3_levels: ntreebuildstep = 8,
+    ntreestockstep = 3; plummer_4k_tb4: ntreebuildstep = 4).  40 (10) MainLoop steps against the reference's own run."""
+    g = load_golden(case + "_steps")
+    nsteps = int(g["nsteps"][0])
+    setup, final = run_shell(tmp_path, case, nsteps)
+    if "final_level" in g:
+        for k in ("level", "nstep", "nlast"):
+            assert np.array_equal(final[k], g["final_" + k]), k
+        assert np.array_equal(final["n_Nsteps_nresync"], g["final_n_Nsteps_nresync"])
+    tf, dtf = g["final_t_timestep"]
+    assert abs(final["t_timestep"][0] - tf) <= 1e-11*abs(tf)
+    assert np.max(np.abs(final["r"] - g["final_r"])) < 1e-9*np.abs(g["final_r"]).max()
+    assert relerr(final["h"], g["final_h"]) < 1e-8
+    assert relerr(final["rho"], g["final_rho"]) < 1e-8
+    assert vec_err(final["a"], g["final_a"]) < 1e-7
+    assert relerr(final["u"], g["final_u"]) < 1e-8
