@@ -508,6 +508,7 @@ extern "C" int gh_update_hydro_forces(gh_ctx *ctx, gh_stats *stats)
   ctx->dom_ms[GH_T_SPH_FORCES] = 0; ctx->dom_calls[GH_T_SPH_FORCES] = 0;
   int rc = gh_hydro_forces_impl(ctx, stats != nullptr);
   if (rc) return rc;
+  if ((rc = gh_dd_return_levelneib(ctx))) return rc;
   rc = gh_sync_collect(ctx, "gh_update_hydro_forces");
   if (rc) return rc;
   if (stats) return read_stats(ctx, stats, GH_T_SPH_FORCES);
@@ -521,6 +522,7 @@ extern "C" int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats)
   int rc = gh_all_forces_impl(ctx, stats != nullptr);
   if (rc) return rc;
   gh_gas_star_forces_impl(ctx);                         // hybrid runs: gas <- stars (GradhSphTree.cpp:600-607)
+  if ((rc = gh_dd_return_levelneib(ctx))) return rc;
   rc = gh_sync_collect(ctx, "gh_update_all_forces");
   if (rc) return rc;
   if (stats) return read_stats(ctx, stats, GH_T_SPH_FORCES);
@@ -529,9 +531,11 @@ extern "C" int gh_update_all_forces(gh_ctx *ctx, gh_stats *stats)
 
 static int forces_impl(gh_ctx *ctx)
 {
-  if (ctx->cfg.self_gravity) { const int rc = gh_all_forces_impl(ctx, false); if (rc) return rc; return gh_gas_star_forces_impl(ctx); }
-  if (ctx->cfg.hydro_forces) return gh_hydro_forces_impl(ctx, false);
-  return gh_fail(ctx, GH_ERR_INVALID, "Error: No forces included in simulation");   // SphSimulation.cpp:474
+  int rc;
+  if (ctx->cfg.self_gravity) { if ((rc = gh_all_forces_impl(ctx, false))) return rc; if ((rc = gh_gas_star_forces_impl(ctx))) return rc; }
+  else if (ctx->cfg.hydro_forces) { if ((rc = gh_hydro_forces_impl(ctx, false))) return rc; }
+  else return gh_fail(ctx, GH_ERR_INVALID, "Error: No forces included in simulation");   // SphSimulation.cpp:474
+  return gh_dd_return_levelneib(ctx);                   // multi-GPU + block timesteps: levelneib raised on halo copies goes home
 }
 
 // ------------------------------------------------------------------------------------------------

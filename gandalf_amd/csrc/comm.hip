@@ -37,7 +37,7 @@
 #define DD_WHDR 4            /* ... header slots of a rank's block (the rank's particle extent rides in them) */
 #define DD_PMAX 5            /* published levels per rank subtree (2^(P+1) - 1 cells) */
 #define DD_FMAX 6            /* halo selection: 2^F fine geometry entries per published bottom cell */
-#define DD_REC 43            /* doubles per migrating particle: D_COUNT_BASE fields + iorig */
+#define DD_RECMAX (D_COUNT + 1)   /* doubles per migrating particle: the fields that are live (D_COUNT_BASE, or all with block timesteps) + iorig */
 
 double *gh_time_dev(gh_ctx *ctx);
 void gh_rootbox_local(gh_ctx *ctx, int node0);
@@ -67,6 +67,13 @@ struct gh_dd {
   double *spl_prev = nullptr, *spl_win = nullptr; int *spl_kd = nullptr, *spl_fail = nullptr;
   struct DDWin *wins = nullptr;
   DDCand *wnd = nullptr, *wnd_all = nullptr;
+  // the last force-phase exchange, for the way back of levelneib: leaves sent to / cells and leaves received from every rank,
+  // receive offsets (doubles), record layout
+  int fwd_ol[GH_MAX_RANKS] = {0}, fwd_ic[GH_MAX_RANKS] = {0}, fwd_il[GH_MAX_RANKS] = {0};
+  long long fwd_roff[GH_MAX_RANKS] = {0};
+  int fwd_lay_cell = 0, fwd_lay_leaf = 0, fwd_occ = 0;
+  char *ln_send = nullptr, *ln_recv = nullptr; size_t ln_send_bytes = 0, ln_recv_bytes = 0;
+  long long *ln_roff = nullptr;                       // device copy of fwd_roff
   bool have_splits = false;
   long long n_spec = 0, n_exact = 0;                  // decompositions done speculatively / with the three-collective search
   // pinned host staging of the halo exchange (sizes in, counts and offsets out): no stack array is read by an async copy
@@ -75,7 +82,7 @@ struct gh_dd {
   int *mig_cnt = nullptr;            // [2*nranks + 4]: leavers per destination, arrivals per source, cursor words
   int *mig_slot = nullptr;           // [own_count] position of every leaver in its destination's block
   int *mig_hole = nullptr;           // [own_count] positions freed by leavers
-  double *mig_send = nullptr, *mig_recv = nullptr;   // [own_count][DD_REC]
+  double *mig_send = nullptr, *mig_recv = nullptr;   // [own_count][DD_RECMAX]
   // published subtree tops
   char *pub_send = nullptr, *pub_recv = nullptr; size_t pub_bytes = 0;
   int F = 0;                         // fine entries: 2^F per published bottom cell
@@ -456,7 +463,7 @@ __global__ void k_mig_count(int n, const int *dest, int self, int *cnt, int *slo
   hole[atomicAdd(&cnt[2*GH_MAX_RANKS], 1)] = i;
 }
 
-struct MigTab { double *fld[DD_REC]; int off[GH_MAX_RANKS]; };
+struct MigTab { double *fld[DD_RECMAX]; int off[GH_MAX_RANKS]; int nf; };      // nf fields travel, then iorig
 
 __global__ void k_mig_pack(MigTab t, const int *iorig, int n, const int *dest, int self, const int *slot, double *send)
 {
@@ -464,9 +471,9 @@ __global__ void k_mig_pack(MigTab t, const int *iorig, int n, const int *dest, i
   if (i >= n) return;
   const int to = dest[i];
   if (to == self) return;
-  double *o = send + (size_t) (t.off[to] + slot[i])*DD_REC;
-  for (int f = 0; f < DD_REC - 1; f++) o[f] = t.fld[f][i];
-  o[DD_REC - 1] = (double) iorig[i];
+  double *o = send + (size_t) (t.off[to] + slot[i])*(t.nf + 1);
+  for (int f = 0; f < t.nf; f++) o[f] = t.fld[f][i];
+  o[t.nf] = (double) iorig[i];
 }
 
 __global__ void k_mig_unpack(MigTab t, int *iorig, int narr, const int *hole, const double *recv)
@@ -474,9 +481,9 @@ __global__ void k_mig_unpack(MigTab t, int *iorig, int narr, const int *hole, co
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= narr) return;
   const int i = hole[e];
-  const double *o = recv + (size_t) e*DD_REC;
-  for (int f = 0; f < DD_REC - 1; f++) t.fld[f][i] = o[f];
-  iorig[i] = (int) o[DD_REC - 1];
+  const double *o = recv + (size_t) e*(t.nf + 1);
+  for (int f = 0; f < t.nf; f++) t.fld[f][i] = o[f];
+  iorig[i] = (int) o[t.nf];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(256) void k_let_compact(int L, int self, const unsi
 }
 
 // record sizes in doubles: cell = id + the records of the phase; leaf = id + occ x particle record
-struct LetLayout { int cell_dbl, part_dbl, leaf_dbl, occ, phase, quad; };
+struct LetLayout { int cell_dbl, part_dbl, leaf_dbl, occ, phase, quad, lev; };     // lev: force records end with the particle's timestep level
 
 // pack / unpack: a thread moves ONE double of one record (cell records: up to 34 doubles; leaf records: id + occ particle
 // records), so that consecutive threads touch consecutive words of the message and of the 32-byte packs
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(256) void k_let_pack(DevicePtrs d, LetLayout lay, i
       else {
         const int t = (w - 1)/lay.part_dbl, k = (w - 1) - t*lay.part_dbl;
         const int first = d.cfirst[n], cn = d.cN[n];
-        if (t < cn) val = k < 4 ? ((const double*) &d.posm[first + t])[k] : ((const double*) &d.hrec[4*(size_t) (first + t)])[k - 4];
+        if (t < cn) val = k < 4 ? ((const double*) &d.posm[first + t])[k] : (k < 20 ? ((const double*) &d.hrec[4*(size_t) (first + t)])[k - 4] : d.f[D_LEVEL][first + t]);
       }
       base[e] = val;
     }
@@ -900,7 +907,8 @@ __global__ __launch_bounds__(256) void k_let_unpack(DevicePtrs d, LetLayout lay,
       const int first = d.cfirst[n], cn = d.cN[n];
       if (t < cn) {
         if (k < 4) ((double*) &d.posm[first + t])[k] = base[e];
-        else ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
+        else if (k < 20) ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
+        else { d.f[D_LEVEL][first + t] = base[e]; d.f[D_LEVELNEIB][first + t] = 0.0; }     // what this rank's active particles raise goes back (gh_dd_return_levelneib)
       }
     }
   }
@@ -943,7 +951,8 @@ extern "C" int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops
     for (int k = 0; k < ctx->ndim; k++)
       ok = ok && c.boundary_lhs[k] == c.boundary_rhs[k] && (c.boundary_lhs[k] == GH_BOUNDARY_OPEN || c.boundary_lhs[k] == GH_BOUNDARY_PERIODIC);
     if (!ok) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: open or periodic boundaries only");
-    if (c.Nlevels > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: global timestep only (Nlevels = 1)");
+    if (c.sink_particles) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: no sink particles (gas only; global or block timesteps)");
+    if (c.Nlevels > 1 && c.sph_single_timestep) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: block timesteps without sph_single_timestep");
     if (c.self_gravity && c.gravity_mac != GH_MAC_GEOMETRIC) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: gravity_mac = geometric only");
     if (c.avisc == GH_AVISC_MON97CD2010 || c.avisc == GH_AVISC_MON97MM97) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: no time-dependent viscosity");
     if (c.ntreebuildstep > 1) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: the tree is rebuilt every step (ntreebuildstep = 1)");
@@ -960,7 +969,7 @@ void gh_dd_free(gh_ctx *ctx)
   if (!D) return;
   void *ptrs[] = {D->topcell, D->cells, D->hist, D->hist_all, D->cand, D->cand_all, D->box6, D->box6_all, D->mig_cnt, D->mig_slot,
                   D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->comb_send, D->comb_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
-                  D->let_send, D->let_recv, D->dt_all, D->let_vis, D->let_work, D->spl_prev, D->spl_win, D->spl_kd, D->wins, D->wnd, D->wnd_all};
+                  D->let_send, D->let_recv, D->ln_send, D->ln_recv, D->ln_roff, D->dt_all, D->let_vis, D->let_work, D->spl_prev, D->spl_win, D->spl_kd, D->wins, D->wnd, D->wnd_all};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   for (void *p : {(void*) D->h_cnt, (void*) D->h_off, (void*) D->h_all}) if (p) (void) hipHostFree(p);
   delete D;
@@ -998,8 +1007,8 @@ static int dd_alloc(gh_ctx *ctx)
   GH_CHECK(ctx, hipMalloc((void**) &D->mig_cnt, sizeof(int)*(4*GH_MAX_RANKS)));
   GH_CHECK(ctx, hipMalloc((void**) &D->mig_slot, sizeof(int)*n));
   GH_CHECK(ctx, hipMalloc((void**) &D->mig_hole, sizeof(int)*n));
-  GH_CHECK(ctx, hipMalloc((void**) &D->mig_send, sizeof(double)*n*DD_REC));
-  GH_CHECK(ctx, hipMalloc((void**) &D->mig_recv, sizeof(double)*n*DD_REC));
+  GH_CHECK(ctx, hipMalloc((void**) &D->mig_send, sizeof(double)*n*DD_RECMAX));
+  GH_CHECK(ctx, hipMalloc((void**) &D->mig_recv, sizeof(double)*n*DD_RECMAX));
   D->pub_bytes = sizeof(PubRec)*(size_t) ((2 << D->P) - 1);
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_send, D->pub_bytes));
   GH_CHECK(ctx, hipMalloc((void**) &D->pub_recv, D->pub_bytes*W));
@@ -1013,6 +1022,7 @@ static int dd_alloc(gh_ctx *ctx)
   }
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cnt, sizeof(int)*8*GH_MAX_RANKS));
   GH_CHECK(ctx, hipMalloc((void**) &D->let_off, sizeof(long long)*2*GH_MAX_RANKS));
+  GH_CHECK(ctx, hipMalloc((void**) &D->ln_roff, sizeof(long long)*GH_MAX_RANKS));
   // a rank can need, at most, all of another rank's subtree
   D->let_cellcap = (size_t) 2*(ctx->gtot >> ctx->L); D->let_leafcap = (size_t) (ctx->gtot >> ctx->L);
   GH_CHECK(ctx, hipMalloc((void**) &D->let_cells, sizeof(int)*D->let_cellcap*W));
@@ -1123,11 +1133,13 @@ int gh_dd_decompose(gh_ctx *ctx)
   D->have_splits = true;
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   MigTab tab;
+  tab.nf = ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE;       // block timesteps: level, levelneib, nstep, nlast, flags (and sinkid) travel too
+  const int nrec = tab.nf + 1;
   long long nsend = 0, nrecv = 0;
   for (int r = 0; r < W; r++) {
     const int out = all[(size_t) ctx->rank*(GH_MAX_RANKS + 1) + r], in = all[(size_t) r*(GH_MAX_RANKS + 1) + ctx->rank];
     tab.off[r] = (int) nsend;
-    sb[r] = (int64_t) out*DD_REC*sizeof(double); rb[r] = (int64_t) in*DD_REC*sizeof(double);
+    sb[r] = (int64_t) out*nrec*sizeof(double); rb[r] = (int64_t) in*nrec*sizeof(double);
     nsend += out; nrecv += in;
   }
   // every rank's particle count is static, so leavers and arrivals balance on EVERY rank or on none: a split that left a
@@ -1139,8 +1151,7 @@ int gh_dd_decompose(gh_ctx *ctx)
     if (o != in) unbalanced = true;
   }
   if (unbalanced) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: unbalanced migration (equal coordinates at a top-level split?)");
-  for (int f = 0; f < DD_REC - 1; f++) tab.fld[f] = own.f[f];
-  static_assert(DD_REC - 1 == D_COUNT_BASE, "migration record = the fields of a global-timestep run + iorig");
+  for (int f = 0; f < tab.nf; f++) tab.fld[f] = own.f[f];
   if (nsend > 0) hipLaunchKernelGGL(k_mig_pack, dim3(nb), dim3(256), 0, s, tab, own.iorig, pn, D->topcell, ctx->rank, D->mig_slot, D->mig_send);
   DD_OP(ctx, D->ops.alltoallv(D->ops.user, D->mig_send, sb, D->mig_recv, rb, (void*) s));     // collective: every rank calls it
   if (nrecv > 0) hipLaunchKernelGGL(k_mig_unpack, dim3(cdiv(nrecv, 256)), dim3(256), 0, s, tab, own.iorig, (int) nrecv, D->mig_hole, D->mig_recv);
@@ -1260,7 +1271,8 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   LetLayout lay;
   lay.phase = phase; lay.quad = ctx->cquad ? 1 : 0; lay.occ = ctx->leafocc;
   lay.cell_dbl = phase == GH_HALO_DENSITY ? 9 : (lay.quad ? 34 : 29);
-  lay.part_dbl = phase == GH_HALO_DENSITY ? 4 : 20;
+  lay.lev = (phase != GH_HALO_DENSITY && ctx->cfg.Nlevels > 1) ? 1 : 0;
+  lay.part_dbl = phase == GH_HALO_DENSITY ? 4 : 20 + lay.lev;
   lay.leaf_dbl = 1 + lay.occ*lay.part_dbl;
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   long long soff[GH_MAX_RANKS], roff[GH_MAX_RANKS], stot = 0, rtot = 0, nimp = 0;
@@ -1274,7 +1286,14 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
     rcnt[2*r] = ic; rcnt[2*r + 1] = il;
     nimp += (long long) il*lay.occ;
   }
-  if (phase != GH_HALO_DENSITY) D->held_particles = ctx->own_count + nimp;
+  if (phase != GH_HALO_DENSITY) {
+    D->held_particles = ctx->own_count + nimp;
+    for (int r = 0; r < W; r++) {
+      D->fwd_ol[r] = r == ctx->rank ? 0 : all[(size_t) ctx->rank*CW + 2*r + 1];
+      D->fwd_ic[r] = rcnt[2*r]; D->fwd_il[r] = rcnt[2*r + 1]; D->fwd_roff[r] = roff[r];
+    }
+    D->fwd_lay_cell = lay.cell_dbl; D->fwd_lay_leaf = lay.leaf_dbl; D->fwd_occ = lay.occ;
+  }
   if (getenv("GH_DD_DEBUG")) {
     fprintf(stderr, "[dd] rank %d phase %d widen %.1f:", ctx->rank, phase, widen);
     for (int r = 0; r < W; r++) if (r != ctx->rank) fprintf(stderr, "  to %d: %d cells %d leaves | from %d: %d cells %d leaves", r,
@@ -1322,6 +1341,100 @@ int gh_dd_min_dt(gh_ctx *ctx)
   gh_dd *D = ctx->dd;
   DD_OP(ctx, dd_allgather(ctx, gh_time_dev(ctx) + 1, D->dt_all, sizeof(double)));
   hipLaunchKernelGGL(k_dd_min_dt, dim3(1), dim3(1), 0, ctx->stream, D->dt_all, ctx->nranks, gh_time_dev(ctx));
+  return GH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block timesteps on more than one rank: the reductions of Simulation::ComputeBlockTimesteps (the MPI_Allreduce calls of
+// Simulation.cpp:1843-1847, 2016-2080: minimum timestep, highest occupied level) and of MainLoop's wake-up count
+// (SphSimulation.cpp:753), on one device word each
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dd_reduce_int(const int *all, int nranks, int *word, int op)
+{
+  int v = all[0];
+  for (int r = 1; r < nranks; r++) v = op == 0 ? max(v, all[r]) : v + all[r];
+  *word = v;
+}
+int gh_dd_reduce_int(gh_ctx *ctx, int *word_dev, int op /* 0 max, 1 sum */)
+{
+  if (ctx->nranks == 1) return GH_OK;
+  gh_dd *D = ctx->dd;
+  DD_OP(ctx, dd_allgather(ctx, word_dev, D->hist_all, sizeof(int)));
+  hipLaunchKernelGGL(k_dd_reduce_int, dim3(1), dim3(1), 0, ctx->stream, D->hist_all, ctx->nranks, word_dev, op);
+  return GH_OK;
+}
+
+// levelneib of the imported particles -> their owners.  An active particle raises levelneib of every SPH neighbour to
+// its own level (GradhSph.cpp:455, 569; GradhSphTree.cpp:376-417); for a neighbour this rank only holds a copy of, the
+// raise lands in the copy (zeroed at import).  The copies' values go back along the lists of the force-phase exchange -
+// no count exchange, the sizes are those of the way out - and the owners take the maximum.  (The reference's MPI layer
+// returns levelneib with the exported particles' accelerations, MpiControl.cpp:910-990.)
+__global__ void k_ln_pack(DevicePtrs d, int self, const double *recv, const long long *roff, const int *rcnt, int cell_dbl, int leaf_dbl, int occ,
+                          const long long *boff, double *out)
+{
+  const int r = blockIdx.y;
+  if (r == self) return;
+  const int ic = rcnt[2*r], il = rcnt[2*r + 1];
+  const double *leaf0 = recv + roff[r] + (long long) ic*cell_dbl;
+  for (int e = blockIdx.x*blockDim.x + threadIdx.x; e < il*occ; e += gridDim.x*blockDim.x) {
+    const int l = e/occ, t = e - l*occ;
+    const int n = (int) leaf0[(long long) l*leaf_dbl];
+    out[boff[r] + e] = t < d.cN[n] ? d.f[D_LEVELNEIB][d.cfirst[n] + t] : 0.0;
+  }
+}
+__global__ void k_ln_merge(DevicePtrs d, int self, const int *cnt, const int *leaves, size_t leafcap, int occ, const long long *boff, const double *in)
+{
+  const int r = blockIdx.y;
+  if (r == self) return;
+  const int ol = cnt[2*r + 1];
+  for (int e = blockIdx.x*blockDim.x + threadIdx.x; e < ol*occ; e += gridDim.x*blockDim.x) {
+    const int l = e/occ, t = e - l*occ;
+    const int n = leaves[(size_t) r*leafcap + l];
+    if (t < d.cN[n]) {
+      const double v = in[boff[r] + e];
+      double *p = &d.f[D_LEVELNEIB][d.cfirst[n] + t];
+      if (*p < v) atomicMax((unsigned long long*) p, (unsigned long long) __double_as_longlong(v));     // non-negative doubles order like their bit patterns
+    }
+  }
+}
+int gh_dd_return_levelneib(gh_ctx *ctx)
+{
+  if (ctx->nranks == 1 || ctx->cfg.Nlevels <= 1) return GH_OK;
+  gh_dd *D = ctx->dd;
+  const int W = ctx->nranks, occ = D->fwd_occ;
+  hipStream_t s = ctx->stream;
+  int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
+  // (h_off is pinned staging shared with the forward exchange, whose copy out of it may still be queued: drain first)
+  GH_CHECK(ctx, hipStreamSynchronize(s));
+  long long *hoff = D->h_off;                             // [0, MAX): send offsets, [MAX, 2 MAX): receive offsets
+  long long stot = 0, rtot = 0;
+  for (int r = 0; r < GH_MAX_RANKS; r++) {
+    const long long sd = r < W ? (long long) D->fwd_il[r]*occ : 0, rd = r < W ? (long long) D->fwd_ol[r]*occ : 0;
+    hoff[r] = stot; hoff[GH_MAX_RANKS + r] = rtot;
+    if (r < W) { sb[r] = sd*8; rb[r] = rd*8; }
+    stot += sd; rtot += rd;
+  }
+  auto grow = [&](char **p, size_t *have, size_t need) -> hipError_t {
+    if (need <= *have) return hipSuccess;
+    if (*p) (void) hipFree(*p);
+    *p = nullptr; *have = 0;
+    const size_t cap = need + need/4 + 4096;
+    const hipError_t e = hipMalloc((void**) p, cap);
+    if (e == hipSuccess) *have = cap;
+    return e;
+  };
+  GH_CHECK(ctx, grow(&D->ln_send, &D->ln_send_bytes, (size_t) stot*8 + 8));
+  GH_CHECK(ctx, grow(&D->ln_recv, &D->ln_recv_bytes, (size_t) rtot*8 + 8));
+  long long *d_offs = D->let_off;                         // device [2 MAX]
+  GH_CHECK(ctx, hipMemcpyAsync(d_offs, hoff, sizeof(long long)*2*GH_MAX_RANKS, hipMemcpyHostToDevice, s));
+  GH_CHECK(ctx, hipMemcpyAsync(D->ln_roff, D->fwd_roff, sizeof(long long)*GH_MAX_RANKS, hipMemcpyHostToDevice, s));
+  DevicePtrs d = gh_dev(ctx);
+  hipLaunchKernelGGL(k_ln_pack, dim3(256, W), dim3(256), 0, s, d, ctx->rank, (const double*) D->let_recv, D->ln_roff, D->let_cnt + 4*GH_MAX_RANKS,
+                     D->fwd_lay_cell, D->fwd_lay_leaf, occ, d_offs, (double*) D->ln_send);
+  DD_OP(ctx, D->ops.alltoallv(D->ops.user, D->ln_send, sb, D->ln_recv, rb, (void*) s));
+  hipLaunchKernelGGL(k_ln_merge, dim3(256, W), dim3(256), 0, s, d, ctx->rank, D->let_cnt, D->let_leaves, D->let_leafcap, occ,
+                     d_offs + GH_MAX_RANKS, (const double*) D->ln_recv);
+  GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
 }
 

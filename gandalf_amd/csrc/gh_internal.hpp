@@ -309,6 +309,8 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen);   // ... with t
 int gh_force_halo(gh_ctx *ctx, int phase);     // forces.hip: force records of the own particles, then the halo of `phase` (redoes a deferred density miss)
 int gh_dd_any(gh_ctx *ctx, const unsigned int *count_dev, int *any);   // any rank's counter non-zero? (collective, synchronises)
 int gh_dd_min_dt(gh_ctx *ctx);                 // time[1] = min over ranks
+int gh_dd_reduce_int(gh_ctx *ctx, int *word_dev, int op);   // one device word: 0 = max, 1 = sum over ranks (block clock)
+int gh_dd_return_levelneib(gh_ctx *ctx);       // block timesteps: levelneib raised on imported copies -> max at their owners
 void gh_dd_free(gh_ctx *ctx);
 // sinks.hip
 int gh_sinks_potmin(gh_ctx *ctx);           // potential-minimum flag of the particles with rho >= rho_sink (after a density pass)

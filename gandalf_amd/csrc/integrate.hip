@@ -390,12 +390,14 @@ int gh_block_timesteps_impl(gh_ctx *ctx)
     const int nblk = 256;
     hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(GH_TS_THREADS), 0, s, d, fill_tp(ctx), ctx->redbuf);
     hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
+    { const int rc = gh_dd_min_dt(ctx); if (rc) return rc; }            // multi-GPU: the minimum over all ranks (Simulation.cpp:1843-1847)
     hipLaunchKernelGGL(k_block_resync_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time, ctx->cfg.Nlevels);
     hipLaunchKernelGGL(k_block_resync_assign, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, time, ctx->cfg.sph_single_timestep);
     hipLaunchKernelGGL(k_block_resync_finish, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
   }
   else {
     hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
+    { const int rc = gh_dd_reduce_int(ctx, ctx->d_blk + B_LMAXNEW, 0); if (rc) return rc; }   // highest occupied level of all ranks (:2016-2080)
     hipLaunchKernelGGL(k_block_clock, dim3(1), dim3(1), 0, s, ctx->d_blk, time);
     hipLaunchKernelGGL(k_block_rescale, dim3(nb), dim3(256), 0, s, d, ctx->d_blk, ctx->cfg.sph_single_timestep);
   }
@@ -478,5 +480,5 @@ int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult)
 int gh_check_timesteps_impl(gh_ctx *ctx)
 {
   hipLaunchKernelGGL(k_check_timesteps, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), ctx->d_blk, ctx->cfg.level_diff_max);
-  return GH_OK;
+  return gh_dd_reduce_int(ctx, ctx->d_blk + B_ACTIVE, 1);               // multi-GPU: particles woken on any rank repeat the passes on all (SphSimulation.cpp:753)
 }

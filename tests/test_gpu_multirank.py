@@ -34,7 +34,8 @@ sim.generate_ic()
 run = DistributedRunner(sim, rank, world)
 run.setup()
 run.steps(nsteps)
-res = {k: run.gather(k) for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot")}
+fields = ["r", "v", "h", "rho", "a", "u", "dudt", "gpot"] + (["level", "levelneib", "nstep", "nlast"] if int(sim.get_param("Nlevels")) > 1 else [])
+res = {k: run.gather(k) for k in fields}
 own_first, own_count, held = run.dev.comm_info()
 info = np.array([own_count, held, sim.t, sim.timestep])
 if world > 1:
@@ -97,6 +98,24 @@ def test_ranks_equal_one_rank(case, world, tmp_path):
         a, b = one[k], many[k]
         assert np.all(np.isfinite(b)), k
         assert _relerr(a, b) <= 1e-13, (k, _relerr(a, b))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", ["plummer_4k_levels", "box3d_4k_levels"])
+def test_block_timesteps_on_ranks_equal_one_rank(case, world, tmp_path):
+    """Hierarchical block timesteps (Nlevels = 5) under the domain decomposition: level / nstep / nlast / flags migrate with
+    the particles, the minimum timestep, the highest occupied level and CheckTimesteps' wake-up count are reduced over the
+    ranks (Simulation.cpp:1843-1847, 2016-2080; SphSimulation.cpp:753), the halo carries the neighbours' levels and the
+    levelneib raised on halo copies returns to the owners.  40 steps: the level structure and the integer clock must be
+    EXACTLY those of the one-rank run, the fields equal to rounding."""
+    one = _run(tmp_path, case, 1, 40, {})
+    many = _run(tmp_path, case, world, 40, {})
+    assert np.all(many["info"][:, 2] == one["info"][2]) and np.all(many["info"][:, 3] == one["info"][3])      # t, dt
+    for k in ("level", "levelneib", "nstep", "nlast"):
+        assert np.array_equal(one[k], many[k]), k
+    for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot"):
+        assert np.all(np.isfinite(many[k])), k
+        assert _relerr(one[k], many[k]) <= 1e-12, (k, _relerr(one[k], many[k]))
 
 
 def test_two_ranks_at_the_benchmark_size(tmp_path):
