@@ -907,7 +907,10 @@ __global__ __launch_bounds__(256) void k_let_unpack(DevicePtrs d, LetLayout lay,
       const int first = d.cfirst[n], cn = d.cN[n];
       if (t < cn) {
         if (k < 4) ((double*) &d.posm[first + t])[k] = base[e];
-        else if (k < 20) ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
+        else if (k < 20) {
+          ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
+          if (k == 4 + 7) d.f[D_HRANGESQD][first + t] = base[e];        // hrangesqd: the candidate classification of k_grav_eval reads the SoA array
+        }
         else { d.f[D_LEVEL][first + t] = base[e]; d.f[D_LEVELNEIB][first + t] = 0.0; }     // what this rank's active particles raise goes back (gh_dd_return_levelneib)
       }
     }
