@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_PEAK_TFLOPS = 78.6    # fp64 vector: half the guide's 157.3 TFLOP/s fp32 vector rate (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+F64_PEAK_TINSTR = 39.3    # ... as issue slots: 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz = 3.93e13 lane-instructions/s
 
 
 def _sha16(path):
@@ -239,15 +240,17 @@ def main():
         #        slot as 2 flop, half the guide's 157.3 TFLOP/s fp32 vector peak);
         #     b. HBM: bytes the kernel actually requests, counted per (leaf, entry) as it loads them.
         instr = 19.0*(forc["n_cells"] + forc["n_direct"]) + 20.0*forc["n_candidates"] + 115.0*forc["n_candidates"]
-        tfl = 2.0*instr/(forc_ms*1e-3)/1e12 if forc_ms > 0 else 0.0
+        tin = instr/(forc_ms*1e-3)/1e12 if forc_ms > 0 else 0.0          # tera lane-instructions per second
         leaf_bytes = (forc["n_leaf_cells"]*36.0 + forc["n_leaf_direct"]*32.0 + forc["n_leaf_cand"]*40.0
                       + forc["n_candidates"]*128.0 + nown*(136.0 + 80.0))
         hbm_gbs = leaf_bytes/(forc_ms*1e-3)/1e9 if forc_ms > 0 else 0.0
-        r_valu = {"kernel": "k_grav_eval", "bound": "fp64_valu", "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": tfl/F64_PEAK_TFLOPS, "traffic": pmc.get("k_grav_eval"),
+        meas = pmc.get("k_grav_eval_f64_flops")
+        r_valu = {"kernel": "k_grav_eval", "bound": "fp64_valu", "achieved": tin, "peak": F64_PEAK_TINSTR, "unit": "T lane-instr/s",
+                  "frac": tin/F64_PEAK_TINSTR, "traffic": pmc.get("k_grav_eval"),
+                  "measured_fp64_tflops": (meas/(forc_ms*1e-3)/1e12 if (meas and forc_ms > 0) else None), "fp64_peak_tflops": F64_PEAK_TFLOPS,
                   "algorithmic_fp64_lane_instructions_per_launch": instr, "avg_launch_ms": forc_ms,
                   "measured_fp64_lane_instructions_per_launch": pmc.get("k_grav_eval_f64_lane_instr"),
-                  "model": "19*(cell + direct terms) + 135*SPH pairs fp64 VALU lane-instructions; peak = 3.93e13 lane-instr/s as 78.6 TFLOP/s (FMA slot = 2 flop)",
+                  "model": "19*(cell + direct terms) + 135*SPH pairs fp64 VALU lane-instructions against the issue peak 3.93e13 lane-instr/s (one slot per instruction whatever it is; measured_fp64_tflops counts an FMA as 2 flop, the others as 1, from the PMC pass)",
                   "hbm_leaf_model": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs/HBM_PEAK_GBS,
                                      "bytes_per_launch": leaf_bytes,
                                      "model": "36 B per (leaf, cell entry) + 32 B per (leaf, direct particle) + 40 B per (leaf, hydro candidate) + 128 B per SPH pair + 216 B per particle"},

@@ -54,13 +54,20 @@ __device__ __forceinline__ int dens_quarter(const DevicePtrs &d, int gnode, int 
 }
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// x^(1/ND), the reference's pow(x, invndim) (Sph.h:259): ND = 1, 2 exactly; ND = 3 through cbrt, which agrees with pow(x, 1.0/3.0)
+// to an ulp or two (h is compared at 1e-12) and needs a third of pow's registers - the kernel spilled around this call
+template <int ND> __device__ __forceinline__ double root_nd(double x)
+{
+  return ND == 1 ? x : (ND == 2 ? sqrt(x) : cbrt(x));
+}
+
 // normalise and store the converged sums of one particle (GradhSph.cpp:262-317)
 template <int ND, class K>
 __device__ __forceinline__ void density_store(const DevicePtrs &d, const DensityParams &P, int i, double mi, double ui,
                                               double rho, double omg, double zet, double hlo, double invhsqd_last, double hmaxl)
 {
   const double invndim = 1.0/(double) ND;
-  const double h = fmax(P.h_fac*pow(mi/rho, invndim), hlo);
+  const double h = fmax(P.h_fac*root_nd<ND>(mi/rho), hlo);
   const double invh1 = 1.0/h;
   const double hfac1 = powN<ND>(invh1)*invh1;
   const double deriv = -invndim*h/rho;                                     // h_rho_deriv, Sph.h:264
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     bool failed = false;
     if (running) {
       rho *= hfactor; omg *= hfactor; zet *= invhsqd;
-      const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
+      const double hnew = P.h_fac*root_nd<ND>(mi/rho);                     // h_rho_func, Sph.h:259
       if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
       else {
         if (iter < 30) h = hnew;
@@ -480,8 +487,11 @@ struct DensLists {
   int rcap;
 };
 
+#ifndef GH_DWALK_WPE
+#define GH_DWALK_WPE 6      /* 80 VGPRs: at 8 waves (64 VGPRs) the quarter-mask code spilled inside the walk loop (0.33 -> 0.31 ms) */
+#endif
 template <int ND, int KT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_dens_walk(DevicePtrs d, DensityParams P, DensLists G, int *flags)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DWALK_WPE, 8))) void k_dens_walk(DevicePtrs d, DensityParams P, DensLists G, int *flags)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_stack[GH_SCAP];
@@ -669,7 +679,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
   typedef typename KSel<ND, KT>::type K;
   constexpr int TC = 64/S;                                 // targets per wave
   constexpr int PPT = 32/S;                                // candidate pairs per tile and lane
-  constexpr int NB = S;                                    // tiles per batch: NB * 2 * PPT = 64 mask bits per lane
+  constexpr int NB = S;                                    // tiles per batch: NB * 2 * PPT = 64 mask bits per lane (three words
+                                                           // per batch - one pass of the fp64 loop over a whole iteration's tiles - measured slower: 1.29 vs 1.10 ms)
   __shared__ int s_idx[GH_DENS_ICAP];                      // particle index | image code << GH_NODE_BITS, -1 = padding
   // a tile in fp32, relative to the quarter's centre: per PAIR of candidates {x0, x1, y0, y1, z0, z1, -, -} (32-byte
   // records: one 16-byte + one 8-byte LDS read feed two packed-fp32 distance evaluations); two buffers - tile t + 1 is
@@ -791,7 +802,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
           const int p = __ffsll((long long) mk) - 1;
           mk &= mk - 1ull;
           const int b = p/(2*PPT), u = p - b*(2*PPT);
-          const int id = s_idx[(tbase + b)*64 + 2*(sl + (u >> 1)*S) + (u & 1)];
+          const int id = s_idx[(tbase + b)*64 + (u >> 1)*2*S + (u & 1)*S + sl];        // own pair u/2, member u%2 (see stage)
           double4 v = d.posm[id & GH_NODE_MASK];
           if (images) {
             double sg[3], sh[3];
@@ -843,10 +854,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
             x = sg[0]*v.x + sh[0]; y = sg[1]*v.y + sh[1]; z = sg[2]*v.z + sh[2];
           }
         }
+        // candidate c of the tile goes to pair record (c / 2S)*S + c % S, member (c / S) % 2: consecutive candidates - the
+        // particles of one leaf, which are neighbours together or not at all - are dealt to different sub-lanes, so the fp64
+        // work of a target is shared evenly (with pairs of adjacent candidates per sub-lane the busiest lane of a wave had
+        // twice the mean)
         float (*f)[8] = s_f[t & 1];
-        f[lane >> 1][lane & 1] = (float) (x - gc[0]);
-        f[lane >> 1][2 + (lane & 1)] = ND > 1 ? (float) (y - gc[1]) : 0.f;
-        f[lane >> 1][4 + (lane & 1)] = ND > 2 ? (float) (z - gc[2]) : 0.f;
+        const int pr = (lane/(2*S))*S + lane%S, pb = (lane/S) & 1;
+        f[pr][pb] = (float) (x - gc[0]);
+        f[pr][2 + pb] = ND > 1 ? (float) (y - gc[1]) : 0.f;
+        f[pr][4 + pb] = ND > 2 ? (float) (z - gc[2]) : 0.f;
       };
       stage(0);
       __syncthreads();
@@ -855,7 +871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
         if (t + 1 < ntiles) stage(t + 1);                  // into the other buffer
         // support mask in packed fp32: dd = |r_c - r_i|^2 - thr from three packed FMAs per candidate pair; its sign bit
         // (set = inside the conservative threshold) is shifted into the mask by one v_alignbit_b32 per candidate: own pair k
-        // (candidates 2*(sl + k*S), + 1) lands in bits 31 - 2k, 30 - 2k of the word, which is bit-reversed at the end.
+        // (candidates 2S*k + sl, + S) lands in bits 31 - 2k, 30 - 2k of the word, which is bit-reversed at the end.
         unsigned int mw = 0;
         {
           const float (*f)[8] = s_f[t & 1];
@@ -880,7 +896,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
         if (COUNT) {
           if (running) {
             for (int k = 0; k < 2*PPT; k++) {
-              const int id = s_idx[t*64 + 2*(sl + (k >> 1)*S) + (k & 1)];
+              const int id = s_idx[t*64 + (k >> 1)*2*S + (k & 1)*S + sl];
               if (id >= 0) {
                 double4 v = d.posm[id & GH_NODE_MASK];
                 if (images) {
@@ -912,7 +928,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GH_DENS_WPE,
     bool failed = false;
     if (running) {
       rho = prho*hfactor; omg = pomg*hfactor; zet = pzet*invhsqd;
-      const double hnew = P.h_fac*pow(mi/rho, invndim);                    // h_rho_func, Sph.h:259
+      const double hnew = P.h_fac*root_nd<ND>(mi/rho);                     // h_rho_func, Sph.h:259
       if (rho > 0.0 && h > hlo && fabs(h - hnew)*invh < P.h_converge) done = true;
       else {
         if (iter < 30) h = hnew;

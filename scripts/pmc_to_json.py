@@ -78,6 +78,7 @@ def main():
         f64 = sum(ge.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
         if f64:
             entry["k_grav_eval_f64_lane_instr"] = 64.0*f64
+            entry["k_grav_eval_f64_flops"] = 64.0*(f64 + ge.get("SQ_INSTS_VALU_FMA_F64", 0.0))     # an FMA counts 2, everything else 1
     gw = first("k_grav_walk<")
     if gw:
         entry["k_grav_walk"] = 2.0*gw.get("FETCH_SIZE", 0.0)*1024 + gw.get("WRITE_SIZE", 0.0)*1024
