@@ -828,7 +828,10 @@ extern "C" int gh_step(gh_ctx *ctx, int nsteps, double *t, double *timestep)
     gh_phase_begin(ctx, GH_T_KDK);
     gh_kdk_advance_impl(ctx, ctx->n, 0.0, 0.0);          // AdvanceParticles + CheckBoundaries
     gh_phase_end(ctx, GH_T_KDK);
-    if ((rc = step_tree_timed(ctx))) return rc;          // BuildTree: rebuild or re-stock
+    ctx->in_step = true;
+    rc = step_tree_timed(ctx);                           // BuildTree: rebuild or re-stock
+    ctx->in_step = false;
+    if (rc) return rc;
     ctx->dd_defer_miss = ctx->nranks > 1;                // multi-GPU: the halo-miss check of the density pass rides in the force-phase exchange
     rc = density_and_hmax(ctx, false);                   // UpdateAllSphProperties
     ctx->dd_defer_miss = false;

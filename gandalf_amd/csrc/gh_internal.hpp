@@ -205,6 +205,7 @@ struct gh_ctx {
   int rank = 0, nranks = 1, L = 0;
   int64_t own_first = 0, own_count = 0;
   int iota_p0 = -1;
+  bool in_step = false;            // inside gh_step's global-timestep loop: the tree build may skip arrays the step rewrites anyway
   bool tree_valid_once = false;    // gh_build_tree_scheduled: a tree has been built for the current particle set
   struct gh_dd *dd = nullptr;
   // gh_step: the check "did any rank's density walk leave its imported halo" is deferred to the count exchange of the

@@ -572,9 +572,10 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
 // ------------------------------------------------------------------------------------------------
 // gather all particle arrays into tree order
 // ------------------------------------------------------------------------------------------------
-__global__ void k_permute(double **tab /* [2*D_COUNT]: src then dst */, const int *perm, int p0, int pn)
+__global__ void k_permute(double **tab /* [2*D_COUNT]: src then dst */, const int *perm, int p0, int pn, unsigned long long live)
 {
   const int f = blockIdx.y;
+  if (!((live >> f) & 1ull)) return;                     // an array every step rewrites before it reads it (gh_tree_build_impl)
   const double *src = tab[f];
   double *dst = tab[D_COUNT + f];
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < pn; i += gridDim.x*blockDim.x) dst[p0 + i] = src[perm[p0 + i]];
@@ -1177,7 +1178,18 @@ int gh_tree_build_impl(gh_ctx *ctx)
   if (ctx->cfg.sink_particles && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], nullptr))) return rc; }
   else if (ctx->exact_armed && ctx->nranks == 1) { if ((rc = exact_build_gated(ctx, ctx->P[pb][0], ctx->d_blk + 13))) return rc; }
   const int *perm = ctx->P[pb][0];
-  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), (ctx->cfg.Nlevels > 1 || ctx->cfg.sink_particles) ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn);
+  // Inside a global-timestep gh_step every particle gets new density-pass outputs (rho, invomega, zeta, hfactor, hrangesqd,
+  // sound, pressure, div_v) and new accelerations (a, atree, gpot, gpot_hydro, dudt: zeroed, then summed) before anything
+  // reads them: those 17 of the 42 arrays need not be carried into the new tree order.  Not with block timesteps (inactive
+  // particles keep theirs), sinks, the time-dependent viscosities (cd2010 gathers the neighbours' a), relative MACs (the
+  // stocking reads atree / gpot), nor for builds the caller asks for itself (gh_build_tree: it may look at anything).
+  unsigned long long live = ~0ull;
+  if (ctx->in_step && ctx->cfg.Nlevels <= 1 && !ctx->cfg.sink_particles && (ctx->cfg.avisc == GH_AVISC_NONE || ctx->cfg.avisc == GH_AVISC_MON97) &&
+      (!ctx->cfg.self_gravity || ctx->cfg.gravity_mac == GH_MAC_GEOMETRIC) && ctx->nstars == 0) {
+    for (int f : {D_RHO, D_INVOMEGA, D_ZETA, D_HFACTOR, D_HRANGESQD, D_SOUND, D_PRESSURE, D_DIV_V, D_AX, D_AY, D_AZ, D_ATX, D_ATY, D_ATZ,
+                  D_GPOT, D_GPOT_HYDRO, D_DUDT}) live &= ~(1ull << f);
+  }
+  hipLaunchKernelGGL(k_permute, dim3(std::min(nb, 2048), (ctx->cfg.Nlevels > 1 || ctx->cfg.sink_particles) ? D_COUNT : D_COUNT_BASE), dim3(256), 0, s, ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, perm, p0, pn, live);
   hipLaunchKernelGGL(k_permute_int, dim3(nb), dim3(256), 0, s, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], perm, p0, pn);
   ctx->cur ^= 1;
   ctx->tree_valid = true;
