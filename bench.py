@@ -164,7 +164,7 @@ def main():
     def comm_calls():
         if runner.ops is None:
             return {"allgather": 0, "alltoallv": 0, "bytes": 0}
-        return runner.ops.counters() if transport == "rccl" else dict(runner.ops.calls)
+        return runner.ops.counters() if runner.transport == "rccl" else dict(runner.ops.calls)
 
     def sync():
         torch.cuda.synchronize()
@@ -283,7 +283,7 @@ def main():
             "counters": {"density": dens, "forces": forc},
         }
         if world > 1:
-            out["multi_gpu"] = {"transport": "RCCL bound natively in libgandalf_hip.so (ncclAllGather, grouped ncclSend/ncclRecv)" if transport == "rccl"
+            out["multi_gpu"] = {"transport": "RCCL bound natively in libgandalf_hip.so (ncclAllGather, grouped ncclSend/ncclRecv)" if runner.transport == "rccl"
                                 else "torch.distributed callbacks (%s)" % backend,
                                 "collectives_per_step": {k: (c1[k] - c0[k])/args.steps for k in ("allgather", "alltoallv")},
                                 "bytes_per_step": (c1["bytes"] - c0["bytes"])/args.steps, "imbalance": imbalance}

@@ -297,7 +297,7 @@ __global__ void k_dd_assign(DevicePtrs d, int *topcell, const DDCell *cells)
 // four times the last shift and for ~256 candidates at the density seen.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_dd_win_init(DDCell *cells, DDWin *wins, int level, const double *dbbmin, const double *dbbmax, const int *cN, int ndim,
-                              const double *spl_prev, const double *spl_win, const int *spl_kd, int *fail)
+                              const double *spl_prev, const double *spl_win, const int *spl_kd, int *fail, double winscale)
 {
   const int c = threadIdx.x;
   if (c >= (1 << level)) return;
@@ -316,7 +316,7 @@ __global__ void k_dd_win_init(DDCell *cells, DDWin *wins, int level, const doubl
   q.rdiv = spl_prev[n]; q.rdiv_id = -1; q.pad = 0;
   cells[c] = q;
   DDWin w;
-  w.lo = spl_prev[n] - spl_win[n]; w.hi = spl_prev[n] + spl_win[n]; w.kd = kd; w.pad = 0;
+  w.lo = spl_prev[n] - winscale*spl_win[n]; w.hi = spl_prev[n] + winscale*spl_win[n]; w.kd = kd; w.pad = 0;
   wins[c] = w;
 }
 
@@ -1082,11 +1082,14 @@ static int dd_levels_speculative(gh_ctx *ctx)
   DevicePtrs own = gh_dev_own(ctx);
   GH_CHECK(ctx, hipMemsetAsync(D->topcell, 0, sizeof(int)*(size_t) pn, s));
   GH_CHECK(ctx, hipMemsetAsync(D->spl_fail, 0, sizeof(int), s));
+  // test hook: GH_DD_WINSCALE=0 empties every window, so each step's speculative attempt misses its medians and the
+  // collective fallback to the exact search runs (test_speculative_splits_fall_back_collectively)
+  const double winscale = getenv("GH_DD_WINSCALE") ? atof(getenv("GH_DD_WINSCALE")) : 1.0;
   for (int l = 0; l < L; l++) {
     const int nc = 1 << l;
     const size_t stride = DD_WHDR + (size_t) nc*(1 + DD_WCAP);
     hipLaunchKernelGGL(k_dd_win_init, dim3(1), dim3(64), 0, s, D->cells, D->wins, l, ctx->dbbmin, ctx->dbbmax, ctx->cN, ctx->ndim,
-                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail);
+                       D->spl_prev, D->spl_win, D->spl_kd, D->spl_fail, winscale);
     GH_CHECK(ctx, hipMemsetAsync(D->wnd, 0, sizeof(DDCand)*stride, s));
     if (l == 0) hipLaunchKernelGGL(k_dd_win_box, dim3(1), dim3(64), 0, s, ctx->dbbmin, ctx->dbbmax, D->wnd);   // this rank's extent (gh_rootbox_local)
     hipLaunchKernelGGL(k_dd_window, dim3(nb), dim3(256), 0, s, own, D->topcell, D->wins, nc, D->wnd, D->spl_fail);

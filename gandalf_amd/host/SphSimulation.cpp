@@ -90,7 +90,7 @@ void SphSimulation::ProcessParameters()
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   // neib_search = octtree: the reference's own OctTree::BuildTree never sets the root cell's box (OctTree.cpp:253-263 compute
   // bbmin / bbmax, :285-288 read the unset celldata[0].bb) and stops with "Error : reached maximum oct-tree level"
-  // (:425-428) on every gradhsph IC tried - there is no reference behaviour to reproduce (tests/test_oracle.py pins that)
+  // (:425-428) on every gradhsph IC tried - there is no reference behaviour to reproduce (pinned by a test that runs the compiled reference)
   if (sp["neib_search"] == "octtree")
     throw GandalfError("neib_search = octtree : not available (the reference's oct-tree build fails for sim = gradhsph, see DESIGN.md section 6); use kdtree");
   if (sp["neib_search"] != "kdtree") throw GandalfError("Unrecognised parameter : neib_search = " + sp["neib_search"]);

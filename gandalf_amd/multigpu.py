@@ -197,6 +197,15 @@ class DistributedRunner:
         self.dev = None
 
     def setup(self):
+        if self.transport == "rccl":
+            # RCCL cannot be loaded at all (no librccl on this host): every rank sees the same and takes the torch transport
+            # instead - decided before the first collective, so no rank waits for another
+            from . import capi
+            err = capi.load_library().gh_rccl_load_error()
+            if err:
+                import sys
+                sys.stderr.write("gandalf_amd: native RCCL transport unavailable (%s): using torch.distributed\n" % err.decode())
+                self.transport = "torch"
         if self.world > 1 or self.transport == "rccl":
             self.ops = RcclOps(self.rank, self.world, self.device) if self.transport == "rccl" else CommOps("device")
         if self.world > 1:

@@ -163,6 +163,17 @@ def test_ranks_hold_only_their_share(tmp_path):
             assert _relerr(a, b) <= 1e-13, k
 
 
+def test_speculative_splits_fall_back_collectively(tmp_path, monkeypatch):
+    """The one-collective-per-level median search (windows around last step's medians) must hand over to the exact search
+    whenever a window misses - on all ranks together.  GH_DD_WINSCALE=0 empties every window, so every step after the first
+    takes: speculative attempt -> status word in the migration counts -> exact search; results as ever."""
+    one = _run(tmp_path, "plummer_4k", 1, 3, {})
+    monkeypatch.setenv("GH_DD_WINSCALE", "0")
+    many = _run(tmp_path, "plummer_4k", 4, 3, {})
+    for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot"):
+        assert _relerr(one[k], many[k]) <= 1e-13, (k, _relerr(one[k], many[k]))
+
+
 def test_lattice_ties_are_refused_on_more_than_one_rank(tmp_path):
     """16^3 cubic lattice (equal coordinates at every median): one rank rebuilds the tree with the reference's own
     quick-select tie order (lattice3d_cubic_grav fixture); across ranks the shared top levels order ties by particle id,
