@@ -102,6 +102,10 @@ struct gh_dd {
   long long held_particles = 0;      // own + imported (last force-phase exchange): what this rank actually holds
   double dt_local[2];
   double *dt_all = nullptr;
+  // gh_dd_gatherv: ragged all-gather of small host-bound records (sink runs)
+  char *gv_send = nullptr, *gv_recv = nullptr; size_t gv_send_bytes = 0, gv_recv_bytes = 0;
+  long long *gv_cnt = nullptr;       // [1 + nranks] device
+  int alloc_gtot = 0, alloc_lgroup = 0; size_t alloc_n = 0;            // what the buffers below were sized for (sink runs: N shrinks)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -476,14 +480,26 @@ __global__ void k_mig_pack(MigTab t, const int *iorig, int n, const int *dest, i
   o[t.nf] = (double) iorig[i];
 }
 
-__global__ void k_mig_unpack(MigTab t, int *iorig, int narr, const int *hole, const double *recv)
+// arrival e takes the place of leaver e; arrivals beyond the leavers (a sink run after accretion elsewhere: this rank's
+// cell grew) line up behind the particles held so far
+__global__ void k_mig_unpack(MigTab t, int *iorig, int narr, const int *hole, const double *recv, int nholes, int held)
 {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= narr) return;
-  const int i = hole[e];
+  const int i = e < nholes ? hole[e] : held + (e - nholes);
   const double *o = recv + (size_t) e*(t.nf + 1);
   for (int f = 0; f < t.nf; f++) t.fld[f][i] = o[f];
   iorig[i] = (int) o[t.nf];
+}
+
+// fewer arrivals than leavers: the particles behind the new end move into the holes that stayed open
+__global__ void k_mig_move(MigTab t, int *iorig, const int *from, const int *to, int n)
+{
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int a = from[e], b = to[e];
+  for (int f = 0; f < t.nf; f++) t.fld[f][b] = t.fld[f][a];
+  iorig[b] = iorig[a];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(256) void k_let_compact(int L, int self, const unsi
 }
 
 // record sizes in doubles: cell = id + the records of the phase; leaf = id + occ x particle record
-struct LetLayout { int cell_dbl, part_dbl, leaf_dbl, occ, phase, quad, lev; };     // lev: force records end with the particle's timestep level
+struct LetLayout { int cell_dbl, part_dbl, leaf_dbl, occ, phase, quad, lev, gpot; };     // lev: force records end with the particle's timestep level; gpot: density records end with last step's potential (sink search)
 
 // pack / unpack: a thread moves ONE double of one record (cell records: up to 34 doubles; leaf records: id + occ particle
 // records), so that consecutive threads touch consecutive words of the message and of the 32-byte packs
@@ -877,7 +893,7 @@ __global__ __launch_bounds__(256) void k_let_pack(DevicePtrs d, LetLayout lay, i
       else {
         const int t = (w - 1)/lay.part_dbl, k = (w - 1) - t*lay.part_dbl;
         const int first = d.cfirst[n], cn = d.cN[n];
-        if (t < cn) val = k < 4 ? ((const double*) &d.posm[first + t])[k] : (k < 20 ? ((const double*) &d.hrec[4*(size_t) (first + t)])[k - 4] : d.f[D_LEVEL][first + t]);
+        if (t < cn) val = k < 4 ? ((const double*) &d.posm[first + t])[k] : (lay.gpot ? d.f[D_GPOT][first + t] : (k < 20 ? ((const double*) &d.hrec[4*(size_t) (first + t)])[k - 4] : d.f[D_LEVEL][first + t]));
       }
       base[e] = val;
     }
@@ -907,6 +923,7 @@ __global__ __launch_bounds__(256) void k_let_unpack(DevicePtrs d, LetLayout lay,
       const int first = d.cfirst[n], cn = d.cN[n];
       if (t < cn) {
         if (k < 4) ((double*) &d.posm[first + t])[k] = base[e];
+        else if (lay.gpot) d.f[D_GPOT][first + t] = base[e];             // the potential-minimum test reads the neighbours' potential of the last force pass (GradhSph.cpp:270-280)
         else if (k < 20) {
           ((double*) &d.hrec[4*(size_t) (first + t)])[k - 4] = base[e];
           if (k == 4 + 7) d.f[D_HRANGESQD][first + t] = base[e];        // hrangesqd: the candidate classification of k_grav_eval reads the SoA array
@@ -954,7 +971,6 @@ extern "C" int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops
     for (int k = 0; k < ctx->ndim; k++)
       ok = ok && c.boundary_lhs[k] == c.boundary_rhs[k] && (c.boundary_lhs[k] == GH_BOUNDARY_OPEN || c.boundary_lhs[k] == GH_BOUNDARY_PERIODIC);
     if (!ok) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: open or periodic boundaries only");
-    if (c.sink_particles) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: no sink particles (gas only; global or block timesteps)");
     if (c.Nlevels > 1 && c.sph_single_timestep) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: block timesteps without sph_single_timestep");
     if (c.self_gravity && c.gravity_mac != GH_MAC_GEOMETRIC) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: gravity_mac = geometric only");
     if (c.avisc == GH_AVISC_MON97CD2010 || c.avisc == GH_AVISC_MON97MM97) return gh_fail(ctx, GH_ERR_UNSUPPORTED, "multi-GPU runs: no time-dependent viscosity");
@@ -966,15 +982,28 @@ extern "C" int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops
   return GH_OK;
 }
 
+// the buffers dd_alloc sizes by the tree (released when a sink run's shrinking N changes the tree's depth)
+static void dd_release(gh_dd *D)
+{
+  void **ptrs[] = {(void**) &D->topcell, (void**) &D->cells, (void**) &D->hist, (void**) &D->hist_all, (void**) &D->cand, (void**) &D->cand_all, (void**) &D->box6,
+                   (void**) &D->box6_all, (void**) &D->mig_cnt, (void**) &D->mig_slot, (void**) &D->mig_hole, (void**) &D->mig_send, (void**) &D->mig_recv,
+                   (void**) &D->pub_send, (void**) &D->pub_recv, (void**) &D->comb_send, (void**) &D->comb_recv, (void**) &D->fine, (void**) &D->fine_all,
+                   (void**) &D->let_cnt, (void**) &D->let_off, (void**) &D->let_cells, (void**) &D->let_leaves, (void**) &D->ln_roff, (void**) &D->dt_all,
+                   (void**) &D->let_vis, (void**) &D->let_work, (void**) &D->spl_prev, (void**) &D->spl_win, (void**) &D->spl_kd, (void**) &D->wins,
+                   (void**) &D->wnd, (void**) &D->wnd_all};
+  for (void **p : ptrs) { if (*p) (void) hipFree(*p); *p = nullptr; }
+  D->spl_fail = nullptr;
+  for (void **p : {(void**) &D->h_cnt, (void**) &D->h_off, (void**) &D->h_all}) { if (*p) (void) hipHostFree(*p); *p = nullptr; }
+  D->have_splits = false;
+}
+
 void gh_dd_free(gh_ctx *ctx)
 {
   gh_dd *D = ctx->dd;
   if (!D) return;
-  void *ptrs[] = {D->topcell, D->cells, D->hist, D->hist_all, D->cand, D->cand_all, D->box6, D->box6_all, D->mig_cnt, D->mig_slot,
-                  D->mig_hole, D->mig_send, D->mig_recv, D->pub_send, D->pub_recv, D->comb_send, D->comb_recv, D->fine, D->fine_all, D->let_cnt, D->let_off, D->let_cells, D->let_leaves,
-                  D->let_send, D->let_recv, D->ln_send, D->ln_recv, D->ln_roff, D->dt_all, D->let_vis, D->let_work, D->spl_prev, D->spl_win, D->spl_kd, D->wins, D->wnd, D->wnd_all};
+  dd_release(D);
+  void *ptrs[] = {D->let_send, D->let_recv, D->ln_send, D->ln_recv, D->gv_send, D->gv_recv, D->gv_cnt};
   for (void *p : ptrs) if (p) (void) hipFree(p);
-  for (void *p : {(void*) D->h_cnt, (void*) D->h_off, (void*) D->h_all}) if (p) (void) hipHostFree(p);
   delete D;
   ctx->dd = nullptr;
 }
@@ -982,9 +1011,11 @@ void gh_dd_free(gh_ctx *ctx)
 static int dd_alloc(gh_ctx *ctx)
 {
   gh_dd *D = ctx->dd;
-  if (D->topcell) return GH_OK;
+  const size_t n = (size_t) std::max(ctx->own_count, ctx->own_held) + 1;
+  if (D->topcell && D->alloc_gtot == ctx->gtot && D->alloc_lgroup == ctx->lgroup && D->alloc_n >= n) return GH_OK;
+  if (D->topcell) { GH_CHECK(ctx, hipStreamSynchronize(ctx->stream)); dd_release(D); }
+  D->alloc_gtot = ctx->gtot; D->alloc_lgroup = ctx->lgroup; D->alloc_n = n;
   const int W = ctx->nranks, half = std::max(W/2, 1);
-  const size_t n = (size_t) ctx->own_count + 1;
   D->P = std::min(DD_PMAX, ctx->lgroup - ctx->L);
   GH_CHECK(ctx, hipMalloc((void**) &D->topcell, sizeof(int)*n));
   GH_CHECK(ctx, hipMalloc((void**) &D->cells, sizeof(DDCell)*W));
@@ -1043,9 +1074,10 @@ static int dd_levels_exact(gh_ctx *ctx)
   gh_dd *D = ctx->dd;
   const int W = ctx->nranks, L = ctx->L;
   hipStream_t s = ctx->stream;
-  const int pn = (int) ctx->own_count;
-  const int nb = cdiv(pn, 256);
+  const int pn = (int) (ctx->own_held >= 0 ? ctx->own_held : ctx->own_count);
+  const int nb = cdiv(std::max(pn, 1), 256);
   DevicePtrs own = gh_dev_own(ctx);
+  own.N = pn;
   // global root box
   hipLaunchKernelGGL(k_dd_box_pack, dim3(1), dim3(64), 0, s, ctx->dbbmin, ctx->dbbmax, D->box6);
   DD_OP(ctx, dd_allgather(ctx, D->box6, D->box6_all, sizeof(double)*6));
@@ -1077,9 +1109,10 @@ static int dd_levels_speculative(gh_ctx *ctx)
   gh_dd *D = ctx->dd;
   const int W = ctx->nranks, L = ctx->L;
   hipStream_t s = ctx->stream;
-  const int pn = (int) ctx->own_count;
-  const int nb = cdiv(pn, 256);
+  const int pn = (int) (ctx->own_held >= 0 ? ctx->own_held : ctx->own_count);
+  const int nb = cdiv(std::max(pn, 1), 256);
   DevicePtrs own = gh_dev_own(ctx);
+  own.N = pn;
   GH_CHECK(ctx, hipMemsetAsync(D->topcell, 0, sizeof(int)*(size_t) pn, s));
   GH_CHECK(ctx, hipMemsetAsync(D->spl_fail, 0, sizeof(int), s));
   // test hook: GH_DD_WINSCALE=0 empties every window, so each step's speculative attempt misses its medians and the
@@ -1101,7 +1134,7 @@ static int dd_levels_speculative(gh_ctx *ctx)
   return GH_OK;
 }
 
-__global__ void k_mig_status(int *mig_cnt, const int *fail) { mig_cnt[GH_MAX_RANKS] = fail ? *fail : 0; }
+__global__ void k_mig_status(int *mig_cnt, const int *fail, int held) { mig_cnt[GH_MAX_RANKS] = fail ? *fail : 0; mig_cnt[GH_MAX_RANKS + 1] = held; }
 
 int gh_dd_decompose(gh_ctx *ctx)
 {
@@ -1111,14 +1144,18 @@ int gh_dd_decompose(gh_ctx *ctx)
   if (rc) return rc;
   const int W = ctx->nranks, L = ctx->L;
   hipStream_t s = ctx->stream;
-  const int pn = (int) ctx->own_count;
-  const int nb = cdiv(pn, 256);
+  // the particles this rank holds: its cell's static count, except right after a sink run removed accreted particles
+  // (gh_sinks_delete_dead): then every cell's count follows the new N and the migration below evens the ranks out
+  const int pn = (int) (ctx->own_held >= 0 ? ctx->own_held : ctx->own_count);
+  const int nb = cdiv(std::max(pn, 1), 256);
   DevicePtrs own = gh_dev_own(ctx);
+  own.N = pn;
 
   // this rank's extent of r -/+ kernrange*h; every own particle starts in this rank's cell
   gh_rootbox_local(ctx, (1 << L) - 1 + ctx->rank);
   bool spec = D->have_splits && !getenv("GH_DD_EXACT");
-  std::vector<int> all((size_t) W*(GH_MAX_RANKS + 1));
+  const int CWM = GH_MAX_RANKS + 2;                         // leavers per destination, status word, particles held
+  std::vector<int> all((size_t) W*CWM);
   for (;;) {
     if ((rc = spec ? dd_levels_speculative(ctx) : dd_levels_exact(ctx))) return rc;
     // migration: topcell is now the destination rank.  Leavers per destination -> every rank learns its arrivals per
@@ -1126,41 +1163,66 @@ int gh_dd_decompose(gh_ctx *ctx)
     // gathered data only - the OR over the ranks below is belt and braces)
     GH_CHECK(ctx, hipMemsetAsync(D->mig_cnt, 0, sizeof(int)*4*GH_MAX_RANKS, s));
     hipLaunchKernelGGL(k_mig_count, dim3(nb), dim3(256), 0, s, pn, D->topcell, ctx->rank, D->mig_cnt, D->mig_slot, D->mig_hole);
-    hipLaunchKernelGGL(k_mig_status, dim3(1), dim3(1), 0, s, D->mig_cnt, spec ? D->spl_fail : nullptr);
-    DD_OP(ctx, dd_allgather(ctx, D->mig_cnt, D->hist_all, sizeof(int)*(GH_MAX_RANKS + 1)));
+    hipLaunchKernelGGL(k_mig_status, dim3(1), dim3(1), 0, s, D->mig_cnt, spec ? D->spl_fail : nullptr, pn);
+    DD_OP(ctx, dd_allgather(ctx, D->mig_cnt, D->hist_all, sizeof(int)*CWM));
     GH_CHECK(ctx, hipMemcpyAsync(all.data(), D->hist_all, sizeof(int)*all.size(), hipMemcpyDeviceToHost, s));
     GH_CHECK(ctx, hipStreamSynchronize(s));
     int failed = 0;
-    for (int r = 0; r < W; r++) failed |= all[(size_t) r*(GH_MAX_RANKS + 1) + GH_MAX_RANKS];
+    for (int r = 0; r < W; r++) failed |= all[(size_t) r*CWM + GH_MAX_RANKS];
     if (spec && failed) { spec = false; continue; }       // collective decision: every rank sees the same words
     break;
   }
   if (spec) D->n_spec++; else D->n_exact++;
   D->have_splits = true;
+  if (getenv("GH_DD_DEBUG")) {
+    fprintf(stderr, "[dd] rank %d held %d cell count %d spec %d:", ctx->rank, pn, ctx->h_cN[(1 << L) - 1 + ctx->rank], (int) spec);
+    for (int r = 0; r < W; r++) fprintf(stderr, " ->%d: %d <-%d: %d", r, all[(size_t) ctx->rank*CWM + r], r, all[(size_t) r*CWM + ctx->rank]);
+    fprintf(stderr, "\n");
+  }
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   MigTab tab;
-  tab.nf = ctx->cfg.Nlevels > 1 ? D_COUNT : D_COUNT_BASE;       // block timesteps: level, levelneib, nstep, nlast, flags (and sinkid) travel too
+  // block timesteps: level, levelneib, nstep, nlast, flags travel too; sink runs: sinkid and the flags (dead, potmin)
+  tab.nf = (ctx->cfg.Nlevels > 1 || ctx->cfg.sink_particles) ? D_COUNT : D_COUNT_BASE;
   const int nrec = tab.nf + 1;
   long long nsend = 0, nrecv = 0;
   for (int r = 0; r < W; r++) {
-    const int out = all[(size_t) ctx->rank*(GH_MAX_RANKS + 1) + r], in = all[(size_t) r*(GH_MAX_RANKS + 1) + ctx->rank];
+    const int out = all[(size_t) ctx->rank*CWM + r], in = all[(size_t) r*CWM + ctx->rank];
     tab.off[r] = (int) nsend;
     sb[r] = (int64_t) out*nrec*sizeof(double); rb[r] = (int64_t) in*nrec*sizeof(double);
     nsend += out; nrecv += in;
   }
-  // every rank's particle count is static, so leavers and arrivals balance on EVERY rank or on none: a split that left a
-  // cell with the wrong count (equal coordinates beyond DD_CAPL) shows up on all ranks, and all of them stop here together
+  // every rank must end up with its cell's count: held - leavers + arrivals = cN on EVERY rank or on none - a split that
+  // left a cell with the wrong count (equal coordinates beyond DD_CAPL) shows up on all ranks, and all of them stop here together
   bool unbalanced = false;
   for (int r = 0; r < W; r++) {
     long long o = 0, in = 0;
-    for (int q = 0; q < W; q++) { o += all[(size_t) r*(GH_MAX_RANKS + 1) + q]; in += all[(size_t) q*(GH_MAX_RANKS + 1) + r]; }
-    if (o != in) unbalanced = true;
+    for (int q = 0; q < W; q++) { o += all[(size_t) r*CWM + q]; in += all[(size_t) q*CWM + r]; }
+    if ((long long) all[(size_t) r*CWM + GH_MAX_RANKS + 1] - o + in != (long long) ctx->h_cN[(1 << L) - 1 + r]) unbalanced = true;
   }
   if (unbalanced) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: unbalanced migration (equal coordinates at a top-level split?)");
   for (int f = 0; f < tab.nf; f++) tab.fld[f] = own.f[f];
   if (nsend > 0) hipLaunchKernelGGL(k_mig_pack, dim3(nb), dim3(256), 0, s, tab, own.iorig, pn, D->topcell, ctx->rank, D->mig_slot, D->mig_send);
   DD_OP(ctx, D->ops.alltoallv(D->ops.user, D->mig_send, sb, D->mig_recv, rb, (void*) s));     // collective: every rank calls it
-  if (nrecv > 0) hipLaunchKernelGGL(k_mig_unpack, dim3(cdiv(nrecv, 256)), dim3(256), 0, s, tab, own.iorig, (int) nrecv, D->mig_hole, D->mig_recv);
+  if (nrecv > 0) hipLaunchKernelGGL(k_mig_unpack, dim3(cdiv(nrecv, 256)), dim3(256), 0, s, tab, own.iorig, (int) nrecv, D->mig_hole, D->mig_recv, (int) nsend, pn);
+  if (nsend > nrecv) {
+    // holes nrecv .. nsend stayed open: the new end is pn - (nsend - nrecv); what lies behind it moves into the open holes before it
+    const int nopen = (int) (nsend - nrecv), target = pn - nopen;
+    std::vector<int> open((size_t) nopen), from, to;
+    GH_CHECK(ctx, hipMemcpyAsync(open.data(), D->mig_hole + nrecv, sizeof(int)*(size_t) nopen, hipMemcpyDeviceToHost, s));
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    std::sort(open.begin(), open.end());
+    for (int q : open) if (q < target) to.push_back(q);
+    for (int q = target; q < pn; q++) if (!std::binary_search(open.begin(), open.end(), q)) from.push_back(q);
+    if (from.size() != to.size()) return gh_fail(ctx, GH_ERR_INVALID, "multi-GPU: migration bookkeeping out of step");
+    if (!from.empty()) {
+      // (topcell / mig_slot have done their work: scratch for the two index lists)
+      GH_CHECK(ctx, hipMemcpyAsync(D->topcell, from.data(), sizeof(int)*from.size(), hipMemcpyHostToDevice, s));
+      GH_CHECK(ctx, hipMemcpyAsync(D->mig_slot, to.data(), sizeof(int)*to.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_mig_move, dim3(cdiv(from.size(), 256)), dim3(256), 0, s, tab, own.iorig, D->topcell, D->mig_slot, (int) from.size());
+      GH_CHECK(ctx, hipStreamSynchronize(s));              // from / to live on this stack
+    }
+  }
+  ctx->own_held = -1;
   D->migrated = nsend;
   GH_CHECK(ctx, hipGetLastError());
   return GH_OK;
@@ -1278,7 +1340,8 @@ int gh_dd_exchange_margin(gh_ctx *ctx, int phase, double widen)
   lay.phase = phase; lay.quad = ctx->cquad ? 1 : 0; lay.occ = ctx->leafocc;
   lay.cell_dbl = phase == GH_HALO_DENSITY ? 9 : (lay.quad ? 34 : 29);
   lay.lev = (phase != GH_HALO_DENSITY && ctx->cfg.Nlevels > 1) ? 1 : 0;
-  lay.part_dbl = phase == GH_HALO_DENSITY ? 4 : 20 + lay.lev;
+  lay.gpot = (phase == GH_HALO_DENSITY && ctx->cfg.sink_particles && ctx->cfg.create_sinks == 1) ? 1 : 0;
+  lay.part_dbl = phase == GH_HALO_DENSITY ? 4 + lay.gpot : 20 + lay.lev;
   lay.leaf_dbl = 1 + lay.occ*lay.part_dbl;
   int64_t sb[GH_MAX_RANKS], rb[GH_MAX_RANKS];
   long long soff[GH_MAX_RANKS], roff[GH_MAX_RANKS], stot = 0, rtot = 0, nimp = 0;
@@ -1441,6 +1504,54 @@ int gh_dd_return_levelneib(gh_ctx *ctx)
   hipLaunchKernelGGL(k_ln_merge, dim3(256, W), dim3(256), 0, s, d, ctx->rank, D->let_cnt, D->let_leaves, D->let_leafcap, occ,
                      d_offs + GH_MAX_RANKS, (const double*) D->ln_recv);
   GH_CHECK(ctx, hipGetLastError());
+  return GH_OK;
+}
+
+// ragged all-gather of small records to the hosts of all ranks (sink runs: dead slots, sink candidates, the rows of the
+// gas inside the sink radii - what the reference moves with MPI_Allgatherv / MPI_Bcast in Sinks.cpp and MpiControl.cpp).
+// `src` may be device or host memory; out = the ranks' blocks in rank order, sizes[r] = bytes of rank r.  Two all-gathers:
+// the sizes, then blocks padded to the largest.  One rank: a plain copy.
+int gh_dd_gatherv(gh_ctx *ctx, const void *src, size_t bytes, std::vector<char> &out, std::vector<size_t> &sizes)
+{
+  const int W = ctx->nranks;
+  hipStream_t s = ctx->stream;
+  sizes.assign((size_t) W, 0);
+  if (W == 1) {
+    out.resize(bytes); sizes[0] = bytes;
+    if (bytes) GH_CHECK(ctx, hipMemcpyAsync(out.data(), src, bytes, hipMemcpyDefault, s));
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    return GH_OK;
+  }
+  gh_dd *D = ctx->dd;
+  if (!D->gv_cnt) GH_CHECK(ctx, hipMalloc((void**) &D->gv_cnt, sizeof(long long)*(GH_MAX_RANKS + 1)));
+  long long mine = (long long) bytes;
+  std::vector<long long> cnt((size_t) W);
+  GH_CHECK(ctx, hipMemcpyAsync(D->gv_cnt, &mine, sizeof(long long), hipMemcpyHostToDevice, s));
+  DD_OP(ctx, dd_allgather(ctx, D->gv_cnt, D->gv_cnt + 1, sizeof(long long)));
+  GH_CHECK(ctx, hipMemcpyAsync(cnt.data(), D->gv_cnt + 1, sizeof(long long)*(size_t) W, hipMemcpyDeviceToHost, s));
+  GH_CHECK(ctx, hipStreamSynchronize(s));
+  size_t mx = 0, tot = 0;
+  for (int r = 0; r < W; r++) { sizes[r] = (size_t) cnt[r]; mx = std::max(mx, sizes[r]); tot += sizes[r]; }
+  out.resize(tot);
+  if (mx == 0) return GH_OK;
+  mx = (mx + 15) & ~(size_t) 15;
+  auto grow = [&](char **p, size_t *have, size_t need) -> hipError_t {
+    if (need <= *have) return hipSuccess;
+    if (*p) (void) hipFree(*p);
+    *p = nullptr; *have = 0;
+    const hipError_t e = hipMalloc((void**) p, need + need/2 + 4096);
+    if (e == hipSuccess) *have = need + need/2 + 4096;
+    return e;
+  };
+  GH_CHECK(ctx, grow(&D->gv_send, &D->gv_send_bytes, mx));
+  GH_CHECK(ctx, grow(&D->gv_recv, &D->gv_recv_bytes, mx*(size_t) W));
+  if (bytes) GH_CHECK(ctx, hipMemcpyAsync(D->gv_send, src, bytes, hipMemcpyDefault, s));
+  DD_OP(ctx, dd_allgather(ctx, D->gv_send, D->gv_recv, mx));
+  std::vector<char> pad(mx*(size_t) W);
+  GH_CHECK(ctx, hipMemcpyAsync(pad.data(), D->gv_recv, pad.size(), hipMemcpyDeviceToHost, s));
+  GH_CHECK(ctx, hipStreamSynchronize(s));
+  size_t o = 0;
+  for (int r = 0; r < W; r++) { if (sizes[r]) memcpy(out.data() + o, pad.data() + (size_t) r*mx, sizes[r]); o += sizes[r]; }
   return GH_OK;
 }
 

@@ -204,6 +204,7 @@ struct gh_ctx {
   // [own_first, own_first + own_count) of the global tree-order index space; everything when nranks == 1
   int rank = 0, nranks = 1, L = 0;
   int64_t own_first = 0, own_count = 0;
+  int64_t own_held = -1;           // sink runs on several ranks: particles in the own range after dead ones left, until the next migration evens the ranks out (-1: own_count)
   int iota_p0 = -1;
   bool in_step = false;            // inside gh_step's global-timestep loop: the tree build may skip arrays the step rewrites anyway
   bool tree_valid_once = false;    // gh_build_tree_scheduled: a tree has been built for the current particle set
@@ -311,6 +312,7 @@ int gh_force_halo(gh_ctx *ctx, int phase);     // forces.hip: force records of t
 int gh_dd_any(gh_ctx *ctx, const unsigned int *count_dev, int *any);   // any rank's counter non-zero? (collective, synchronises)
 int gh_dd_min_dt(gh_ctx *ctx);                 // time[1] = min over ranks
 int gh_dd_reduce_int(gh_ctx *ctx, int *word_dev, int op);   // one device word: 0 = max, 1 = sum over ranks (block clock)
+int gh_dd_gatherv(gh_ctx *ctx, const void *src, size_t bytes, std::vector<char> &out, std::vector<size_t> &sizes);   // ragged all-gather to the hosts (sink runs)
 int gh_dd_return_levelneib(gh_ctx *ctx);       // block timesteps: levelneib raised on imported copies -> max at their owners
 void gh_dd_free(gh_ctx *ctx);
 // sinks.hip

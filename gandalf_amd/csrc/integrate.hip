@@ -425,6 +425,7 @@ int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult)
     const int nblk = 256;
     hipLaunchKernelGGL(k_timestep_partial, dim3(nblk), dim3(GH_TS_THREADS), 0, s, d, fill_tp(ctx), ctx->redbuf);
     hipLaunchKernelGGL(k_timestep_final, dim3(1), dim3(256), 0, s, ctx->redbuf, nblk, time);
+    { const int rc = gh_dd_min_dt(ctx); if (rc) return rc; }            // several ranks: the gas minimum of all of them (the stars are everybody's)
     GH_CHECK(ctx, hipMemcpyAsync(tt, time, sizeof(tt), hipMemcpyDeviceToHost, s));
     GH_CHECK(ctx, hipStreamSynchronize(s));
     const double dt_min_hydro = tt[1];
@@ -448,6 +449,7 @@ int gh_block_timesteps_hybrid(gh_ctx *ctx, gh_host_stars &S, double nbody_mult)
     return GH_OK;
   }
   hipLaunchKernelGGL(k_block_levels, dim3(nb), dim3(256), 0, s, d, fill_tp(ctx), ctx->d_blk, time, ctx->cfg.level_diff_max);
+  { const int rc = gh_dd_reduce_int(ctx, ctx->d_blk + B_LMAXNEW, 0); if (rc) return rc; }     // highest occupied gas level of all ranks
   GH_CHECK(ctx, hipMemcpyAsync(blk, ctx->d_blk, sizeof(blk), hipMemcpyDeviceToHost, s));
   GH_CHECK(ctx, hipMemcpyAsync(tt, time, sizeof(tt), hipMemcpyDeviceToHost, s));
   GH_CHECK(ctx, hipStreamSynchronize(s));

@@ -33,24 +33,30 @@
 // tree order (GradhSphTree.cpp:200-219), hmax being the cell's 1.05^k hmax of the successful ComputeH call.  The flag is
 // cleared if some neighbour j has gpot_j > 1.000000001 gpot_i while the distance of the neighbour BEFORE it in the list
 // (for j = 0: of the last one) lies inside kernrange*h of the last h iteration.
-__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd);
-__global__ void k_potmin(DevicePtrs d, double rho_sink, double kernrangesqd)
+//
+// Several ranks: the candidates are this rank's own particles [p0, p0 + pn); their neighbours may be imported copies, of
+// which the density-phase halo carries position, mass and - in sink-creating runs - last force pass's potential (comm.hip,
+// LetLayout::gpot), so positions are read from the (x, y, z, m) pack everywhere.  The cells this test opens are among those
+// the particle's own density walk opened (its cull radius is that walk's), so they were imported; one that was not raises
+// FLAG_LET_MISS like in every other walk.
+__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd, int *flags);
+__global__ void k_potmin(DevicePtrs d, double rho_sink, double kernrangesqd, int p0, int pn, int *flags)
 {
-  const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= d.N) return;
+  const int i = p0 + blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= p0 + pn) return;
   const int fl = (int) d.f[D_FLAGS][i];
   if (fl & GH_FLAG_DEAD) return;
   if (d.levels && !(fl & GH_FLAG_ACTIVE)) return;
   if (!(d.f[D_RHO][i] >= rho_sink)) return;
-  potmin_serial(d, i, kernrangesqd);
+  potmin_serial(d, i, kernrangesqd, flags);
 }
-__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd)
+__device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd, int *flags)
 {
   const int fl = (int) d.f[D_FLAGS][i];
   const double cull = d.pm_cullsqd[i], invhsqd = d.pm_invhsqd[i];
   const double thr = 1.000000001*d.f[D_GPOT][i];
-  double ri[3] = {0.0, 0.0, 0.0};
-  for (int k = 0; k < d.ndim; k++) ri[k] = d.f[D_RX + k][i];
+  const double4 pi4 = d.posm[i];
+  const double ri[3] = {pi4.x, pi4.y, pi4.z};
   int stack[40];
   int sp = 0;
   stack[sp++] = 0;
@@ -60,6 +66,7 @@ __device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd)
   while (sp > 0) {
     const int n = stack[--sp];
     const CellBox b = d.cbox[n];
+    if (b.N < 0) atomicOr(flags, FLAG_LET_MISS);
     if (b.N <= 0) continue;
     double md = 0.0;
     for (int k = 0; k < d.ndim; k++) {
@@ -70,8 +77,10 @@ __device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd)
     if (n >= leaf0) {
       for (int t = 0; t < b.N; t++) {
         const int j = b.first + t;
+        const double4 pj = d.posm[j];
+        const double rj[3] = {pj.x, pj.y, pj.z};
         double d2 = 0.0;
-        for (int k = 0; k < d.ndim; k++) { const double dx = d.f[D_RX + k][j] - ri[k]; d2 += dx*dx; }
+        for (int k = 0; k < d.ndim; k++) { const double dx = rj[k] - ri[k]; d2 += dx*dx; }
         if (!(d2 + SK_SMALL <= cull)) continue;
         const double gj = d.f[D_GPOT][j];
         if (!have_first) { have_first = true; g_first = gj; }
@@ -93,10 +102,10 @@ __device__ void potmin_serial(const DevicePtrs &d, int i, double kernrangesqd)
 // one of the previous chunk.  Same arithmetic, same decisions; a particle whose frontier outgrows the LDS list is left
 // to the serial kernel (mask).
 #define PM_CAP 1536
-__global__ void k_potmin_collect(DevicePtrs d, double rho_sink, int *list, int *count)
+__global__ void k_potmin_collect(DevicePtrs d, double rho_sink, int *list, int *count, int p0, int pn)
 {
-  const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i >= d.N) return;
+  const int i = p0 + blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= p0 + pn) return;
   const int fl = (int) d.f[D_FLAGS][i];
   if (fl & GH_FLAG_DEAD) return;
   if (d.levels && !(fl & GH_FLAG_ACTIVE)) return;
@@ -104,7 +113,7 @@ __global__ void k_potmin_collect(DevicePtrs d, double rho_sink, int *list, int *
   list[atomicAdd(count, 1)] = i;
 }
 
-__global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernrangesqd, const int *list, const int *count, int *redo, int *nredo)
+__global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernrangesqd, const int *list, const int *count, int *redo, int *nredo, int *flags)
 {
   __shared__ int s_a[PM_CAP], s_b[PM_CAP];
   const int lane = threadIdx.x;
@@ -116,8 +125,8 @@ __global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernran
     const int fl = (int) d.f[D_FLAGS][i];
     const double cull = d.pm_cullsqd[i], invhsqd = d.pm_invhsqd[i];
     const double thr = 1.000000001*d.f[D_GPOT][i];
-    double ri[3] = {0.0, 0.0, 0.0};
-    for (int k = 0; k < d.ndim; k++) ri[k] = d.f[D_RX + k][i];
+    const double4 pi4 = d.posm[i];
+    const double ri[3] = {pi4.x, pi4.y, pi4.z};
     int *cur = s_a, *nxt = s_b;
     int ncur = 1;
     bool overflow = false;
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernran
         if (e < ncur) {
           n = cur[e];
           const CellBox b = d.cbox[n];
+          if (b.N < 0) atomicOr(flags, FLAG_LET_MISS);
           if (b.N > 0) {
             double md = 0.0;
             for (int k = 0; k < d.ndim; k++) {
@@ -170,7 +180,9 @@ __global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernran
         const CellBox b = d.cbox[cur[li]];
         if (t < b.N) {
           const int j = b.first + t;
-          for (int k = 0; k < d.ndim; k++) { const double dx = d.f[D_RX + k][j] - ri[k]; d2 += dx*dx; }
+          const double4 pj = d.posm[j];
+          const double rj[3] = {pj.x, pj.y, pj.z};
+          for (int k = 0; k < d.ndim; k++) { const double dx = rj[k] - ri[k]; d2 += dx*dx; }
           acc = d2 + SK_SMALL <= cull;
           gj = d.f[D_GPOT][j];
         }
@@ -195,10 +207,10 @@ __global__ __launch_bounds__(64) void k_potmin_wave(DevicePtrs d, double kernran
 }
 
 // the serial test for the particles the wave kernel left (frontier larger than its list)
-__global__ void k_potmin_redo(DevicePtrs d, double kernrangesqd, const int *redo, const int *nredo)
+__global__ void k_potmin_redo(DevicePtrs d, double kernrangesqd, const int *redo, const int *nredo, int *flags)
 {
   const int n = *nredo;
-  for (int c = blockIdx.x*blockDim.x + threadIdx.x; c < n; c += gridDim.x*blockDim.x) potmin_serial(d, redo[c], kernrangesqd);
+  for (int c = blockIdx.x*blockDim.x + threadIdx.x; c < n; c += gridDim.x*blockDim.x) potmin_serial(d, redo[c], kernrangesqd, flags);
 }
 
 int gh_sinks_potmin(gh_ctx *ctx)
@@ -209,14 +221,15 @@ int gh_sinks_potmin(gh_ctx *ctx)
   int *list = ctx->P[0][0], *redo = ctx->P[0][1], *cnt = ctx->d_blk + 16;
   // k_potmin_wave takes its candidates 8 leaves x 8 slots at a time: leaves wider than 8 particles (Nleafmax up to 32 is
   // accepted) go through the serial kernel, which walks every slot of a leaf
+  const int p0 = (int) ctx->own_first, pn = (int) ctx->own_count;
   if (!list || !redo || ctx->leafocc > 8 || getenv("GH_POTMIN_SERIAL")) {
-    hipLaunchKernelGGL(k_potmin, dim3(cdiv(ctx->N, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, krs);
+    hipLaunchKernelGGL(k_potmin, dim3(cdiv(pn, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, krs, p0, pn, ctx->d_flags);
     return GH_OK;
   }
   GH_CHECK(ctx, hipMemsetAsync(cnt, 0, 2*sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(k_potmin_collect, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, list, cnt);
-  hipLaunchKernelGGL(k_potmin_wave, dim3(8192), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, list, cnt, redo, cnt + 1);
-  hipLaunchKernelGGL(k_potmin_redo, dim3(256), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, redo, cnt + 1);
+  hipLaunchKernelGGL(k_potmin_collect, dim3(cdiv(pn, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), ctx->cfg.rho_sink, list, cnt, p0, pn);
+  hipLaunchKernelGGL(k_potmin_wave, dim3(8192), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, list, cnt, redo, cnt + 1, ctx->d_flags);
+  hipLaunchKernelGGL(k_potmin_redo, dim3(256), dim3(64), 0, ctx->stream, gh_dev(ctx), krs, redo, cnt + 1, ctx->d_flags);
   return GH_OK;
 }
 
@@ -233,40 +246,55 @@ __global__ void k_dead_collect(DevicePtrs d, int *count, int *slots, int *alive)
 }
 
 // stable compaction of every particle array; a survivor whose slot lies beyond the new end takes the hole the
-// reference moves it to (from[] sorted ascending)
+// reference moves it to (from[] sorted ascending).  src_off / dst_off: where this rank's own range starts before and
+// after (several ranks: the ranges follow the new N, see gh_sinks_delete_dead)
 __global__ void k_dead_compact(double **tab, const int *iorig_in, int *iorig_out, const int *alive, const int *newidx, int N,
-                               const int *from, const int *to, int nmove, int nfields)
+                               const int *from, const int *to, int nmove, int nfields, size_t src_off, size_t dst_off)
 {
   const int f = blockIdx.y;
   for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < N; i += gridDim.x*blockDim.x) {
     if (!alive[i]) continue;
     const int o = newidx[i];
-    if (f < nfields) tab[D_COUNT + f][o] = tab[f][i];
+    if (f < nfields) tab[D_COUNT + f][dst_off + o] = tab[f][src_off + i];
     else {
-      int slot = iorig_in[i];
+      int slot = iorig_in[src_off + i];
       int lo = 0, hi = nmove - 1;
       while (lo <= hi) { const int mid = (lo + hi) >> 1; if (from[mid] == slot) { slot = to[mid]; break; } if (from[mid] < slot) lo = mid + 1; else hi = mid - 1; }
-      iorig_out[o] = slot;
+      iorig_out[dst_off + o] = slot;
     }
   }
 }
 
+// Several ranks.  The reference's loop works on ITS array of all particles, whose slots are what `iorig` holds here
+// (caller order, global): every rank gathers every rank's dead slots and runs the same loop, so the survivors' new slots
+// are the single-rank run's.  The new particle count changes every tree cell's count and with it every rank's own range
+// [own_first, own_first + own_count) (gh_alloc_tree): each rank compacts its survivors to the start of its NEW range and
+// reports how many it holds (own_held); the migration of the tree build that follows evens the ranks out to the new cell
+// counts (gh_dd_decompose: arrivals need not equal leavers then).
 int gh_sinks_delete_dead(gh_ctx *ctx)
 {
   if (!ctx->cfg.sink_particles || ctx->N <= 0) return GH_OK;
   const int N = (int) ctx->N;
+  const int pn = (int) ctx->own_count;
+  const size_t old_first = (size_t) ctx->own_first;
   hipStream_t s = ctx->stream;
   int *cnt = ctx->d_blk + 15;
   GH_CHECK(ctx, hipMemsetAsync(cnt, 0, sizeof(int), s));
   // scratch: P[0..2] of the idle build buffers are free between builds
   int *slots = ctx->P[0][0], *alive = ctx->P[0][1], *newidx = ctx->P[0][2];
-  hipLaunchKernelGGL(k_dead_collect, dim3(cdiv(N, 256)), dim3(256), 0, s, gh_dev(ctx), cnt, slots, alive);
-  int ndead = 0;
-  GH_CHECK(ctx, hipMemcpyAsync(&ndead, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_dead_collect, dim3(cdiv(pn, 256)), dim3(256), 0, s, gh_dev_own(ctx), cnt, slots, alive);
+  int nmine = 0;
+  GH_CHECK(ctx, hipMemcpyAsync(&nmine, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
   GH_CHECK(ctx, hipStreamSynchronize(s));
+  std::vector<int> dslots;
+  {
+    std::vector<char> all; std::vector<size_t> sizes;
+    int rc = gh_dd_gatherv(ctx, slots, sizeof(int)*(size_t) nmine, all, sizes);      // (one rank: the copy to the host)
+    if (rc) return rc;
+    dslots.assign((const int*) all.data(), (const int*) all.data() + all.size()/sizeof(int));
+  }
+  const int ndead = (int) dslots.size();
   if (ndead == 0) return GH_OK;
-  std::vector<int> dslots((size_t) ndead);
-  GH_CHECK(ctx, hipMemcpy(dslots.data(), slots, sizeof(int)*(size_t) ndead, hipMemcpyDeviceToHost));
   std::sort(dslots.begin(), dslots.end());
   // the reference's loop, restricted to the slots it acts on (Hydrodynamics.h:171-185): every dead slot i < ilast takes
   // the particle of slot --ilast, again if that one was dead too
@@ -292,25 +320,34 @@ int gh_sinks_delete_dead(gh_ctx *ctx)
   GH_CHECK(ctx, hipMemcpyAsync(d_from, from.data(), sizeof(int)*from.size(), hipMemcpyHostToDevice, s));
   GH_CHECK(ctx, hipMemcpyAsync(d_to, to.data(), sizeof(int)*to.size(), hipMemcpyHostToDevice, s));
   size_t need = 0;
-  GH_CHECK(ctx, rocprim::exclusive_scan(nullptr, need, alive, newidx, 0, (size_t) N, rocprim::plus<int>(), s));
+  GH_CHECK(ctx, rocprim::exclusive_scan(nullptr, need, alive, newidx, 0, (size_t) pn, rocprim::plus<int>(), s));
   if (need > ctx->sorttemp_bytes) {
     if (ctx->sorttemp) (void) hipFree(ctx->sorttemp);
     ctx->sorttemp = nullptr; ctx->sorttemp_bytes = 0;
     GH_CHECK(ctx, hipMalloc(&ctx->sorttemp, need));
     ctx->sorttemp_bytes = need;
   }
-  GH_CHECK(ctx, rocprim::exclusive_scan(ctx->sorttemp, need, alive, newidx, 0, (size_t) N, rocprim::plus<int>(), s));
-  hipLaunchKernelGGL(k_dead_compact, dim3(std::min(cdiv(N, 256), 1024), D_COUNT + 1), dim3(256), 0, s,
-                     ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], alive, newidx, N,
-                     d_from, d_to, (int) moves.size(), D_COUNT);
+  GH_CHECK(ctx, rocprim::exclusive_scan(ctx->sorttemp, need, alive, newidx, 0, (size_t) pn, rocprim::plus<int>(), s));
+  // the new particle count fixes the new cell counts and this rank's new range
+  ctx->N = Nnew;
+  if (ctx->nranks > 1) {
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    const int rc = gh_alloc_tree(ctx);
+    if (rc) return rc;
+  }
+  else { ctx->own_first = 0; ctx->own_count = Nnew; }
+  const size_t new_first = (size_t) ctx->own_first;
+  hipLaunchKernelGGL(k_dead_compact, dim3(std::min(cdiv(pn, 256), 1024), D_COUNT + 1), dim3(256), 0, s,
+                     ctx->d_ptrtab + (size_t) ctx->cur*2*D_COUNT, ctx->iorig[ctx->cur], ctx->iorig[ctx->cur ^ 1], alive, newidx, pn,
+                     d_from, d_to, (int) moves.size(), D_COUNT, old_first, new_first);
   ctx->cur ^= 1;
   GH_CHECK(ctx, hipStreamSynchronize(s));                   // from / to live on the host stack until the kernel has read them
-  ctx->N = Nnew;
-  ctx->own_first = 0; ctx->own_count = Nnew;
+  const int held = pn - nmine;
+  if (ctx->nranks > 1) ctx->own_held = held;
   ctx->tree_valid = false;
   ctx->rebuild_tree = true;
   // a global-timestep run keeps only "dead" and "potmin" in the flag word: both start afresh
-  if (ctx->cfg.Nlevels <= 1) GH_CHECK(ctx, hipMemsetAsync(ctx->fbuf[ctx->cur][D_FLAGS], 0, sizeof(double)*(size_t) Nnew, s));
+  if (ctx->cfg.Nlevels <= 1 && held > 0) GH_CHECK(ctx, hipMemsetAsync(ctx->fbuf[ctx->cur][D_FLAGS] + new_first, 0, sizeof(double)*(size_t) held, s));
   return GH_OK;
 }
 
@@ -476,7 +513,7 @@ static int sk_upload_stars(gh_ctx *ctx, SinkScratch &W, const gh_host_stars &S, 
   return GH_OK;
 }
 
-// rows (all fields + slot) of the particles idx[0..n)
+// rows (all fields + slot) of the particles idx[0..n) - indices into this rank's own range, like everywhere below
 static int sk_fetch_rows(gh_ctx *ctx, SinkScratch &W, const std::vector<int> &idx, std::vector<double> &rows)
 {
   const size_t n = idx.size();
@@ -485,7 +522,7 @@ static int sk_fetch_rows(gh_ctx *ctx, SinkScratch &W, const std::vector<int> &id
   int rc = sk_reserve(ctx, W, ctx->sinks.size(), n + 16, n);
   if (rc) return rc;
   GH_CHECK(ctx, hipMemcpyAsync(W.d_i, idx.data(), sizeof(int)*n, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, (int) n, W.d_rows);
+  hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, gh_dev_own(ctx), W.d_i, (int) n, W.d_rows);
   GH_CHECK(ctx, hipMemcpyAsync(rows.data(), W.d_rows, sizeof(double)*n*SK_ROW, hipMemcpyDeviceToHost, ctx->stream));
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return GH_OK;
@@ -515,14 +552,24 @@ struct SinkKernel {
 };
 
 // Sinks::CreateNewSinkParticle (Sinks.cpp:282-356) from the packed row of the chosen particle + the mass inside the new
-// sink (Sinks.cpp:243-253)
-static int sk_create(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, int idx, double t)
+// sink (Sinks.cpp:243-253).  Several ranks: `owner` holds the particle (own index idx) and hands its row to everybody;
+// every rank appends the same star and sink; the mass inside the radius is summed in slot order over all ranks' particles.
+static int sk_create(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, int idx, int owner, double t)
 {
   const int nd = ctx->ndim;
-  std::vector<int> one(1, idx);
+  const bool mine = owner == ctx->rank;
   std::vector<double> row;
-  int rc = sk_fetch_rows(ctx, W, one, row);
-  if (rc) return rc;
+  int rc;
+  {
+    std::vector<int> one;
+    if (mine) one.push_back(idx);
+    std::vector<double> own_row;
+    if ((rc = sk_fetch_rows(ctx, W, one, own_row))) return rc;
+    std::vector<char> all; std::vector<size_t> sizes;
+    if ((rc = gh_dd_gatherv(ctx, own_row.data(), sizeof(double)*own_row.size(), all, sizes))) return rc;
+    if (all.size() != sizeof(double)*SK_ROW) return gh_fail(ctx, GH_ERR_INVALID, "sink creation: the chosen particle's row did not arrive");
+    row.assign((const double*) all.data(), (const double*) all.data() + SK_ROW);
+  }
   const SinkKernel K(ctx);
   gh_sink_rec sk = gh_sink_rec();
   const double h = row[D_H];
@@ -540,17 +587,20 @@ static int sk_create(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, int idx, dou
   S.m[sk.istar] = row[D_M]; S.h[sk.istar] = K.invkernrange*sk.radius; S.gpot[sk.istar] = row[D_GPOT];
   S.tlast[sk.istar] = t; S.dti[sk.istar] = 9.9e20;
   if (ctx->cfg.Nlevels > 1) { S.level[sk.istar] = (int) row[D_LEVEL]; S.nstep[sk.istar] = (int) row[D_NSTEP]; S.nlast[sk.istar] = (int) row[D_NLAST]; }
-  // the particle is gone: m = 0, dead
-  const double zero = 0.0;
-  GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, &zero, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_sink_apply, dim3(1), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, W.d_rows, 1);
+  // the particle is gone: m = 0, dead (W.d_i[0] still holds its index from the row fetch)
+  if (mine) {
+    const double zero = 0.0;
+    GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, &zero, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_sink_apply, dim3(1), dim3(64), 0, ctx->stream, gh_dev_own(ctx), W.d_i, W.d_rows, 1);
+  }
   // mmax: masses of the live particles inside the radius, summed in slot order
   double c[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < nd; k++) c[k] = S.r[o + k];
-  if ((rc = sk_reserve(ctx, W, ctx->sinks.size() + 1, (size_t) ctx->N + 16, 1))) return rc;
+  const int pn = (int) ctx->own_count;
+  if ((rc = sk_reserve(ctx, W, ctx->sinks.size() + 1, (size_t) pn + 16, 1))) return rc;
   GH_CHECK(ctx, hipMemcpyAsync(W.d_st, c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
   GH_CHECK(ctx, hipMemsetAsync(W.d_i, 0, sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(k_sink_within, dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), W.d_st, sk.radius*sk.radius, W.d_i, W.d_i + 1, (int) ctx->N);
+  hipLaunchKernelGGL(k_sink_within, dim3(cdiv(pn, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), W.d_st, sk.radius*sk.radius, W.d_i, W.d_i + 1, pn);
   int cnt = 0;
   GH_CHECK(ctx, hipMemcpyAsync(&cnt, W.d_i, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -558,28 +608,36 @@ static int sk_create(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, int idx, dou
   if (cnt) GH_CHECK(ctx, hipMemcpy(in.data(), W.d_i + 1, sizeof(int)*(size_t) cnt, hipMemcpyDeviceToHost));
   std::vector<double> rows;
   if ((rc = sk_fetch_rows(ctx, W, in, rows))) return rc;
-  std::vector<std::pair<int, double> > sm((size_t) cnt);
-  for (int e = 0; e < cnt; e++) sm[e] = std::make_pair((int) rows[(size_t) e*SK_ROW + D_COUNT], rows[(size_t) e*SK_ROW + D_M]);
+  std::vector<double> mine_sm((size_t) 2*cnt);              // (slot, mass) of this rank's particles inside
+  for (int e = 0; e < cnt; e++) { mine_sm[2*e] = rows[(size_t) e*SK_ROW + D_COUNT]; mine_sm[2*e + 1] = rows[(size_t) e*SK_ROW + D_M]; }
+  std::vector<char> all; std::vector<size_t> sizes;
+  if ((rc = gh_dd_gatherv(ctx, mine_sm.data(), sizeof(double)*mine_sm.size(), all, sizes))) return rc;
+  const size_t ntot = all.size()/(2*sizeof(double));
+  const double *q = (const double*) all.data();
+  std::vector<std::pair<int, double> > sm(ntot);
+  for (size_t e = 0; e < ntot; e++) sm[e] = std::make_pair((int) q[2*e], q[2*e + 1]);
   std::sort(sm.begin(), sm.end());
   sk.mmax = 0.0;
-  for (int e = 0; e < cnt; e++) sk.mmax += sm[e].second;
+  for (size_t e = 0; e < ntot; e++) sk.mmax += sm[e].second;
   ctx->sinks.push_back(sk);
   return GH_OK;
 }
 
-// Sinks::SearchForNewSinkParticles (Sinks.cpp:118-273); the global timestep makes "n % nstep == 0" true for everyone
+// Sinks::SearchForNewSinkParticles (Sinks.cpp:118-273); the global timestep makes "n % nstep == 0" true for everyone.
+// Several ranks: every rank's best candidate (density, slot) is gathered; the densest wins, the lowest slot among equals -
+// the particle the reference's ascending scan over all slots keeps (its MPI build reduces the same way, Sinks.cpp:207-241).
 static int sk_search(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double t)
 {
   if ((int) ctx->sinks.size() >= ctx->cfg.Nsinkfixed && ctx->cfg.Nsinkfixed != -1) return GH_OK;
-  const int N = (int) ctx->N;
-  const int nblk = cdiv(N, 256);
+  const int pn = (int) ctx->own_count;
+  const int nblk = cdiv(pn, 256);
   for (;;) {
     int rc = sk_reserve(ctx, W, ctx->sinks.size() + 1, (size_t) 2*nblk + 16, (size_t) nblk/SK_ROW + 2);
     if (rc) return rc;
     SinkTab T;
     if ((rc = sk_upload_stars(ctx, W, S, T))) return rc;
     double *b_rho = W.d_rows; int *b_slot = W.d_i, *b_idx = W.d_i + nblk;
-    hipLaunchKernelGGL(k_sink_search, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev(ctx), T, ctx->cfg.rho_sink, ctx->cfg.sink_radius, ctx->n, b_rho, b_slot, b_idx);
+    hipLaunchKernelGGL(k_sink_search, dim3(nblk), dim3(256), 0, ctx->stream, gh_dev_own(ctx), T, ctx->cfg.rho_sink, ctx->cfg.sink_radius, ctx->n, b_rho, b_slot, b_idx);
     std::vector<double> hr((size_t) nblk); std::vector<int> hs((size_t) 2*nblk);
     GH_CHECK(ctx, hipMemcpyAsync(hr.data(), b_rho, sizeof(double)*(size_t) nblk, hipMemcpyDeviceToHost, ctx->stream));
     GH_CHECK(ctx, hipMemcpyAsync(hs.data(), b_slot, sizeof(int)*(size_t) 2*nblk, hipMemcpyDeviceToHost, ctx->stream));
@@ -587,17 +645,32 @@ static int sk_search(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double t)
     double rho = 0.0; int slot = 0x7fffffff, idx = -1;               // rho_max starts at 0: a candidate needs rho > 0
     for (int b = 0; b < nblk; b++)
       if (hs[nblk + b] >= 0 && (hr[b] > rho || (hr[b] == rho && idx >= 0 && hs[b] < slot))) { rho = hr[b]; slot = hs[b]; idx = hs[nblk + b]; }
-    if (idx < 0) return GH_OK;
-    if ((rc = sk_create(ctx, W, S, idx, t))) return rc;
+    int owner = ctx->rank;
+    if (ctx->nranks > 1) {
+      const double mine[2] = {idx >= 0 ? rho : 0.0, idx >= 0 ? (double) slot : -1.0};
+      std::vector<char> all; std::vector<size_t> sizes;
+      if ((rc = gh_dd_gatherv(ctx, mine, sizeof(mine), all, sizes))) return rc;
+      const double *q = (const double*) all.data();
+      double brho = 0.0; int bslot = 0x7fffffff; owner = -1;
+      for (int r = 0; r < ctx->nranks; r++) {
+        const double rr = q[2*r]; const int rs = (int) q[2*r + 1];
+        if (rs >= 0 && (rr > brho || (rr == brho && owner >= 0 && rs < bslot))) { brho = rr; bslot = rs; owner = r; }
+      }
+      if (owner < 0) return GH_OK;
+    }
+    else if (idx < 0) return GH_OK;
+    if ((rc = sk_create(ctx, W, S, idx, owner, t))) return rc;
   }
 }
 
-// Sinks::AccreteMassToSinks (Sinks.cpp:365-770)
+// Sinks::AccreteMassToSinks (Sinks.cpp:365-770).  Several ranks: every rank finds its own particles inside the sink
+// radii and all ranks gather all of their rows (a few dozen per sink), rank by rank = in global tree order; the serial part
+// below then runs on every rank alike, and each rank writes back the masses of its own particles.
 static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double timestep)
 {
   const int nd = ctx->ndim;
   const int ns = (int) ctx->sinks.size();
-  const int N = (int) ctx->N;
+  const int N = (int) ctx->own_count;
   int rc;
   // slots: [0] pair count, [1 .. ns] Ngas, then the pairs
   const int cap = std::max(4096, N/4);
@@ -606,7 +679,7 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
   if ((rc = sk_upload_stars(ctx, W, S, T))) return rc;
   GH_CHECK(ctx, hipMemsetAsync(W.d_i, 0, sizeof(int)*(size_t) (ns + 2), ctx->stream));
   int2 *d_pairs = (int2*) (W.d_i + ((ns + 2 + 1) & ~1));
-  hipLaunchKernelGGL(k_sink_assign, dim3(cdiv(N, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), T, W.d_i + 1, W.d_i, d_pairs, cap);
+  hipLaunchKernelGGL(k_sink_assign, dim3(cdiv(N, 256)), dim3(256), 0, ctx->stream, gh_dev_own(ctx), T, W.d_i + 1, W.d_i, d_pairs, cap);
   std::vector<int> head((size_t) ns + 1);
   GH_CHECK(ctx, hipMemcpyAsync(head.data(), W.d_i, sizeof(int)*(size_t) (ns + 1), hipMemcpyDeviceToHost, ctx->stream));
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -614,19 +687,44 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
   if (np > cap) return gh_fail(ctx, GH_ERR_CAPACITY, "sink accretion: more than N/4 particles inside sink radii");
   std::vector<int2> pairs((size_t) np);
   if (np) GH_CHECK(ctx, hipMemcpy(pairs.data(), d_pairs, sizeof(int2)*(size_t) np, hipMemcpyDeviceToHost));
-  for (int s = 0; s < ns; s++) ctx->sinks[s].Ngas = head[1 + s];
   // a particle accretes to the last sink that holds it; per sink the list in tree order (= the reference's neiblist order)
   std::sort(pairs.begin(), pairs.end(), [](const int2 &a, const int2 &b) { return a.y != b.y ? a.y < b.y : a.x < b.x; });
   std::vector<std::vector<int> > lists((size_t) ns);
   for (int e = 0; e < np; e++) if (e + 1 == np || pairs[e + 1].y != pairs[e].y) lists[pairs[e].x].push_back(pairs[e].y);
-  std::vector<int> all;
-  std::vector<size_t> off((size_t) ns + 1, 0);
-  for (int s = 0; s < ns; s++) { off[s] = all.size(); all.insert(all.end(), lists[s].begin(), lists[s].end()); }
-  off[ns] = all.size();
+  std::vector<int> mine;                                             // this rank's particles, sink by sink
+  for (int s = 0; s < ns; s++) mine.insert(mine.end(), lists[s].begin(), lists[s].end());
+  std::vector<double> myrows;
+  if ((rc = sk_fetch_rows(ctx, W, mine, myrows))) return rc;
+  // every rank's block: [Ngas of every sink | rows per sink | rows ...]; `who` = (rank, own index) of every gathered row
   std::vector<double> rows;
-  if ((rc = sk_fetch_rows(ctx, W, all, rows))) return rc;
-  std::vector<double> mnew(all.size());
-  for (size_t e = 0; e < all.size(); e++) mnew[e] = rows[e*SK_ROW + D_M];
+  std::vector<std::pair<int, int> > who;
+  std::vector<size_t> off((size_t) ns + 1, 0);
+  {
+    std::vector<double> blk((size_t) 2*ns + myrows.size());
+    for (int s = 0; s < ns; s++) { blk[s] = (double) head[1 + s]; blk[ns + s] = (double) lists[s].size(); }
+    std::copy(myrows.begin(), myrows.end(), blk.begin() + 2*ns);
+    std::vector<char> all; std::vector<size_t> sizes;
+    if ((rc = gh_dd_gatherv(ctx, blk.data(), sizeof(double)*blk.size(), all, sizes))) return rc;
+    const int Wn = ctx->nranks;
+    std::vector<const double*> base((size_t) Wn);
+    { size_t o = 0; for (int r = 0; r < Wn; r++) { base[r] = (const double*) (all.data() + o); o += sizes[r]; } }
+    for (int s = 0; s < ns; s++) ctx->sinks[s].Ngas = 0;
+    std::vector<size_t> cursor((size_t) Wn, 0), local((size_t) Wn, 0);      // rows / own-list entries of rank r consumed so far
+    for (int s = 0; s < ns; s++) {
+      off[s] = who.size();
+      for (int r = 0; r < Wn; r++) {
+        ctx->sinks[s].Ngas += (int) base[r][s];
+        const size_t cnt = (size_t) base[r][ns + s];
+        const double *src = base[r] + 2*ns + cursor[r]*SK_ROW;
+        rows.insert(rows.end(), src, src + cnt*SK_ROW);
+        for (size_t e = 0; e < cnt; e++) who.push_back(std::make_pair(r, r == ctx->rank ? mine[local[r] + e] : -1));
+        cursor[r] += cnt; local[r] += cnt;
+      }
+    }
+    off[ns] = who.size();
+  }
+  std::vector<double> mnew(who.size());
+  for (size_t e = 0; e < who.size(); e++) mnew[e] = rows[e*SK_ROW + D_M];
   const SinkKernel K(ctx);
   const double small_number = SK_SMALL, pi = 3.14159265358979, twopi = 6.28318530717959;
   std::vector<int> lnb_idx, lnb_lvl;                                 // levelneib of the particles a sink accretes from (:516)
@@ -649,7 +747,7 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
       const double drsqd = dot3(dr, dr, nd);
       if (drsqd > sk.radius*sk.radius) continue;
       il.push_back(e); rs.push_back(drsqd);
-      if (ctx->cfg.Nlevels > 1) { lnb_idx.push_back(all[e]); lnb_lvl.push_back(S.level[is]); }
+      if (ctx->cfg.Nlevels > 1 && who[e].first == ctx->rank) { lnb_idx.push_back(who[e].second); lnb_lvl.push_back(S.level[is]); }
     }
     const int Nneib = (int) il.size();
     for (int j = 1; j < Nneib; j++) {
@@ -736,20 +834,24 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
     const double asqd = dot3(sa, sa, nd);
     S.dti[is] = 0.4*sqrt(sk.radius/(sqrt(asqd) + small_number));
   }
-  // masses and dead flags back to the device
-  if (!all.empty()) {
-    if ((rc = sk_reserve(ctx, W, ns, all.size() + 16, all.size()))) return rc;
-    GH_CHECK(ctx, hipMemcpyAsync(W.d_i, all.data(), sizeof(int)*all.size(), hipMemcpyHostToDevice, ctx->stream));
-    GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, mnew.data(), sizeof(double)*all.size(), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_sink_apply, dim3(cdiv(all.size(), 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, W.d_rows, (int) all.size());
-    GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // masses and dead flags back to the device (this rank's particles)
+  {
+    std::vector<int> aidx; std::vector<double> am;
+    for (size_t e = 0; e < who.size(); e++) if (who[e].first == ctx->rank) { aidx.push_back(who[e].second); am.push_back(mnew[e]); }
+    if (!aidx.empty()) {
+      if ((rc = sk_reserve(ctx, W, ns, aidx.size() + 16, aidx.size()))) return rc;
+      GH_CHECK(ctx, hipMemcpyAsync(W.d_i, aidx.data(), sizeof(int)*aidx.size(), hipMemcpyHostToDevice, ctx->stream));
+      GH_CHECK(ctx, hipMemcpyAsync(W.d_rows, am.data(), sizeof(double)*aidx.size(), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_sink_apply, dim3(cdiv(aidx.size(), 64)), dim3(64), 0, ctx->stream, gh_dev_own(ctx), W.d_i, W.d_rows, (int) aidx.size());
+      GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
   if (!lnb_idx.empty()) {
     const size_t nl = lnb_idx.size();
     if ((rc = sk_reserve(ctx, W, ns, 2*nl + 16, 1))) return rc;
     GH_CHECK(ctx, hipMemcpyAsync(W.d_i, lnb_idx.data(), sizeof(int)*nl, hipMemcpyHostToDevice, ctx->stream));
     GH_CHECK(ctx, hipMemcpyAsync(W.d_i + nl, lnb_lvl.data(), sizeof(int)*nl, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_sink_levelneib, dim3(cdiv(nl, 64)), dim3(64), 0, ctx->stream, gh_dev(ctx), W.d_i, W.d_i + nl, (int) nl);
+    hipLaunchKernelGGL(k_sink_levelneib, dim3(cdiv(nl, 64)), dim3(64), 0, ctx->stream, gh_dev_own(ctx), W.d_i, W.d_i + nl, (int) nl);
     GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return GH_OK;
@@ -764,12 +866,26 @@ int gh_sinks_step(gh_ctx *ctx, gh_host_stars &S, double t, double timestep)
   int rc;
   if (ctx->cfg.create_sinks == 1 && (rc = sk_search(ctx, W, S, t))) return rc;
   if (ctx->sinks.empty()) return GH_OK;
-  // mmean: masses summed in slot order, dead particles (m = 0) included in the count (SphSimulation.cpp:826-828)
-  {
+  // mmean: masses summed in slot order, dead particles (m = 0) included in the count (SphSimulation.cpp:826-828).
+  // Several ranks: every rank sums its own particles (tree order), the partial sums are added in rank order - mmean only
+  // enters the "what is left is less than smooth_accrete_frac*mmean" test of the smooth accretion
+  if (ctx->nranks == 1) {
     std::vector<double> m((size_t) ctx->N);
     if ((rc = gh_download(ctx, GH_F_M, m.data()))) return rc;
     double sum = 0.0;
     for (size_t i = 0; i < m.size(); i++) sum += m[i];
+    ctx->mmean = sum/(double) ctx->N;
+  }
+  else {
+    std::vector<double> m((size_t) ctx->own_count);
+    GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    GH_CHECK(ctx, hipMemcpy(m.data(), ctx->fbuf[ctx->cur][D_M] + ctx->own_first, sizeof(double)*m.size(), hipMemcpyDeviceToHost));
+    double part = 0.0;
+    for (size_t i = 0; i < m.size(); i++) part += m[i];
+    std::vector<char> all; std::vector<size_t> sizes;
+    if ((rc = gh_dd_gatherv(ctx, &part, sizeof(double), all, sizes))) return rc;
+    double sum = 0.0;
+    for (int r = 0; r < ctx->nranks; r++) sum += ((const double*) all.data())[r];
     ctx->mmean = sum/(double) ctx->N;
   }
   return sk_accrete(ctx, W, S, timestep);

@@ -94,7 +94,12 @@ __global__ void k_gas_star_forces(DevicePtrs d, StarTab S, const double *ktab)
 
 // stars <- gas: one wavefront per star
 template <int ND, int KT, bool QUAD>
-__global__ __launch_bounds__(64) void k_star_gas_forces(DevicePtrs d, StarTab S, const double *ktab, double *out_a, double *out_gpot, int *flags)
+//
+// Several ranks: every rank walks the shared top levels alike and its OWN subtree below them; a node's contribution is
+// summed by the rank that owns it (level >= L: the rank whose cell it lies in; above: the rank of its leftmost descendant),
+// the other ranks' subtrees are skipped, and the ranks' partial sums are added up on the host (gh_star_gas_forces) - the
+// reference's MPI_Allreduce of the star forces (MpiControl / NbodySimulation: every rank holds all stars).  L = 0: one rank.
+__global__ __launch_bounds__(64) void k_star_gas_forces(DevicePtrs d, StarTab S, const double *ktab, double *out_a, double *out_gpot, int *flags, int L, int self)
 {
   typedef typename KSel<ND, KT>::type K;
   __shared__ int s_front[2][GH_STAR_FRONT];
@@ -115,7 +120,9 @@ __global__ __launch_bounds__(64) void k_star_gas_forces(DevicePtrs d, StarTab S,
       const bool have = base + lane < nf;
       const int n = have ? s_front[cur][base + lane] : 0;
       bool open = false;
-      if (have) {
+      const int lev = 31 - __clz(n + 1), jlev = n - ((1 << lev) - 1);
+      const bool mine = (lev >= L ? jlev >> (lev - L) : jlev << (L - lev)) == self;
+      if (have && (mine || lev < L)) {
         const CellGeo g = d.cgeo[n];
         double drsqd = 0.0;
         for (int k = 0; k < ND; k++) { const double dx = g.rcell[k] - rs[k]; drsqd += dx*dx; }
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(64) void k_star_gas_forces(DevicePtrs d, StarTab S,
           }
         }
         else if (g.N > 0 && drsqd > g.cdistsqd) {              // far: cell, or its only particle (:834-851)
-          if (isleaf && g.N == 1) {
+          if (!mine) { /* a shared top cell another rank sums */ }
+          else if (isleaf && g.N == 1) {
             const double4 p = d.posm[g.first];
             double dr[3] = {p.x - rs[0], ND > 1 ? p.y - rs[1] : 0.0, ND > 2 ? p.z - rs[2] : 0.0};
             const double invdrmag = fast_rsqrt(dr[0]*dr[0] + dr[1]*dr[1] + dr[2]*dr[2]);
@@ -240,9 +248,9 @@ extern "C" int gh_set_stars(gh_ctx *ctx, int64_t nstars, const double *r, const 
 int gh_zeta_stars_impl(gh_ctx *ctx)
 {
   if (ctx->nstars <= 0) return GH_OK;
-  DevicePtrs d = gh_dev(ctx);
+  DevicePtrs d = gh_dev_own(ctx);
   const StarTab S = star_tab(ctx);
-#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_zeta_stars<ND_, KT_>), dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, d, S, ctx->ktab);
+#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_zeta_stars<ND_, KT_>), dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, d, S, ctx->ktab);
   GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   return GH_OK;
@@ -251,9 +259,9 @@ int gh_zeta_stars_impl(gh_ctx *ctx)
 int gh_gas_star_forces_impl(gh_ctx *ctx)
 {
   if (ctx->nstars <= 0) return GH_OK;
-  DevicePtrs d = gh_dev(ctx);
+  DevicePtrs d = gh_dev_own(ctx);
   const StarTab S = star_tab(ctx);
-#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_gas_star_forces<ND_, KT_>), dim3(cdiv(ctx->N, 256)), dim3(256), 0, ctx->stream, d, S, ctx->ktab);
+#define LAUNCH(ND_, KT_) hipLaunchKernelGGL((k_gas_star_forces<ND_, KT_>), dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, d, S, ctx->ktab);
   GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   return GH_OK;
@@ -269,12 +277,26 @@ extern "C" int gh_star_gas_forces(gh_ctx *ctx, double *a, double *gpot)
   const bool quad = ctx->cfg.multipole == GH_MULTIPOLE_QUADRUPOLE || ctx->cfg.multipole == GH_MULTIPOLE_FAST_QUADRUPOLE;
   double *oa = ctx->star_out, *og = ctx->star_out + (size_t) 3*ctx->nstars;
 #define LAUNCH(ND_, KT_)                                                                                                         \
-  if (quad) hipLaunchKernelGGL((k_star_gas_forces<ND_, KT_, true>), dim3(ctx->nstars), dim3(64), 0, ctx->stream, d, S, ctx->ktab, oa, og, ctx->d_flags); \
-  else hipLaunchKernelGGL((k_star_gas_forces<ND_, KT_, false>), dim3(ctx->nstars), dim3(64), 0, ctx->stream, d, S, ctx->ktab, oa, og, ctx->d_flags);
+  if (quad) hipLaunchKernelGGL((k_star_gas_forces<ND_, KT_, true>), dim3(ctx->nstars), dim3(64), 0, ctx->stream, d, S, ctx->ktab, oa, og, ctx->d_flags, ctx->L, ctx->rank); \
+  else hipLaunchKernelGGL((k_star_gas_forces<ND_, KT_, false>), dim3(ctx->nstars), dim3(64), 0, ctx->stream, d, S, ctx->ktab, oa, og, ctx->d_flags, ctx->L, ctx->rank);
   GH_DISPATCH(ctx, LAUNCH)
 #undef LAUNCH
   int rc = gh_sync_collect(ctx, "gh_star_gas_forces");
   if (rc) return rc;
+  if (ctx->nranks > 1) {
+    // the ranks' partial sums, added in rank order on every rank alike
+    const size_t ns = (size_t) ctx->nstars, nd = (size_t) ctx->ndim;
+    std::vector<char> all; std::vector<size_t> sizes;
+    if ((rc = gh_dd_gatherv(ctx, ctx->star_out, sizeof(double)*4*ns, all, sizes))) return rc;
+    for (size_t i = 0; i < ns*nd; i++) a[i] = 0.0;
+    for (size_t i = 0; i < ns; i++) gpot[i] = 0.0;
+    for (int r = 0; r < ctx->nranks; r++) {
+      const double *blk = (const double*) all.data() + (size_t) r*4*ns;
+      for (size_t i = 0; i < ns*nd; i++) a[i] += blk[i];
+      for (size_t i = 0; i < ns; i++) gpot[i] += blk[3*ns + i];
+    }
+    return GH_OK;
+  }
   GH_CHECK(ctx, hipMemcpy(a, oa, sizeof(double)*(size_t) ctx->ndim*ctx->nstars, hipMemcpyDeviceToHost));
   GH_CHECK(ctx, hipMemcpy(gpot, og, sizeof(double)*(size_t) ctx->nstars, hipMemcpyDeviceToHost));
   return GH_OK;

@@ -898,7 +898,7 @@ DevicePtrs gh_dev_own(gh_ctx *ctx)
   for (int f = 0; f < D_COUNT; f++) d.f[f] += o;
   d.iorig += o; d.posm += o; d.hrec += 4*o;
   if (d.pm_invhsqd) { d.pm_invhsqd += o; d.pm_cullsqd += o; }
-  d.N = (int) ctx->own_count;
+  d.N = (int) (ctx->own_held >= 0 ? ctx->own_held : ctx->own_count);     // (own_held: between gh_sinks_delete_dead and the migration)
   return d;
 }
 
@@ -1096,7 +1096,10 @@ int gh_tree_build_impl(gh_ctx *ctx)
   if (ctx->nranks > 1) {
     // root box, the L shared top levels (distributed median splits) and the migration of the particles that changed
     // cells; leaves every own particle in cell (1 << L) - 1 + rank with that cell's inherited box in dbbmin/dbbmax
+    const bool uneven = ctx->own_held >= 0;               // a sink run after accretion: this rank's range may have grown
     if ((rc = gh_dd_decompose(ctx))) return rc;
+    if (uneven)                                            // ... beyond the particles gh_rootbox_local put into the rank's cell
+      hipLaunchKernelGGL(k_fill_int, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, ctx->cellnode[0] + ctx->own_first, (int) ctx->own_count, (1 << L) - 1 + ctx->rank);
   }
   else gh_rootbox_local(ctx, 0);
   const int p0 = (int) ctx->own_first, pn = (int) ctx->own_count;
@@ -1104,6 +1107,20 @@ int gh_tree_build_impl(gh_ctx *ctx)
   const int nb = cdiv(pn, 256);
   DevicePtrs d = gh_dev(ctx);
   hipStream_t s = ctx->stream;
+  if (getenv("GH_DD_DEBUG")) {
+    // this rank's particles after the migration: ids and coordinates must be distinct
+    GH_CHECK(ctx, hipStreamSynchronize(s));
+    std::vector<int> ids((size_t) pn); std::vector<double> x((size_t) pn), m((size_t) pn);
+    GH_CHECK(ctx, hipMemcpy(ids.data(), ctx->iorig[ctx->cur] + p0, sizeof(int)*(size_t) pn, hipMemcpyDeviceToHost));
+    GH_CHECK(ctx, hipMemcpy(x.data(), ctx->fbuf[ctx->cur][D_RX] + p0, sizeof(double)*(size_t) pn, hipMemcpyDeviceToHost));
+    GH_CHECK(ctx, hipMemcpy(m.data(), ctx->fbuf[ctx->cur][D_M] + p0, sizeof(double)*(size_t) pn, hipMemcpyDeviceToHost));
+    std::vector<int> si(ids); std::sort(si.begin(), si.end());
+    std::vector<double> sx(x); std::sort(sx.begin(), sx.end());
+    int dupi = 0, dupx = 0, zm = 0, bad = 0;
+    for (int i = 1; i < pn; i++) { if (si[i] == si[i - 1]) dupi++; if (sx[i] == sx[i - 1]) dupx++; }
+    for (int i = 0; i < pn; i++) { if (m[i] == 0.0) zm++; if (ids[i] < 0 || ids[i] >= N) bad++; }
+    fprintf(stderr, "[build] rank %d N %d p0 %d pn %d: duplicate ids %d, equal x %d, zero masses %d, ids out of range %d\n", ctx->rank, N, p0, pn, dupi, dupx, zm, bad);
+  }
 
   // One argsort per axis, on three streams.  The keys are 32-bit fixed-point coordinates relative to the build's box
   // (monotone in x), sorted with rocPRIM's onesweep radix sort (4 passes; its merge sort, which it would pick for <= 2^20

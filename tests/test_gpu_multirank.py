@@ -35,7 +35,15 @@ run = DistributedRunner(sim, rank, world)
 run.setup()
 run.steps(nsteps)
 fields = ["r", "v", "h", "rho", "a", "u", "dudt", "gpot"] + (["level", "levelneib", "nstep", "nlast"] if int(sim.get_param("Nlevels")) > 1 else [])
+sinks = int(sim.get_param("sink_particles")) == 1
+if sinks:
+    fields += ["m", "sinkid", "flags"]
 res = {k: run.gather(k) for k in fields}
+if sinks:
+    sk = run.dev.sinks()
+    for k, v in sk.items():
+        res["sink_" + k] = np.atleast_1d(np.asarray(v))
+    res["Nhydro"] = np.array([run.dev.N])
 own_first, own_count, held = run.dev.comm_info()
 info = np.array([own_count, held, sim.t, sim.timestep])
 if world > 1:
@@ -116,6 +124,41 @@ def test_block_timesteps_on_ranks_equal_one_rank(case, world, tmp_path):
     for k in ("r", "v", "h", "rho", "a", "u", "dudt", "gpot"):
         assert np.all(np.isfinite(many[k])), k
         assert _relerr(one[k], many[k]) <= 1e-12, (k, _relerr(one[k], many[k]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case,nsteps", [("bb_sinks_8k", 12), ("bb_sinks_8k_levels", 40)])
+def test_sinks_on_ranks_equal_one_rank(case, nsteps, world, tmp_path):
+    """Sink particles under the domain decomposition (BASELINE configs[4]'s physics: Boss-Bodenheimer cloud, sink creation,
+    smooth accretion; `_levels`: on the block-timestep ladder).  The sinks' stars live on every rank; the candidate search is a
+    gather of the ranks' best (density, slot), the chosen particle's row and the gas inside the sink radii are gathered to all
+    ranks, which run the serial accretion alike; accreted particles leave the arrays by the reference's slot rule applied to the
+    gathered dead slots, every cell's particle count follows the new N and the next migration evens the ranks out; the star
+    forces are partial sums over the ranks' subtrees.  Two sinks form and accrete in these steps: which particles they were,
+    Ngas, sinkid and dead flag of every particle, the compacted order, levels and clock are EXACTLY the one-rank run's; sums to
+    rounding.  (One difference is inherent: inside a leaf cell the one-rank sink run keeps the reference's quick-select order,
+    several ranks the coordinate order - the potential-minimum test, which the reference makes order dependent, sees its
+    neighbours in that order.)"""
+    one = _run(tmp_path, case, 1, nsteps, {})
+    many = _run(tmp_path, case, world, nsteps, {})
+    assert one["Nhydro"][0] == many["Nhydro"][0] < 8192 and len(one["sink_istar"]) == len(many["sink_istar"]) == 2
+    # (the stars' accelerations are sums of the ranks' partial sums: equal to rounding, and so are the timesteps they set)
+    assert np.all(np.abs(many["info"][:, 2] - one["info"][2]) <= 1e-12*one["info"][2])                       # t
+    assert np.all(np.abs(many["info"][:, 3] - one["info"][3]) <= 1e-10*one["info"][3])                       # dt
+    assert many["info"][:, 0].sum() == many["Nhydro"][0]                                                     # the ranks' cells hold the new N
+    for k in ("sinkid", "flags") + (("level", "levelneib", "nstep", "nlast") if case.endswith("levels") else ()):
+        a, b = one[k].astype(np.int64), many[k].astype(np.int64)
+        if k == "flags":
+            a, b = a & 4, b & 4                                                                               # dead (potmin: where the search reads it)
+        assert np.array_equal(a, b), k
+    assert np.array_equal(one["m"] == 0.0, many["m"] == 0.0)
+    for k in ("r", "v", "h", "rho", "a", "u", "gpot", "m"):
+        assert np.all(np.isfinite(many[k])), k
+        assert _relerr(one[k], many[k]) <= 1e-11, (k, _relerr(one[k], many[k]))
+    assert np.array_equal(one["sink_istar"], many["sink_istar"]) and np.array_equal(one["sink_Ngas"], many["sink_Ngas"])
+    for k in ("radius", "mmax", "menc", "dmdt", "ketot", "gpetot", "rotketot", "utot", "taccrete", "trad", "trot", "tvisc", "angmom", "mmean"):
+        a, b = one["sink_" + k], many["sink_" + k]
+        assert np.max(np.abs(a - b)) <= 1e-10*max(np.max(np.abs(a)), 1e-300), k
 
 
 def test_two_ranks_at_the_benchmark_size(tmp_path):
