@@ -202,7 +202,13 @@ __global__ __launch_bounds__(1024) void k_dd_scan(DDCell *cells, const int *hist
       q.loB = q.scA > 0.0 ? q.loA + (double) bsel/q.scA : q.loA;
       q.scB = q.scA*(double) DD_G;
     }
-    else q.binB = bsel;
+    else {
+      q.binB = bsel;
+      // particles in the coarse bin (the fine histogram counts only those): the density the next step's window is sized by
+      long long tot = 0;
+      for (int b = 0; b < DD_G; b++) tot += s_cum[b];
+      q.pad = (int) (tot > 0x7fffffff ? 0x7fffffff : tot);
+    }
     cells[c] = q;
   }
 }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
     int run = 0; long long base = 0; int bad = 0;
     for (int r = 0; r < nranks; r++) {
       s_off[r] = run;
-      if (s_cnt[r] > DD_WCAP) bad = 1;
+      if (s_cnt[r] > DD_WCAP) bad = 2;                       // (status bits: 1 axis changed, 2 a rank's window overflowed, 4 root axis, 8 median outside the windows)
       run += min(s_cnt[r], DD_WCAP);
       base += s_below[r];
     }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
         dbbmin[k] = s_box[k]; dbbmax[k] = s_box[3 + k];
         if (k < ndim && s_box[3 + k] - s_box[k] > rkmax) { rkmax = s_box[3 + k] - s_box[k]; kd = k; }
       }
-      if (kd != cells[0].kd) s_bad = 1;
+      if (kd != cells[0].kd) s_bad |= 4;
     }
   }
   __syncthreads();
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
       wnew = fmin(wnew, 0.25*(dbbmax[n*3 + kd] - dbbmin[n*3 + kd]));
       spl_prev[n] = m.key; spl_win[n] = wnew;
     }
-    else atomicOr(fail, 1);
+    else atomicOr(fail, s_bad ? s_bad : 8);
     for (int k = 0; k < 3; k++) {
       dbbmin[c1*3 + k] = dbbmin[n*3 + k]; dbbmax[c1*3 + k] = (k == kd) ? w.rdiv : dbbmax[n*3 + k];
       dbbmin[c2*3 + k] = (k == kd) ? w.rdiv : dbbmin[n*3 + k]; dbbmax[c2*3 + k] = dbbmax[n*3 + k];
@@ -1169,6 +1175,7 @@ int gh_dd_decompose(gh_ctx *ctx)
     GH_CHECK(ctx, hipStreamSynchronize(s));
     int failed = 0;
     for (int r = 0; r < W; r++) failed |= all[(size_t) r*CWM + GH_MAX_RANKS];
+    if (spec && failed && getenv("GH_DD_DEBUG")) fprintf(stderr, "[dd] rank %d: speculative splits failed, status %d\n", ctx->rank, failed);
     if (spec && failed) { spec = false; continue; }       // collective decision: every rank sees the same words
     break;
   }

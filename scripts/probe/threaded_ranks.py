@@ -158,8 +158,13 @@ def run(world, N, nsteps, params):
                     if shared.token:
                         shared.token.acquire()
             dev = sim.device()
-            out[r] = {k: np.nan_to_num(dev.download(k), nan=0.0) for k in ("h", "rho", "a", "gpot", "dudt")}
+            sinks = sim.get_param("sink_particles") == "1"
+            names = ("h", "rho", "a", "gpot", "dudt") + (("m", "sinkid", "flags") if sinks else ())
+            out[r] = {k: np.nan_to_num(dev.download(k), nan=0.0) for k in names}
             out[r]["info"] = dev.comm_info()
+            if sinks:
+                out[r]["sinks"] = dev.sinks()
+                out[r]["N"] = dev.N
             if shared.token:
                 shared.token.release()
         except Exception as e:          # noqa: BLE001
@@ -181,7 +186,11 @@ def run(world, N, nsteps, params):
         t.join()
     if fail or shared.errors:
         raise RuntimeError("ranks failed: %r %r" % (fail, shared.errors))
-    res = {k: sum(o[k] for o in out) for k in ("h", "rho", "a", "gpot", "dudt")}     # every particle is owned by one rank
+    res = {k: sum(o[k] for o in out) for k in out[0] if k not in ("info", "sinks", "N")}     # every particle is owned by one rank
+    if "sinks" in out[0]:
+        for o in out[1:]:       # the sinks (and the particle count) are everybody's: identical on all ranks
+            assert o["N"] == out[0]["N"] and all(np.array_equal(o["sinks"][k], out[0]["sinks"][k]) for k in out[0]["sinks"])
+        res["sinks"], res["N"] = out[0]["sinks"], out[0]["N"]
     # all ranks share ONE GPU: the wall time of a step is (roughly) the SUM of the ranks' work plus the harness's device-wide
     # synchronisations - an upper bound of the mean work per rank when divided by the rank count, not a multi-GPU timing
     print("world %d: %.2f ms per step on one shared GPU = %.2f ms per rank" % (world, 1e3*max(wall), 1e3*max(wall)/world))
@@ -202,12 +211,24 @@ def main():
     params = sys.argv[4] if len(sys.argv) > 4 else "plummer_4k"
     one, _ = run(1, N, nsteps, params)
     many, info = run(world, N, nsteps, params)
-    errs = {k: relerr(one[k], many[k]) for k in one}
+    sinks = "sinks" in one
+    errs = {k: relerr(one[k], many[k]) for k in one if k not in ("sinks", "N", "sinkid", "flags")}
     own = [int(i[1]) for i in info]
     held = [int(i[2]) for i in info]
     print("world %d N %d steps %d %s: max rel err vs one rank %s" % (world, N, nsteps, params, {k: "%.2e" % v for k, v in errs.items()}))
     print("own", own, "held", held)
-    assert all(v <= 1e-13 for v in errs.values()), errs
+    if sinks:
+        # sink run: which particles became sinks or were accreted, sinkid and dead flag of everybody, Ngas - exact; sums to rounding
+        # (the stars' forces are sums of the ranks' partial sums)
+        a, b = one["sinks"], many["sinks"]
+        print("sinks: N %d -> %d (one rank: %d), %d sinks, Ngas %s" % (N, many["N"], one["N"], len(b["istar"]), list(b["Ngas"])))
+        assert one["N"] == many["N"] == sum(own) and len(a["istar"]) == len(b["istar"]) > 0
+        assert np.array_equal(a["Ngas"], b["Ngas"]) and np.array_equal(one["sinkid"], many["sinkid"])
+        assert np.array_equal(one["flags"].astype(np.int64) & 4, many["flags"].astype(np.int64) & 4)
+        assert np.array_equal(one["m"] == 0.0, many["m"] == 0.0)
+        for k in ("mmax", "menc", "dmdt", "utot"):
+            assert np.max(np.abs(a[k] - b[k])) <= 1e-10*np.max(np.abs(a[k])), k
+    assert all(v <= (1e-11 if sinks else 1e-13) for v in errs.values()), errs
     print("OK")
 
 

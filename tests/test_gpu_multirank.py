@@ -173,13 +173,13 @@ def test_two_ranks_at_the_benchmark_size(tmp_path):
         assert _relerr(one[k], two[k]) <= 1e-13, (k, _relerr(one[k], two[k]))
 
 
-@pytest.mark.parametrize("world,n,par", [(8, 65536, "plummer_4k"), (8, 1048576, "plummer_4k"), (8, 65536, "box3d_4k")])
+@pytest.mark.parametrize("world,n,par", [(8, 65536, "plummer_4k"), (8, 1048576, "plummer_4k"), (8, 65536, "box3d_4k"), (8, 65536, "bb_sinks_8k_levels")])
 def test_eight_ranks_in_one_process(world, n, par):
     """The 8-rank case of the scaling bench (L = 3 shared levels) cannot run as 8 processes on a one-GPU box (process
     guard); scripts/probe/threaded_ranks.py runs the ranks as threads of one process, all contexts on GPU 0, with the two
     collectives as device-to-device copies behind a barrier.  Results against the one-rank run, at 65 536 particles after
     setup + 2 steps (Plummer sphere with self-gravity; periodic box) and at the benchmark's 1 048 576 after setup + 1 step."""
-    steps = "2" if n < 1000000 else "1"
+    steps = "10" if par.startswith("bb_sinks") else ("2" if n < 1000000 else "1")       # sink run: two sinks form on the first step and accrete
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe", "threaded_ranks.py"), str(world), str(n), steps, par],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
