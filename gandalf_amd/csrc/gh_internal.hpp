@@ -146,6 +146,7 @@ struct gh_ctx {
   void *sink_scratch = nullptr;
   double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
   int *qs_ids = nullptr; double *qs_keys = nullptr;   // exact (quick-select order) build, tree.hip
+  double *qw_k[2] = {nullptr, nullptr}; int *qw_i[2] = {nullptr, nullptr}, *qw_rk = nullptr, *qw_blk = nullptr; void *qw_st = nullptr; size_t qw_words = 0;   // ... its device-wide passes (top levels)
   bool exact_armed = false;        // a build split equal coordinates: every later build runs the gated exact kernels
   int *leafact = nullptr;          // [gtot] active particles per leaf at the last stocking (ntreestockstep > 1 and Nlevels > 1 only)
   double *leaf_amin = nullptr;

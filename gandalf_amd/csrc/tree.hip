@@ -339,8 +339,18 @@ __global__ void k_qsel_init(DevicePtrs d, int *ids, const int *gate)
 // place (R rotations, M ops).  So the element that ends at a position >= f0 + R is found by following "rotation at op i ->
 // token (number of rotations up to i)" until a push is reached: a chain of strictly decreasing positions, O(log M) long.
 // All positions are independent: the pass is a prefix sum and a gather instead of M/64 dependent block steps.
+// state of one cell's quick-select while its range is wider than a workgroup's LDS (k_qw_*, below)
+struct QSel {
+  int left, right;                   // current range (the pivot search continues in it)
+  int cur, done, conv;               // buffer the range lives in; range fits LDS or converged; converged (pivot landed on the median)
+  int f0, nb4, jguess, none;         // this pass: first "> pivot" position, "<=" elements before it, where the pivot lands, no element > pivot
+  int nleft, nright, nconv;          // the range after this pass
+  double rpiv;                       // last pivot value
+};
+struct QWide { const QSel *st; double *k0, *k1; int *i0, *i1; };
+
 __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level, int *ids, double *keys, double *dbbmin, double *dbbmax,
-                                                        int *kdiv, const int *gate, int qcap)
+                                                        int *kdiv, const int *gate, int qcap, QWide wide)
 {
   if (gate && !*gate) return;
   __shared__ int s_wave[16];
@@ -358,11 +368,23 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
   double rkmax = 0.0;
   int kd = 0;
   for (int k = 0; k < d.ndim; k++) { const double ext = dbbmax[n*3 + k] - dbbmin[n*3 + k]; if (ext > rkmax) { rkmax = ext; kd = k; } }
-  for (int p = first + tid; p < first + cnt; p += nt) keys[p] = d.f[D_RX + kd][ids[p]];
+  if (!wide.st) for (int p = first + tid; p < first + cnt; p += nt) keys[p] = d.f[D_RX + kd][ids[p]];
   __syncthreads();
   int left = first, right = first + cnt - 1;
   const int jpivot = first + cnt/2;
   double rpivot = dbbmin[n*3 + kd];
+  // the wide passes (k_qw_*) have narrowed the range (as a rule to what fits the LDS buffers; a range of many equal
+  // coordinates, which the reference's quick-select peels one element per pass, is handed over as it is after a few dozen
+  // passes) or finished it: go on from their state, in their buffer, and copy what was left of the range to `ids` at the end
+  int *const ids_out = ids;
+  bool wconv = false;
+  int wleft = 0, wright = -1;
+  if (wide.st) {
+    const QSel S = wide.st[blockIdx.x];
+    left = S.left; right = S.right; rpivot = S.rpiv; wconv = S.conv != 0;
+    wleft = S.left; wright = S.conv ? S.left - 1 : S.right;
+    keys = S.cur ? wide.k1 : wide.k0; ids = S.cur ? wide.i1 : wide.i0;
+  }
   // block-wide: exclusive prefix of a flag over the threads, and the total
   auto scan = [&](bool f, int &pre) -> int {
     const unsigned long long m = __ballot(f);
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
     }
     return true;
   };
-  if (cnt > 0) {
+  if (cnt > 0 && !wconv) {
     bool converged = false;
     // ---- ranges larger than the LDS buffers: block steps on the global arrays
     while (right - left + 1 > qcap) {
@@ -525,6 +547,10 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
       for (int r = tid; r < m0; r += nt) { keys[base + r] = s_qk[cur][r]; ids[base + r] = s_qi[cur][r]; }
     }
   }
+  if (wide.st) {
+    __syncthreads();
+    for (int p = wleft + tid; p <= wright; p += nt) ids_out[p] = ids[p];
+  }
   if (tid == 0) {
     const int c1 = 2*n + 1, c2 = 2*n + 2;
     for (int k = 0; k < 3; k++) {
@@ -533,6 +559,185 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
     }
     kdiv[n] = kd;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wide quick-select passes: the top levels of an exact-mode build (every build of a sink run).  One workgroup per cell
+// walks a range of a million elements in two thousand dependent block steps per pass (37 of the 77 ms of a 2 000 000
+// particle sink step); the closed form of a Lomuto pass (above) has no such dependence, so here the WHOLE DEVICE does one
+// pass of every cell of a level at a time: count "<= pivot" per block (k_qw_count), prefix over the blocks and the pass's
+// outcome (k_qw_scan), ranks (k_qw_rank), scatter / chain gather into the other buffer (k_qw_gather).  Element for element
+// what k_qselect_level's block steps - and the reference's serial loop - produce, including the pivot's trip to the end of
+// the range and back (done virtually: a(q) below).  Positions that leave the range are final and go straight to `out`;
+// when a range fits a workgroup's LDS, k_qselect_level finishes it from the state left here.
+// ------------------------------------------------------------------------------------------------
+#define GH_QW_BLOCK 1024
+struct QWArgs {
+  QSel *st_cur, *st_next;            // state read by this pass / written for the next one
+  double *k[2]; int *i[2];           // the two buffers (keys, ids)
+  int *rk;                           // "<=" rank of every position of the pass
+  int *blkcnt, *blkfirst, *blkpre;   // per (cell, block)
+  int *out;                          // final ids
+  int nb, level, qcap;
+};
+
+__global__ void k_qw_init(DevicePtrs d, QWArgs a, const int *ids, const double *dbbmin, const double *dbbmax)
+{
+  const int c = blockIdx.y, n = (1 << a.level) - 1 + c;
+  const int first = d.cfirst[n], cnt = d.cN[n];
+  double rkmax = 0.0; int kd = 0;
+  for (int k = 0; k < d.ndim; k++) { const double ext = dbbmax[n*3 + k] - dbbmin[n*3 + k]; if (ext > rkmax) { rkmax = ext; kd = k; } }
+  const int q = blockIdx.x*blockDim.x + threadIdx.x;
+  if (q < cnt) { const int id = ids[first + q]; a.i[0][first + q] = id; a.k[0][first + q] = d.f[D_RX + kd][id]; }
+  if (q == 0) {
+    QSel S;
+    S.left = first; S.right = first + cnt - 1; S.cur = 0; S.conv = 0;
+    S.done = cnt <= a.qcap ? 1 : 0;
+    S.f0 = S.nb4 = S.jguess = S.none = 0; S.nleft = S.left; S.nright = S.right; S.nconv = 0;
+    S.rpiv = dbbmin[n*3 + kd];
+    a.st_cur[c] = S;
+  }
+}
+
+// a(q): the range as the pass sees it - the pivot guess (middle element) has changed places with the last element
+__device__ __forceinline__ double qw_key(const double *A, int q, int jg0, int hi) { return A[q == jg0 ? hi : q]; }
+__device__ __forceinline__ int qw_id(const int *Ai, int q, int jg0, int hi) { return Ai[q == jg0 ? hi : q]; }
+
+__global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_count(QWArgs a)
+{
+  __shared__ int s_c[GH_QW_BLOCK/64], s_f[GH_QW_BLOCK/64];
+  const int c = blockIdx.y;
+  const QSel S = a.st_cur[c];
+  if (S.done) return;
+  const int lo = S.left, hi = S.right;
+  const int q = lo + blockIdx.x*GH_QW_BLOCK + threadIdx.x;
+  if (lo + (int) blockIdx.x*GH_QW_BLOCK >= hi) return;
+  const double *A = a.k[S.cur];
+  const int jg0 = (lo + hi)/2;
+  const double rp = A[jg0];
+  const bool in = q < hi;
+  const bool le = in && qw_key(A, q, jg0, hi) <= rp;
+  const unsigned long long m = __ballot(le), g = __ballot(in && !le);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_c[wv] = __popcll(m); s_f[wv] = g ? q + (__ffsll((long long) g) - 1) : 0x7fffffff; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int cnt = 0, f = 0x7fffffff;
+    for (int w = 0; w < GH_QW_BLOCK/64; w++) { cnt += s_c[w]; f = min(f, s_f[w]); }
+    a.blkcnt[(size_t) c*a.nb + blockIdx.x] = cnt; a.blkfirst[(size_t) c*a.nb + blockIdx.x] = f;
+  }
+}
+
+// one workgroup per cell: prefix over the blocks' counts, outcome of the pass, the state of the next pass
+__global__ __launch_bounds__(1024) void k_qw_scan(DevicePtrs d, QWArgs a)
+{
+  __shared__ int s_w[16], s_fw[16];
+  const int c = blockIdx.x, n = (1 << a.level) - 1 + c;
+  QSel S = a.st_cur[c];
+  if (S.done) { if (threadIdx.x == 0) a.st_next[c] = S; return; }
+  const int lo = S.left, hi = S.right;
+  const int nbl = (hi - lo + GH_QW_BLOCK - 1)/GH_QW_BLOCK;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int run = 0, f0 = 0x7fffffff;
+  for (int b0 = 0; b0 < nbl; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    const int v = b < nbl ? a.blkcnt[(size_t) c*a.nb + b] : 0;
+    if (b < nbl) f0 = min(f0, a.blkfirst[(size_t) c*a.nb + b]);
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int wpre = 0, tot = 0;
+    for (int w = 0; w < 16; w++) { if (w < wv) wpre += s_w[w]; tot += s_w[w]; }
+    if (b < nbl) a.blkpre[(size_t) c*a.nb + b] = run + wpre + inc - v;
+    run += tot;
+    __syncthreads();
+  }
+  for (int off = 32; off > 0; off >>= 1) f0 = min(f0, __shfl_xor(f0, off, 64));
+  if (lane == 0) s_fw[wv] = f0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < 16; w++) f0 = min(f0, s_fw[w]);
+    const int tot_le = run;
+    const double *A = a.k[S.cur];
+    const int jpivot = d.cfirst[n] + d.cN[n]/2;
+    S.rpiv = A[(lo + hi)/2];
+    S.none = f0 == 0x7fffffff ? 1 : 0;
+    if (S.none) { S.f0 = hi; S.nb4 = hi - lo; S.jguess = hi; }
+    else { S.f0 = f0; S.nb4 = f0 - lo; S.jguess = f0 + (tot_le - S.nb4); }
+    S.nleft = lo; S.nright = hi; S.nconv = 0;
+    if (S.jguess < jpivot) S.nleft = S.jguess + 1;
+    else if (S.jguess > jpivot) S.nright = S.jguess - 1;
+    else S.nconv = 1;
+    a.st_cur[c] = S;
+    QSel T = S;
+    T.left = S.nleft; T.right = S.nright; T.cur = S.cur ^ 1; T.conv = S.nconv;
+    T.done = (S.nconv || S.nright - S.nleft + 1 <= a.qcap) ? 1 : 0;
+    a.st_next[c] = T;
+  }
+}
+
+__global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_rank(QWArgs a)
+{
+  __shared__ int s_c[GH_QW_BLOCK/64];
+  const int c = blockIdx.y;
+  const QSel S = a.st_cur[c];
+  if (S.done || S.none) return;
+  const int lo = S.left, hi = S.right;
+  if (lo + (int) blockIdx.x*GH_QW_BLOCK >= hi) return;
+  const int q = lo + blockIdx.x*GH_QW_BLOCK + threadIdx.x;
+  const double *A = a.k[S.cur];
+  const int jg0 = (lo + hi)/2;
+  const double rp = S.rpiv;
+  const bool le = q < hi && qw_key(A, q, jg0, hi) <= rp;
+  const unsigned long long m = __ballot(le);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_c[wv] = __popcll(m);
+  __syncthreads();
+  int pre = a.blkpre[(size_t) c*a.nb + blockIdx.x];
+  for (int w = 0; w < wv; w++) pre += s_c[w];
+  // "<=" elements: inclusive count of "<=" in [lo, q]; "> pivot" elements: -1 (the chains of k_qw_gather stop there, and
+  // one 4-byte word per hop is all they read)
+  if (q < hi) a.rk[q] = le ? pre + __popcll(m & ((2ull << lane) - 1ull)) : -1;
+}
+
+__global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_gather(QWArgs a)
+{
+  const int c = blockIdx.y;
+  const QSel S = a.st_cur[c];
+  if (S.done) return;
+  const int lo = S.left, hi = S.right;
+  const int q = lo + blockIdx.x*GH_QW_BLOCK + threadIdx.x;
+  if (q > hi) return;
+  const double *A = a.k[S.cur]; const int *Ai = a.i[S.cur];
+  double *B = a.k[S.cur ^ 1]; int *Bi = a.i[S.cur ^ 1];
+  const int jg0 = (lo + hi)/2;
+  const double rp = S.rpiv;
+  // a position that stays in the range goes to the other buffer, one that leaves it is final
+  auto put = [&](int p, double key, int id) {
+    if (!S.nconv && p >= S.nleft && p <= S.nright) { B[p] = key; Bi[p] = id; }
+    else a.out[p] = id;
+  };
+  if (q == hi) { put(S.jguess, rp, Ai[jg0]); return; }       // the pivot lands between the two sides
+  const double aq = qw_key(A, q, jg0, hi);
+  const int iq = qw_id(Ai, q, jg0, hi);
+  if (S.none || q < S.f0) { put(q, aq, iq); return; }
+  int cd = a.rk[q];
+  if (cd >= 0) put(S.f0 + (cd - S.nb4) - 1, aq, iq);
+  if (q >= S.jguess) {
+    int src = q;
+    while (cd >= 0) { src = S.f0 + (cd - S.nb4) - 1; cd = a.rk[src]; }
+    put(q == S.jguess ? hi : q, qw_key(A, src, jg0, hi), qw_id(Ai, src, jg0, hi));            // (the element at jguess changes places with the pivot)
+  }
+}
+
+__global__ void k_qw_pending(const QSel *st, int ncells, int *out)
+{
+  int n = 0;
+  for (int c = threadIdx.x; c < ncells; c += blockDim.x) n += st[c].done ? 0 : 1;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
 
 __global__ void k_tie_reset(int *t) { t[1] |= t[0]; t[0] = 0; }
@@ -556,6 +761,9 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
   DevicePtrs d = gh_dev(ctx);
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(k_qsel_init, dim3(cdiv(N, 256)), dim3(256), 0, s, d, ctx->qs_ids, gate);
+  // levels whose cells hold more than `wide_min` elements run their passes device-wide (ungated builds only: the host reads a
+  // "cells still going" word between batches of passes)
+  const int wide_min = getenv("GH_QSEL_WIDE_MIN") ? atoi(getenv("GH_QSEL_WIDE_MIN")) : 16384;
   for (int l = 0; l < ctx->ltot; l++) {
     int mx = 1;
     for (int j = 0; j < (1 << l); j += std::max(1, (1 << l)/64)) mx = std::max(mx, ctx->h_cN[(1 << l) - 1 + j]);   // cells of a level differ by at most 1
@@ -563,7 +771,52 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
     int bs = 64;
     while (bs < mx && bs < 1024) bs <<= 1;
     const int qcap = std::min(std::max(mx, 2), GH_QCAP);
-    hipLaunchKernelGGL(k_qselect_level, dim3(1 << l), dim3(bs), (size_t) 28*qcap, s, d, l, ctx->qs_ids, ctx->qs_keys, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, gate, qcap);
+    QWide wide = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!gate && mx > wide_min && mx > GH_QCAP && wide_min > 0) {
+      const int ncells = 1 << l;
+      if (!ctx->qw_k[0]) {
+        for (int b = 0; b < 2; b++) {
+          GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_k[b], sizeof(double)*(size_t) ctx->Ncap));
+          GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_i[b], sizeof(int)*(size_t) ctx->Ncap));
+        }
+        GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_rk, sizeof(int)*(size_t) ctx->Ncap));
+        // per (cell, block) words: at most Ncap/1024 + one per cell; states: two per cell of the deepest wide level
+        ctx->qw_words = (size_t) ctx->Ncap/GH_QW_BLOCK + 2*(size_t) (ctx->Ncap/std::max(wide_min, 1) + 2) + 1024;
+        GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_blk, sizeof(int)*3*ctx->qw_words));
+        GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_st, sizeof(QSel)*2*ctx->qw_words));
+      }
+      QWArgs a;
+      a.k[0] = ctx->qw_k[0]; a.k[1] = ctx->qw_k[1]; a.i[0] = ctx->qw_i[0]; a.i[1] = ctx->qw_i[1];
+      a.rk = ctx->qw_rk; a.out = ctx->qs_ids;
+      a.nb = cdiv(mx, GH_QW_BLOCK); a.level = l; a.qcap = GH_QCAP;
+      if ((size_t) a.nb*ncells > ctx->qw_words || (size_t) ncells > ctx->qw_words) return gh_fail(ctx, GH_ERR_CAPACITY, "exact tree build: wide quick-select scratch too small");
+      a.blkcnt = ctx->qw_blk; a.blkfirst = ctx->qw_blk + ctx->qw_words; a.blkpre = ctx->qw_blk + 2*ctx->qw_words;
+      QSel *st[2] = {(QSel*) ctx->qw_st, (QSel*) ctx->qw_st + ctx->qw_words};
+      int par = 0;
+      a.st_cur = st[0]; a.st_next = st[1];
+      hipLaunchKernelGGL(k_qw_init, dim3(a.nb, ncells), dim3(GH_QW_BLOCK), 0, s, d, a, ctx->qs_ids, ctx->dbbmin, ctx->dbbmax);
+      int *pending = ctx->d_blk + 18;
+      // (8 rounds of 8 passes: a range still wider than the LDS buffers after that is one with many equal coordinates, which
+      //  every pass shortens by a single element; k_qselect_level's in-place block steps take it from there)
+      for (int round = 0; round < 8; round++) {
+        for (int pass = 0; pass < 8; pass++) {
+          a.st_cur = st[par]; a.st_next = st[par ^ 1];
+          hipLaunchKernelGGL(k_qw_count, dim3(a.nb, ncells), dim3(GH_QW_BLOCK), 0, s, a);
+          hipLaunchKernelGGL(k_qw_scan, dim3(ncells), dim3(1024), 0, s, d, a);
+          hipLaunchKernelGGL(k_qw_rank, dim3(a.nb, ncells), dim3(GH_QW_BLOCK), 0, s, a);
+          hipLaunchKernelGGL(k_qw_gather, dim3(a.nb, ncells), dim3(GH_QW_BLOCK), 0, s, a);
+          par ^= 1;
+        }
+        GH_CHECK(ctx, hipMemsetAsync(pending, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_qw_pending, dim3(1), dim3(256), 0, s, st[par], ncells, pending);
+        int np = 0;
+        GH_CHECK(ctx, hipMemcpyAsync(&np, pending, sizeof(int), hipMemcpyDeviceToHost, s));
+        GH_CHECK(ctx, hipStreamSynchronize(s));
+        if (np == 0) break;
+      }
+      wide.st = st[par]; wide.k0 = a.k[0]; wide.k1 = a.k[1]; wide.i0 = a.i[0]; wide.i1 = a.i[1];
+    }
+    hipLaunchKernelGGL(k_qselect_level, dim3(1 << l), dim3(bs), (size_t) 28*qcap, s, d, l, ctx->qs_ids, ctx->qs_keys, ctx->dbbmin, ctx->dbbmax, ctx->kdiv, gate, qcap, wide);
   }
   hipLaunchKernelGGL(k_copy_if, dim3(cdiv(N, 256)), dim3(256), 0, s, ctx->qs_ids, perm_out, N, gate);
   return GH_OK;

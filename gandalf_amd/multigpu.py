@@ -184,6 +184,34 @@ class RcclOps:
             self.handle = C.c_void_p()
 
 
+def _selftest_ops(ops_ptr, rank, world, device):
+    """one all-gather and one ragged all-to-all through a gh_comm_ops table on known data; "" if both came out right"""
+    ops = C.cast(ops_ptr, C.POINTER(_OpsStruct)).contents
+    dev = torch.device("cuda", device)
+    stream = torch.cuda.current_stream(dev)
+    send = torch.full((4,), rank + 1, dtype=torch.int64, device=dev)
+    recv = torch.zeros(4*world, dtype=torch.int64, device=dev)
+    stream.synchronize()
+    if ops.allgather(ops.user, send.data_ptr(), recv.data_ptr(), 32, stream.cuda_stream) != 0:
+        return "all-gather returned an error"
+    stream.synchronize()
+    if not torch.equal(recv.cpu(), torch.arange(1, world + 1, dtype=torch.int64).repeat_interleave(4)):
+        return "all-gather delivered wrong data"
+    # rank r sends (d + 1) words of value 100 r + d to rank d
+    sb = [(d + 1)*8 for d in range(world)]
+    rb = [(rank + 1)*8]*world
+    out = torch.cat([torch.full((d + 1,), 100*rank + d, dtype=torch.int64) for d in range(world)]).to(dev)
+    inn = torch.zeros((rank + 1)*world, dtype=torch.int64, device=dev)
+    stream.synchronize()
+    if ops.alltoallv(ops.user, out.data_ptr(), (C.c_int64*world)(*sb), inn.data_ptr(), (C.c_int64*world)(*rb), stream.cuda_stream) != 0:
+        return "all-to-all returned an error"
+    stream.synchronize()
+    want = torch.cat([torch.full((rank + 1,), 100*s + rank, dtype=torch.int64) for s in range(world)])
+    if not torch.equal(inn.cpu(), want):
+        return "all-to-all delivered wrong data"
+    return ""
+
+
 class DistributedRunner:
     """setup() / steps(n) of a gandalf_amd.host.Simulation on `world` ranks (rank r owns top-level KD cell r).
     world == 1 is the plain single-GPU run."""
@@ -206,7 +234,27 @@ class DistributedRunner:
                 import sys
                 sys.stderr.write("gandalf_amd: native RCCL transport unavailable (%s): using torch.distributed\n" % err.decode())
                 self.transport = "torch"
-        if self.world > 1 or self.transport == "rccl":
+        if self.transport == "rccl" and self.world > 1:
+            # bring the native transport up and try both collectives once on known data; the verdict is reduced over the
+            # ranks (torch's process group), so either every rank steps on RCCL inside the library or every rank takes the
+            # torch.distributed callbacks - never a mixture, never a failure in the middle of the stepped loop
+            ok, why = 1, ""
+            try:
+                self.ops = RcclOps(self.rank, self.world, self.device)
+                why = _selftest_ops(self.ops.ptr, self.rank, self.world, self.device)
+                ok = 0 if why else 1
+            except Exception as e:      # noqa: BLE001
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", self.device) if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                import sys
+                if why:
+                    sys.stderr.write("gandalf_amd: rank %d: native RCCL transport failed its self-test (%s)\n" % (self.rank, why))
+                if self.rank == 0:
+                    sys.stderr.write("gandalf_amd: using torch.distributed for the collectives\n")
+                self.transport, self.ops = "torch", None
+        if self.ops is None and (self.world > 1 or self.transport == "rccl"):
             self.ops = RcclOps(self.rank, self.world, self.device) if self.transport == "rccl" else CommOps("device")
         if self.world > 1:
             self.sim.init_comm(self.rank, self.world, self.ops.ptr)

@@ -287,8 +287,9 @@ typedef struct gh_comm_ops {
                    void *hip_stream);
 } gh_comm_ops;
 /* call after gh_create and before gh_upload_particles.  nranks = 1 (ops may be NULL) is the single-GPU default.
- * Multi-rank runs: open or periodic boundaries, global timestep, geometric MAC, constant-alpha viscosity, tree rebuilt every step;
- * anything else is refused here (GH_ERR_UNSUPPORTED).  gh_upload_particles then takes the WHOLE initial condition on
+ * Multi-rank runs: open or periodic boundaries, global or block timesteps, sinks and stars (gh_hybrid_setup / gh_hybrid_step are
+ * collective calls then; the star context is the same on every rank), geometric MAC, constant-alpha viscosity, tree rebuilt
+ * every step; anything else is refused here (GH_ERR_UNSUPPORTED).  gh_upload_particles then takes the WHOLE initial condition on
  * every rank and keeps this rank's share; gh_download / gh_upload_field touch only this rank's own particles.
  * gh_build_tree, gh_update_density, gh_update_*_forces, gh_setup and gh_step are collective calls from then on. */
 int gh_comm_init(gh_ctx *ctx, int rank, int nranks, const gh_comm_ops *ops);

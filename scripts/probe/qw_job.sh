@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "wide_quickselect or sinks_match" > gpurun_out/qw_tests.log 2>&1
+tail -25 gpurun_out/qw_tests.log

@@ -31,8 +31,10 @@ if world > 1:
 torch.cuda.set_device(0)
 sim = Simulation(os.path.join(sys.argv[1], "tests", "params", case + ".dat"), **over)
 sim.generate_ic()
-run = DistributedRunner(sim, rank, world)
+run = DistributedRunner(sim, rank, world, transport=os.environ.get("GH_TEST_TRANSPORT", "torch"))
 run.setup()
+if os.environ.get("GH_TEST_TRANSPORT"):
+    print("TRANSPORT rank %d: %s" % (rank, run.transport), flush=True)
 run.steps(nsteps)
 fields = ["r", "v", "h", "rho", "a", "u", "dudt", "gpot"] + (["level", "levelneib", "nstep", "nlast"] if int(sim.get_param("Nlevels")) > 1 else [])
 sinks = int(sim.get_param("sink_particles")) == 1
@@ -62,17 +64,22 @@ def _port():
     return p
 
 
-def _run(tmp_path, case, world, nsteps, over):
+def _run(tmp_path, case, world, nsteps, over, extra_env=None, timeout=900):
     wf = tmp_path/"worker.py"
     wf.write_text(WORKER)
     out = str(tmp_path/("w%d.npz" % world))
     port = _port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(wf), ROOT, case, out, str(nsteps), json.dumps(over)], env=env))
-    for p in procs:
-        assert p.wait(timeout=900) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=timeout) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     return dict(np.load(out))
 
 
@@ -299,9 +306,22 @@ side.synchronize()
 assert rc == 0, ops.error()
 assert torch.equal(c[:777], a[:777]) and float(c[777:].abs().sum()) == 0.0
 assert ops.counters() == {"allgather": 1, "alltoallv": 1, "bytes": 8000 + 777*8}
+from gandalf_amd.multigpu import _selftest_ops
+assert _selftest_ops(ops.ptr, 0, 1, 0) == ""          # the check DistributedRunner makes before it trusts the transport
 ops.close()
 print("RCCL_NATIVE_OK")
 '''
+
+
+def test_native_transport_falls_back_on_all_ranks_together(tmp_path):
+    """bench.py --gpus N asks for the library's own RCCL transport.  DistributedRunner brings it up, tries both collectives
+    on known data and reduces the verdict over the ranks: if it cannot work on ANY rank, EVERY rank takes the torch.distributed
+    callbacks instead, before the first collective of the run.  Two ranks on ONE GPU is such a case (RCCL refuses a second rank
+    on a device): the run must go through on the fallback and equal the one-rank run."""
+    one = _run(tmp_path, "plummer_4k", 1, 2, {})
+    two = _run(tmp_path, "plummer_4k", 2, 2, {}, extra_env={"GH_TEST_TRANSPORT": "rccl"}, timeout=300)
+    for k in ("h", "rho", "a", "gpot"):
+        assert _relerr(one[k], two[k]) <= 1e-13, (k, _relerr(one[k], two[k]))
 
 
 def test_native_rccl_ops(tmp_path):

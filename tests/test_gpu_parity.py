@@ -399,6 +399,32 @@ def test_sinks_match_reference(case):
     assert relerr(nb.download("dt_internal"), g["final_star_dt_internal"]) < 1e-8
 
 
+@pytest.mark.parametrize("n,ties", [(70001, False), (70001, True), (300000, True)])
+def test_wide_quickselect_passes_equal_the_block_steps(n, ties, monkeypatch):
+    """Exact-mode tree build (the reference's quick-select order, every build of a sink run): cells wider than 16 384 elements
+    run their Lomuto passes device-wide in closed form (k_qw_*, tree.hip); smaller ones - and, with GH_QSEL_WIDE_MIN=0, all -
+    take the one-workgroup-per-cell block steps that the sink fixtures pin against the reference.  Both must leave the SAME
+    permutation and cell boxes: random positions, and positions rounded to a grid (thousands of equal coordinates: the ties
+    whose order is the whole point); also with every level above 2 048 elements forced wide."""
+    rng = np.random.default_rng(11)
+    r = rng.standard_normal((n, 3))
+    if ties:
+        r = np.round(r, 1 if n < 100000 else 2)
+    m = np.full(n, 1.0/n); h = np.full(n, 0.1)
+    out = {}
+    for tag, wide in (("block", "0"), ("wide", "16384"), ("wide2k", "2049")):
+        monkeypatch.setenv("GH_QSEL_WIDE_MIN", wide)
+        sim, _ = make("bb_sinks_8k")
+        sim.upload(r, m, h, v=np.zeros((n, 3)), u=np.ones(n))
+        sim.build_tree()
+        t = sim.export_tree()
+        out[tag] = (t["order"].copy(), t["bbmin"].copy(), t["bbmax"].copy())
+    assert len(np.unique(out["block"][0])) == n
+    for tag in ("wide", "wide2k"):
+        assert np.array_equal(out["block"][0], out[tag][0]), tag
+        assert np.array_equal(out["block"][1], out[tag][1]) and np.array_equal(out["block"][2], out[tag][2]), tag
+
+
 def test_point_gather_query_matches_brute_force():
     """gh_gather_neighbours_at (NeighbourSearch::GetGatherNeighbourList(rp, rsearch, ...), Tree.cpp:208-280): the set
     of particles within rsearch of arbitrary points, against a brute-force distance test; overflow answer -1"""
