@@ -82,6 +82,7 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, std::string(where) + ": multi-GPU: a median split separates particles with equal coordinates (lattice "
                      "initial conditions?) - the reference's quick-select tie order is reproduced on one rank only");
   }
+  if (ctx->cfg.self_gravity && !flags) { const int rc = gh_grav_list_headroom(ctx); if (rc) return rc; }
   if (flags) {
     GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
     std::string m = std::string(where) + ":";
@@ -332,6 +333,7 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
   ctx->rebuild_tree = true;
   ctx->exact_armed = false;
+  ctx->glist_checked = -1;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
   GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*24));

@@ -174,6 +174,7 @@ struct gh_ctx {
   int *gl_cells = nullptr, *gl_dirl = nullptr, *gl_hydl = nullptr, *gl_len = nullptr, *gl_gcells = nullptr, *gl_glen = nullptr;
   size_t glist_leaves = 0;
   int glist_caps = 0;
+  int glist_mul[3] = {1, 1, 1}, glist_cap[3] = {0, 0, 0}, glist_max[3] = {0, 0, 0}, glist_checked = -1;   // headroom tracking (gh_grav_list_headroom)
 
   // candidate range lists of the split density path (density.hip)
   void *dl_rl = nullptr; int *dl_rlen = nullptr; int dl_groups = 0;
@@ -278,6 +279,7 @@ int gh_update_hmax_impl(gh_ctx *ctx);
 int gh_density_impl(gh_ctx *ctx, bool count, bool redo_only = false);   // redo_only: just the groups a deferred miss check found
 int gh_hydro_forces_impl(gh_ctx *ctx, bool count);
 int gh_all_forces_impl(gh_ctx *ctx, bool count);
+int gh_grav_list_headroom(gh_ctx *ctx);   // longest interaction lists -> capacities of the next pass (called where the host synchronises anyway)
 int gh_grav_lists_impl(gh_ctx *ctx, bool count);   // two-kernel gravity with interaction lists in HBM
 int gh_zero_acc_impl(gh_ctx *ctx);
 int gh_kdk_advance_impl(gh_ctx *ctx, int n, double t, double timestep);

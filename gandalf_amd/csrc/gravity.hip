@@ -965,6 +965,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // ================================================================================================
 // host
 // ================================================================================================
+// Headroom of the per-leaf interaction lists.  A list that overflows makes the evaluation kernel stand back; the fused
+// kernel (forces.hip) then does the call - but it has neither quadrupoles nor relative MACs, where an overflow is an error
+// (GH_ERR_CAPACITY).  So the longest list of every kind is looked at whenever the host synchronises anyway
+// (gh_sync_collect): one that has used more than half its capacity gets twice the room from the next pass on (up to 8 x:
+// 288 GB of HBM hold it), long before a run drifts into an overflow.
+__global__ __launch_bounds__(256) void k_list_max(const int *len, int nleaf, int *out)
+{
+  int m[3] = {0, 0, 0};
+  for (int l = blockIdx.x*blockDim.x + threadIdx.x; l < nleaf; l += gridDim.x*blockDim.x)
+    for (int k = 0; k < 3; k++) m[k] = max(m[k], len[(size_t) l*3 + k]);
+  for (int k = 0; k < 3; k++) {
+    for (int off = 32; off > 0; off >>= 1) m[k] = max(m[k], __shfl_xor(m[k], off, 64));
+    if ((threadIdx.x & 63) == 0 && m[k] > 0) atomicMax(&out[k], m[k]);
+  }
+}
+int gh_grav_list_headroom(gh_ctx *ctx)
+{
+  if (!ctx->gl_len || ctx->glist_leaves == 0 || ctx->glist_cap[0] == 0 || getenv("GH_GRAV_CAPS")) return GH_OK;
+  if (ctx->Nsteps - ctx->glist_checked < 8 && ctx->glist_checked >= 0) return GH_OK;      // lists grow slowly: every eighth step is often enough
+  ctx->glist_checked = ctx->Nsteps;
+  int *out = ctx->gl_len + ctx->glist_leaves*3 + 1;           // three spare words behind the fallback flag
+  GH_CHECK(ctx, hipMemsetAsync(out, 0, 3*sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_list_max, dim3(64), dim3(256), 0, ctx->stream, ctx->gl_len, (int) ctx->glist_leaves, out);
+  int mx[3] = {0, 0, 0};
+  GH_CHECK(ctx, hipMemcpyAsync(mx, out, sizeof(mx), hipMemcpyDeviceToHost, ctx->stream));
+  GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; k++) {
+    ctx->glist_max[k] = mx[k];
+    if (2*mx[k] > ctx->glist_cap[k] && ctx->glist_mul[k] < 8) ctx->glist_mul[k] *= 2;
+  }
+  if (getenv("GH_GRAV_DEBUG"))
+    fprintf(stderr, "[lists] step %d longest %d %d %d capacity %d %d %d next x%d x%d x%d\n", ctx->Nsteps, mx[0], mx[1], mx[2],
+            ctx->glist_cap[0], ctx->glist_cap[1], ctx->glist_cap[2], ctx->glist_mul[0], ctx->glist_mul[1], ctx->glist_mul[2]);
+  return GH_OK;
+}
+
 int gh_grav_lists_impl(gh_ctx *ctx, bool count)
 {
   // capacities per leaf: accepted cells, direct-only leaves, hydro-candidate leaves
@@ -973,10 +1009,17 @@ int gh_grav_lists_impl(gh_ctx *ctx, bool count)
   // list every other leaf while that is cheap (<= 8192 leaves x 2048 entries x 4 B = 64 MB)
   if (ctx->gtot <= 8192) cap_d = std::max(256, std::min(ctx->gtot, 2048));
   const int cap_g = 4096;
+  if (const char *e = getenv("GH_GRAV_CAPS0")) {      // test hook: starting capacities (the headroom rule below still applies)
+    int a = 0, b = 0, c = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { cap_c = a; cap_d = b; cap_h = c; }
+  }
+  // lists that came within a factor two of their capacity at the last look (gh_grav_list_headroom) get twice the room
+  cap_c *= ctx->glist_mul[0]; cap_d *= ctx->glist_mul[1]; cap_h *= ctx->glist_mul[2];
   if (const char *e = getenv("GH_GRAV_CAPS")) {       // test hook: tiny capacities force the overflow fallback
     int a = 0, b = 0, c = 0;
     if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { cap_c = a; cap_d = b; cap_h = c; }
   }
+  ctx->glist_cap[0] = cap_c; ctx->glist_cap[1] = cap_d; ctx->glist_cap[2] = cap_h;
   const size_t nleaf = (size_t) ctx->gtot;
   if (ctx->glist_leaves != nleaf || ctx->glist_caps != cap_c + 7*cap_d + 31*cap_h) {
     for (void *p : {(void*) ctx->gl_cells, (void*) ctx->gl_dirl, (void*) ctx->gl_hydl, (void*) ctx->gl_len}) if (p) (void) hipFree(p);

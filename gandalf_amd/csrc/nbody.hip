@@ -412,6 +412,8 @@ extern "C" int gh_hybrid_step(gh_ctx *gas, gh_nbody *nb, int nsteps, double *t_o
     return GH_OK;
   }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0 || nsteps < 0) return GH_ERR_INVALID;
+  // (several ranks: stars go through the sink / block-timestep path above, which is the one the multi-rank tests exercise)
+  if (gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs with a global timestep and no sinks: one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
   const int64_t Ns = nb->N;
   const int nd = nb->ndim;
@@ -475,6 +477,7 @@ extern "C" int gh_hybrid_setup(gh_ctx *gas, gh_nbody *nb, int initial_h_provided
     return GH_OK;
   }
   if (!gas || !nb || nb->N <= 0 || gas->N <= 0) return GH_ERR_INVALID;
+  if (gas->nranks > 1) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs with a global timestep and no sinks: one rank");
   if (!gas->cfg.self_gravity) return gh_fail(gas, GH_ERR_UNSUPPORTED, "hybrid runs need self_gravity = 1");
   const int64_t Ns = nb->N;
   const int nd = nb->ndim;

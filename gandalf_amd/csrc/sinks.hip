@@ -683,8 +683,9 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
   std::vector<int> head((size_t) ns + 1);
   GH_CHECK(ctx, hipMemcpyAsync(head.data(), W.d_i, sizeof(int)*(size_t) (ns + 1), hipMemcpyDeviceToHost, ctx->stream));
   GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  const int np = head[0];
-  if (np > cap) return gh_fail(ctx, GH_ERR_CAPACITY, "sink accretion: more than N/4 particles inside sink radii");
+  // (a rank whose pair buffer overflowed says so in its block of the gather below: all ranks stop together)
+  const bool toomany = head[0] > cap;
+  const int np = toomany ? 0 : head[0];
   std::vector<int2> pairs((size_t) np);
   if (np) GH_CHECK(ctx, hipMemcpy(pairs.data(), d_pairs, sizeof(int2)*(size_t) np, hipMemcpyDeviceToHost));
   // a particle accretes to the last sink that holds it; per sink the list in tree order (= the reference's neiblist order)
@@ -700,14 +701,17 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
   std::vector<std::pair<int, int> > who;
   std::vector<size_t> off((size_t) ns + 1, 0);
   {
-    std::vector<double> blk((size_t) 2*ns + myrows.size());
+    std::vector<double> blk((size_t) 2*ns + 1 + myrows.size());
     for (int s = 0; s < ns; s++) { blk[s] = (double) head[1 + s]; blk[ns + s] = (double) lists[s].size(); }
-    std::copy(myrows.begin(), myrows.end(), blk.begin() + 2*ns);
+    blk[2*ns] = toomany ? 1.0 : 0.0;
+    std::copy(myrows.begin(), myrows.end(), blk.begin() + 2*ns + 1);
     std::vector<char> all; std::vector<size_t> sizes;
     if ((rc = gh_dd_gatherv(ctx, blk.data(), sizeof(double)*blk.size(), all, sizes))) return rc;
     const int Wn = ctx->nranks;
     std::vector<const double*> base((size_t) Wn);
     { size_t o = 0; for (int r = 0; r < Wn; r++) { base[r] = (const double*) (all.data() + o); o += sizes[r]; } }
+    for (int r = 0; r < Wn; r++)
+      if (base[r][2*ns] != 0.0) return gh_fail(ctx, GH_ERR_CAPACITY, "sink accretion: more than N/4 particles inside sink radii");
     for (int s = 0; s < ns; s++) ctx->sinks[s].Ngas = 0;
     std::vector<size_t> cursor((size_t) Wn, 0), local((size_t) Wn, 0);      // rows / own-list entries of rank r consumed so far
     for (int s = 0; s < ns; s++) {
@@ -715,7 +719,7 @@ static int sk_accrete(gh_ctx *ctx, SinkScratch &W, gh_host_stars &S, double time
       for (int r = 0; r < Wn; r++) {
         ctx->sinks[s].Ngas += (int) base[r][s];
         const size_t cnt = (size_t) base[r][ns + s];
-        const double *src = base[r] + 2*ns + cursor[r]*SK_ROW;
+        const double *src = base[r] + 2*ns + 1 + cursor[r]*SK_ROW;
         rows.insert(rows.end(), src, src + cnt*SK_ROW);
         for (size_t e = 0; e < cnt; e++) who.push_back(std::make_pair(r, r == ctx->rank ? mine[local[r] + e] : -1));
         cursor[r] += cnt; local[r] += cnt;

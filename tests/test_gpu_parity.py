@@ -3,10 +3,16 @@
 
 Tolerances (SURVEY.md 8d): tree membership and neighbour ids exact; h, rho <= 1e-12 relative;
 forces <= 1e-11 relative to max(|a_i|, mean|a|)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 from conftest import PARAMS, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -423,6 +429,46 @@ def test_wide_quickselect_passes_equal_the_block_steps(n, ties, monkeypatch):
     for tag in ("wide", "wide2k"):
         assert np.array_equal(out["block"][0], out[tag][0]), tag
         assert np.array_equal(out["block"][1], out[tag][1]) and np.array_equal(out["block"][2], out[tag][2]), tag
+
+
+LISTS_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from test_gpu_parity import make, load_golden
+g = load_golden("plummer_4k_quadrupole_passes")
+sim, _ = make("plummer_4k_quadrupole")
+sim.upload(g["in_r"], g["in_m"], g["in_h"], v=g["in_v"], u=g["in_u"])
+sim.setup(initial_h_provided=True)
+sim.step(20)
+np.save(sys.argv[2], sim.download("a"))
+'''
+
+
+def test_interaction_lists_grow_before_they_overflow(tmp_path):
+    """An interaction list that overflows is an error with quadrupole moments or relative MACs (the fused fallback kernel has
+    neither).  The library therefore looks at the longest list of each kind where the host synchronises anyway and doubles
+    the capacity of a kind that is more than half full (gh_grav_list_headroom).  Here: the quadrupole Plummer run with
+    starting capacities 1.5 x its longest lists - the first look must double all three, and nothing else may change."""
+    wf = tmp_path/"lists_worker.py"
+    wf.write_text(LISTS_WORKER)
+
+    def run(tag, env):
+        out = subprocess.run([sys.executable, str(wf), ROOT, str(tmp_path/(tag + ".npy"))], env=dict(os.environ, GH_GRAV_DEBUG="1", **env),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        looks = [[int(x.lstrip("x")) for x in ln.split() if x.lstrip("x").isdigit()] for ln in out.stderr.splitlines() if ln.startswith("[lists]")]
+        return np.load(tmp_path/(tag + ".npy")), looks
+
+    a0, looks0 = run("default", {})
+    assert looks0 and all(lk[-3:] == [1, 1, 1] for lk in looks0)                 # default capacities: ample
+    longest = np.max(np.array([lk[1:4] for lk in looks0]), axis=0)
+    assert longest[0] > 0 and longest[2] > 0                                     # accepted cells, hydro candidates (a 4k sphere has no direct-only leaves)
+    tight = [int(1.5*m) + 1 if m > 0 else 64 for m in longest]
+    a1, looks1 = run("tight", {"GH_GRAV_CAPS0": ",".join(map(str, tight))})
+    want = [2 if m > 0 else 1 for m in longest]
+    assert looks1[0][-3:] == want and looks1[-1][4:7] == [c*w for c, w in zip(tight, want)]
+    assert np.array_equal(a0, a1)
 
 
 def test_point_gather_query_matches_brute_force():
