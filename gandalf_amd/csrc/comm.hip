@@ -262,15 +262,16 @@ __global__ __launch_bounds__(1024) void k_dd_select(DDCell *cells, const DDCand 
     if (rank == want) s_found = e;
   }
   __syncthreads();
+  // equal coordinates on both sides of the split: which of them go left is decided here by particle id, in the
+  // reference by the dynamics of its quick-select (KDTree.cpp:682-750) - reported, see gh_sync_collect
+  if (s_found >= 0) {
+    const DDCand m = entry(s_found);
+    for (int e = threadIdx.x; e < ntot; e += blockDim.x) { const DDCand o = entry(e); if (o.key == m.key && o.id < m.id) atomicOr(tie, 1); }
+  }
   if (threadIdx.x == 0) {
     DDCell w = q;
     const int n = q.node, c1 = 2*n + 1, c2 = 2*n + 2, kd = q.kd;
-    if (s_found >= 0) {
-      const DDCand m = entry(s_found); w.rdiv = m.key; w.rdiv_id = m.id;
-      // equal coordinates on both sides of the split: which of them go left is decided here by particle id, in the
-      // reference by the dynamics of its quick-select (KDTree.cpp:682-750) - reported, see gh_sync_collect
-      for (int e = 0; e < ntot; e++) { const DDCand o = entry(e); if (o.key == m.key && o.id < m.id) { atomicOr(tie, 1); break; } }
-    }
+    if (s_found >= 0) { const DDCand m = entry(s_found); w.rdiv = m.key; w.rdiv_id = m.id; }
     else if (ntot > 0 || q.target > 0) atomicOr(flags, FLAG_DD_SPLIT);       // the bracket lost the median: never expected
     // what next step's speculative split starts from: the median, the axis, and a window that holds ~256 candidates at
     // the density of the final bin (ntot candidates in a bin of width 1/scB)
@@ -438,13 +439,22 @@ __global__ __launch_bounds__(1024) void k_dd_wselect(DDCell *cells, const DDCand
     }
   }
   __syncthreads();
+  // equal coordinates on both sides of the split (see k_dd_select): all threads look, each at its candidates - one thread
+  // walking the gathered blocks entry by entry was 150 us of dependent global loads per level
+  if (s_found >= 0) {
+    const DDCand m = entry(s_found);
+    for (int e = threadIdx.x; e < ntot; e += blockDim.x) {
+      const double ok = inlds ? s_key[e] : entry(e).key;
+      const int oi = inlds ? s_id[e] : entry(e).id;
+      if (ok == m.key && oi < m.id) atomicOr(tie, 1);
+    }
+  }
   if (threadIdx.x == 0) {
     DDCell w = q;
     const int n = q.node, c1 = 2*n + 1, c2 = 2*n + 2, kd = q.kd;
     if (s_found >= 0) {
       const DDCand m = entry(s_found);
       w.rdiv = m.key; w.rdiv_id = m.id;
-      for (int e = 0; e < ntot; e++) { const DDCand o = entry(e); if (o.key == m.key && o.id < m.id) { atomicOr(tie, 1); break; } }     // see k_dd_select
       const double wold = spl_win[n], shift = fabs(m.key - spl_prev[n]);
       double wnew = fmax(4.0*shift, 256.0*wold/(double) ntot);
       wnew = fmin(wnew, 0.25*(dbbmax[n*3 + kd] - dbbmin[n*3 + kd]));
