@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <map>
 #include "SphSimulation.h"
 
@@ -151,16 +152,106 @@ void ReadSerenUnformSnapshotFile(const std::string &filename, Snapshot &s)
   if (!in) throw GandalfError("Truncated snapshot : " + filename);
 }
 
+// ---- SEREN formatted (ASCII) --------------------------------------------------------------------------
+// The same header and arrays as the unformatted file, as text (SimulationIO.hpp:993-1232 write, :601-925 read): scientific
+// notation, floats 18 wide with 10 decimals, integers 2 wide for the five words that open the file and 10 wide after them
+// (formatted_output.h), one header word / one particle per line.  The tag is "SERENASCIIDUMPV2", the precision word 4
+// whatever the build, the header's time words are written as they are (dimensionless runs: outscale = 1).
+static const char *kSerenAsciiTag = "SERENASCIIDUMPV2";
+
+void WriteSerenFormSnapshotFile(const std::string &filename, const Snapshot &s)
+{
+  std::ofstream out(filename.c_str());
+  if (!out) throw GandalfError("Cannot open snapshot file for writing : " + filename);
+  out.setf(std::ios::scientific, std::ios::floatfield);
+  const int nd = s.ndim, N = s.N;
+  int wi = 2;
+  auto pi = [&](long long v) { out << std::setw(wi) << v; };
+  auto pf = [&](double v) { out << std::setw(18) << std::setprecision(10) << v; };
+  struct Arr { const char *id; int t[5]; };
+  const Arr arrs[7] = {{"porig", {1, 1, N, 2, 0}}, {"r", {nd, 1, N, 4, 1}}, {"m", {1, 1, N, 4, 2}}, {"h", {1, 1, N, 4, 1}},
+                       {"v", {nd, 1, N, 4, 4}}, {"rho", {1, 1, N, 4, 6}}, {"u", {1, 1, N, 4, 20}}};
+  const int ndata = N > 0 ? 7 : 0;
+  int idata[50] = {0}, ilpdata[50] = {0}; double rdata[50] = {0.0}, ddata[50] = {0.0};
+  idata[0] = N; idata[1] = 0; idata[4] = N; idata[19] = 0; idata[20] = ndata;
+  ilpdata[0] = s.Noutsnap; ilpdata[1] = s.Nsteps; ilpdata[10] = s.Noutlitesnap;       // (the reference's ilpdata are ints here)
+  rdata[0] = s.h_fac;
+  ddata[0] = s.t; ddata[1] = s.tsnaplast; ddata[2] = s.mmean; ddata[10] = s.tlitesnaplast;
+  out << kSerenAsciiTag << std::endl;
+  pi(4); out << std::endl;
+  for (int k = 0; k < 3; k++) { pi(nd); out << std::endl; }
+  wi = 10;
+  for (int i = 0; i < 50; i++) { pi(idata[i]); out << std::endl; }
+  for (int i = 0; i < 50; i++) { pi(ilpdata[i]); out << std::endl; }
+  for (int i = 0; i < 50; i++) { pf(rdata[i]); out << std::endl; }
+  for (int i = 0; i < 50; i++) { pf(ddata[i]); out << std::endl; }
+  for (int a = 0; a < ndata; a++) out << arrs[a].id << std::endl;
+  for (int a = 0; a < ndata; a++) { for (int j = 0; j < 5; j++) pi(arrs[a].t[j]); out << std::endl; }
+  if (N > 0) {
+    for (int i = 0; i < N; i++) { pi(s.iorig.empty() ? i : s.iorig[i]); out << std::endl; }
+    auto vec = [&](const std::vector<double> &a) { for (int i = 0; i < N; i++) { for (int k = 0; k < nd; k++) pf(a[(size_t) i*nd + k]); out << std::endl; } };
+    auto sca = [&](const std::vector<double> &a) { for (int i = 0; i < N; i++) { pf(a[i]); out << std::endl; } };
+    vec(s.r); sca(s.m); sca(s.h); vec(s.v); sca(s.rho); sca(s.u);
+  }
+}
+
+void ReadSerenFormSnapshotFile(const std::string &filename, Snapshot &s)
+{
+  std::ifstream in(filename.c_str());
+  if (!in) throw GandalfError("Cannot open snapshot file : " + filename);
+  std::string tag;
+  in >> tag;
+  if (tag != kSerenAsciiTag && tag != "SERENASCIIDUMPV3") throw GandalfError("Incorrect format of snapshot file " + filename + ": " + tag);
+  int prec = 0, nd = 0, nd2 = 0, nd3 = 0;
+  in >> prec >> nd >> nd2 >> nd3;
+  if (!in || nd < 1 || nd > 3 || nd2 != nd || nd3 != nd) throw GandalfError("Incorrect no. of dimensions in file : " + filename);
+  long long idata[50], ilpdata[50]; double rdata[50], ddata[50];
+  for (int i = 0; i < 50; i++) in >> idata[i];
+  for (int i = 0; i < 50; i++) in >> ilpdata[i];
+  for (int i = 0; i < 50; i++) in >> rdata[i];
+  for (int i = 0; i < 50; i++) in >> ddata[i];
+  if (!in) throw GandalfError("Truncated snapshot header : " + filename);
+  const long long N = idata[0], Nstar = idata[1], nunit = idata[19], ndata = idata[20];
+  if (Nstar != 0) throw GandalfError("snapshots with stars / sinks are not read on this path : " + filename);
+  if (N < 0 || N > 0x7fffffff || ndata < 0 || ndata > 50 || nunit < 0 || nunit > 50) throw GandalfError("Corrupt snapshot header : " + filename);
+  std::string word;
+  for (int i = 0; i < nunit; i++) in >> word;
+  std::vector<std::string> ids((size_t) ndata);
+  for (int a = 0; a < ndata; a++) in >> ids[a];
+  std::vector<long long> typ((size_t) ndata*5);
+  for (int a = 0; a < ndata; a++) for (int j = 0; j < 5; j++) in >> typ[(size_t) a*5 + j];
+  if (!in) throw GandalfError("Truncated snapshot header : " + filename);
+  s.ndim = nd; s.N = (int) N; s.t = ddata[0]; s.tsnaplast = ddata[1]; s.mmean = ddata[2]; s.tlitesnaplast = ddata[10];
+  s.h_fac = rdata[0]; s.Noutsnap = ilpdata[0]; s.Nsteps = ilpdata[1]; s.Noutlitesnap = ilpdata[10];
+  s.r.assign((size_t) N*nd, 0.0); s.v.assign((size_t) N*nd, 0.0);
+  s.m.assign(N, 0.0); s.h.assign(N, 0.0); s.rho.assign(N, 0.0); s.u.assign(N, 0.0); s.iorig.assign(N, 0);
+  for (int a = 0; a < ndata; a++) {
+    const long long width = typ[(size_t) a*5], ifirst = typ[(size_t) a*5 + 1], ilast = typ[(size_t) a*5 + 2];
+    std::vector<double> *dst = nullptr;
+    if (ids[a] == "r") dst = &s.r; else if (ids[a] == "v") dst = &s.v; else if (ids[a] == "m") dst = &s.m;
+    else if (ids[a] == "h") dst = &s.h; else if (ids[a] == "rho") dst = &s.rho; else if (ids[a] == "u") dst = &s.u;
+    if (ids[a] == "porig") { for (long long i = 0; i < N; i++) in >> s.iorig[i]; }
+    else if (dst) { for (size_t q = 0; q < dst->size(); q++) in >> (*dst)[q]; }      // N x ndim (r, v) or N values, as the reference reads them
+    else if (width >= 1 && ilast >= ifirst - 1 && ilast - ifirst < 0x7fffffff) {     // an array this path does not use: skip its words
+      for (long long i = ifirst - 1; i < ilast; i++) for (long long k = 0; k < width; k++) in >> word;
+    }
+    else throw GandalfError("Corrupt array descriptor in snapshot : " + ids[a]);
+    if (!in) throw GandalfError("Truncated snapshot : " + filename);
+  }
+}
+
 void WriteSnapshotFile(const std::string &filename, const std::string &fileform, const Snapshot &s)
 {
   if (fileform == "column") WriteColumnSnapshotFile(filename, s);
   else if (fileform == "su" || fileform == "seren_unform") WriteSerenUnformSnapshotFile(filename, s);
-  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su)");
+  else if (fileform == "sf" || fileform == "seren_form") WriteSerenFormSnapshotFile(filename, s);
+  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su, sf)");
 }
 
 void ReadSnapshotFile(const std::string &filename, const std::string &fileform, Snapshot &s)
 {
   if (fileform == "column") ReadColumnSnapshotFile(filename, s);
   else if (fileform == "su" || fileform == "seren_unform") ReadSerenUnformSnapshotFile(filename, s);
-  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su)");
+  else if (fileform == "sf" || fileform == "seren_form") ReadSerenFormSnapshotFile(filename, s);
+  else throw GandalfError("Unrecognised file format : " + fileform + " (built: column, su, sf)");
 }

@@ -1,4 +1,4 @@
-// SnapshotIO.h -- GANDALF's `column` and SEREN unformatted (`su`) snapshot formats for the gas particles of the hot
+// SnapshotIO.h -- GANDALF's `column`, SEREN unformatted (`su`) and SEREN formatted (`sf`) snapshot formats for the gas particles of the hot
 // path, so that runs can start from and be compared with the reference's own files.
 //
 // File layouts restated from the reference's writers / readers:
@@ -24,6 +24,9 @@ void WriteColumnSnapshotFile(const std::string &filename, const Snapshot &s);
 void ReadColumnSnapshotFile(const std::string &filename, Snapshot &s);
 void WriteSerenUnformSnapshotFile(const std::string &filename, const Snapshot &s);
 void ReadSerenUnformSnapshotFile(const std::string &filename, Snapshot &s);
-// fileform = column | su | seren_unform   (SimulationBase::Read/WriteSnapshotFile, SimulationIO.hpp:59-125)
+//   sf     : SimulationIO.hpp:601-925 (read), :993-1232 (write); tag "SERENASCIIDUMPV2", the su layout as text (10 decimals)
+void WriteSerenFormSnapshotFile(const std::string &filename, const Snapshot &s);
+void ReadSerenFormSnapshotFile(const std::string &filename, Snapshot &s);
+// fileform = column | su | seren_unform | sf | seren_form   (SimulationBase::Read/WriteSnapshotFile, SimulationIO.hpp:59-125)
 void WriteSnapshotFile(const std::string &filename, const std::string &fileform, const Snapshot &s);
 void ReadSnapshotFile(const std::string &filename, const std::string &fileform, Snapshot &s);

@@ -174,16 +174,20 @@ void SphSimulation::GenerateIC()
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
   if (ic == "file") {
-    // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su); the smoothing lengths are
-    // recomputed from scratch by the setup (initial_h_provided = false)
+    // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su | sf).  The readers differ in
+    // what they leave behind, and the run inherits it: column and su set the simulation time and leave the smoothing lengths
+    // to be recomputed from scratch (initial_h_provided stays false, SimulationIO.hpp:274-360, 1382); the formatted SEREN
+    // reader declares the file's h provided (:794) and keeps t = 0 unless the run is a restart (:677-687)
     Snapshot snap;
-    ReadSnapshotFile(sp["in_file"], sp["in_file_form"], snap);
+    const std::string form = sp["in_file_form"];
+    ReadSnapshotFile(sp["in_file"], form, snap);
     if (snap.ndim != ndim) throw GandalfError("Incorrect no. of dimensions in file");
     sph->AllocateMemory(std::max(snap.N, 1));
     HydroParticles &q = sph->part;
     q.r = snap.r; q.v = snap.v; q.m = snap.m; q.h = snap.h; q.u = snap.u;
-    t = snap.t;
-    initial_h_provided = false;
+    const bool sf = form == "sf" || form == "seren_form";
+    t = sf ? 0.0 : snap.t;
+    initial_h_provided = sf;
     return;
   }
   const int N = ip["Nhydro"];

@@ -15,7 +15,7 @@
 //   ref_dump steps  <params.dat> <out_prefix> <nsteps>
 //       SetupSimulation(), dump "setup"; nsteps x MainLoop(); dump "final".
 //   ref_dump snap   <params.dat> <out_prefix> [nsteps]
-//       SetupSimulation(), nsteps x MainLoop(), then the reference's column and SEREN-unformatted snapshot writers.
+//       SetupSimulation(), nsteps x MainLoop(), then the reference's column, SEREN-unformatted and SEREN-formatted snapshot writers.
 //   ref_dump time   <params.dat> <nsteps> [warmup]
 //       SetupSimulation(); warmup x MainLoop(); time nsteps x MainLoop(); prints one JSON line
 //       (the CPU baseline of bench.py, kind "reference").
@@ -268,6 +268,7 @@ static int run(const string &mode_in, Parameters *params, SimulationBase *simbas
     for (int s = 0; s < nsteps; s++) sim->MainLoop();
     sim->WriteSnapshotFile(prefix + ".column", "column");
     sim->WriteSnapshotFile(prefix + ".su", "su");
+    sim->WriteSnapshotFile(prefix + ".sf", "sf");
     { Dump out(prefix + "_snap.gdmp"); dump_particles<ndim>(out, sim);
       vector<double> v; v.push_back(sim->t); v.push_back(sim->tsnaplast); v.push_back(sph->mmean); v.push_back(sim->tlitesnaplast); v.push_back(sph->h_fac); out.d("snap_t_tsnaplast_mmean_tlitesnaplast_hfac", v);
       vector<int> w; w.push_back(sim->Noutsnap); w.push_back(sim->Nsteps); w.push_back(sim->Noutlitesnap); out.i("snap_Noutsnap_Nsteps_Noutlitesnap", w); }

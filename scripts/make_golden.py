@@ -8,6 +8,7 @@ Run in the build container only (needs /root/reference to have been compiled by
 """
 import os
 import subprocess
+import shutil
 import sys
 import tempfile
 
@@ -207,6 +208,23 @@ def fromfile(name, nsteps=20):
         print(name, "fromfile ->", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def snapshots():
+    """the reference's own snapshot writers (`ref_dump snap`: column, su and sf files of one state, plus that state): the 3-D
+    512-particle box after setup and the 1-D shock tube after two steps -> tests/golden/snapshots/{box,sod}.{column,su,sf},
+    {box,sod}_state.npz"""
+    dst = os.path.join(GOLD, "snapshots")
+    os.makedirs(dst, exist_ok=True)
+    for tag, par, nsteps in (("box", "box3d_512", 0), ("sod", "adsod_1d", 2)):
+        with tempfile.TemporaryDirectory() as tmp:
+            run(["snap", os.path.join(ROOT, "tests", "params", par + ".dat"), os.path.join(tmp, tag), str(nsteps)], tmp, threads=1)
+            for ext in ("column", "su", "sf"):
+                shutil.copy(os.path.join(tmp, "%s.%s" % (tag, ext)), os.path.join(dst, "%s.%s" % (tag, ext)))
+            st = read_gdmp(os.path.join(tmp, tag + "_snap.gdmp"))
+            keep = {k: st[k] for k in ("r", "v", "m", "h", "rho", "u", "iorig", "snap_t_tsnaplast_mmean_tlitesnaplast_hfac", "snap_Noutsnap_Nsteps_Noutlitesnap")}
+            np.savez_compressed(os.path.join(dst, tag + "_state.npz"), **keep)
+        print("snapshots:", tag)
+
+
 NBODY_FIELDS = ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt", "t_dt"]
 
 
@@ -250,6 +268,8 @@ if __name__ == "__main__":
             long_run("adsod_mirror", 1334, "full")          # tend = 5 of the root adsod.dat
         elif cfg.endswith("_fromfile"):
             fromfile(cfg)
+        elif cfg == "snapshots":
+            snapshots()
         elif "_sinks" in cfg:
             sinks(cfg, 40 if cfg.endswith("_levels") else 12)
         elif cfg.endswith("_stars_levels"):

@@ -236,6 +236,27 @@ def test_run_from_reference_snapshot(tmp_path):
     assert np.array_equal(f["rho"], dev.download("rho")) and np.array_equal(f["r"].ravel(), dev.download("r").ravel())
 
 
+def test_run_from_reference_sf_snapshot():
+    """ic = file with in_file_form = sf: the reference's formatted reader declares the file's smoothing lengths provided and,
+    unlike the column / su readers, leaves the time at 0 unless the run is a restart (SimulationIO.hpp:677-687, 794) - the
+    run from tests/golden/snapshots/sod.sf therefore starts at t = 0 with the file's h; setup + 20 steps against the
+    reference's own run from the same file"""
+    from gandalf_amd.host import Simulation
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "adsod_1d_sf_fromfile_steps.npz"))
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d_sf_fromfile.dat"), in_file=os.path.join(here, "golden", "snapshots", "sod.sf"))
+    sim.setup()
+    dev = sim.device()
+    assert sim.t == 0.0 == g["setup_t_timestep"][0]
+    assert np.max(np.abs(dev.download("h")/g["setup_h"] - 1)) < 1e-12
+    assert abs(sim.timestep - g["setup_t_timestep"][1]) < 1e-12*sim.timestep
+    sim.main_loop(int(g["nsteps"][0]))
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-12
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-11
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-10
+    assert np.max(np.abs(dev.download("u")/g["final_u"] - 1)) < 1e-10
+
+
 @pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4", "plummer_4k_ts3"])
 def test_restocked_tree_runs_match_reference(case):
     """ntreebuildstep = 4: from the IC through the setup and ten steps - the tree is rebuilt on steps 1, 4, 8 and re-stocked

@@ -1,7 +1,8 @@
-"""Snapshot formats: the host shell's `column` and SEREN-unformatted (`su`) readers / writers against
-files written by the reference's own writers (tests/golden/snapshots/*.column, *.su: `ref_dump snap`, i.e.
-Simulation::WriteColumnSnapshotFile / WriteSerenUnformSnapshotFile on a 3-D box after setup and on the 1-D shock tube
-after two steps) and the state the reference held when it wrote them (*_state.npz)."""
+"""Snapshot formats: the host shell's `column`, SEREN-unformatted (`su`) and SEREN-formatted (`sf`)
+readers / writers against files written by the reference's own writers (tests/golden/snapshots/*.column, *.su, *.sf:
+`ref_dump snap`, i.e. Simulation::WriteColumnSnapshotFile / WriteSerenUnformSnapshotFile / WriteSerenFormSnapshotFile on a
+3-D box after setup and on the 1-D shock tube after two steps; scripts/make_golden.py snapshots) and the state the
+reference held when it wrote them (*_state.npz)."""
 import filecmp
 import os
 
@@ -36,7 +37,7 @@ def test_su_reader_returns_the_reference_state(name):
 
 
 @pytest.mark.parametrize("name", ["box", "sod"])
-@pytest.mark.parametrize("form", ["su", "column"])
+@pytest.mark.parametrize("form", ["su", "column", "sf"])
 def test_writer_is_byte_identical_to_the_reference(name, form, tmp_path):
     out = str(tmp_path / ("%s.%s" % (name, form)))
     write_snapshot(out, form, state(name))
@@ -54,6 +55,18 @@ def test_column_reader(name):
         assert np.all(np.abs(a - b) <= 5e-6*np.abs(b) + 1e-300), k
 
 
+@pytest.mark.parametrize("name", ["box", "sod"])
+def test_sf_reader(name):
+    """the formatted SEREN file keeps 11 significant digits (scientific, 10 decimals); header words and ids exact"""
+    s = state(name)
+    f = read_snapshot(os.path.join(SNAP, name + ".sf"), "seren_form")
+    assert f["N"] == len(s["m"]) and f["Nsteps"] == s["Nsteps"] and np.array_equal(f["iorig"], s["iorig"])
+    assert abs(f["t"] - s["t"]) <= 1e-10*abs(s["t"]) and abs(f["h_fac"] - s["h_fac"]) <= 1e-10*s["h_fac"]
+    for k in ("r", "v", "m", "h", "rho", "u"):
+        a, b = f[k].reshape(f["N"], -1), s[k].reshape(f["N"], -1)
+        assert np.all(np.abs(a - b) <= 1e-10*np.abs(b) + 1e-300), k
+
+
 def test_round_trip_and_errors(tmp_path):
     s = state("box")
     out = str(tmp_path / "rt.su")
@@ -61,7 +74,9 @@ def test_round_trip_and_errors(tmp_path):
     f = read_snapshot(out, "su")
     assert np.array_equal(f["r"], s["r"]) and np.array_equal(f["u"], s["u"])
     with pytest.raises(HostError):
-        write_snapshot(out, "sf", s)                           # formatted SEREN is not built
+        write_snapshot(out, "slite", s)                        # the lite format is not built
+    with pytest.raises(HostError):
+        read_snapshot(os.path.join(SNAP, "box.su"), "sf")      # wrong tag
     with pytest.raises(HostError):
         read_snapshot(os.path.join(SNAP, "box.column"), "su")  # wrong tag
     with pytest.raises(HostError):
