@@ -174,10 +174,11 @@ void SphSimulation::GenerateIC()
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
   if (ic == "file") {
-    // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su | sf).  The readers differ in
-    // what they leave behind, and the run inherits it: column and su set the simulation time and leave the smoothing lengths
-    // to be recomputed from scratch (initial_h_provided stays false, SimulationIO.hpp:274-360, 1382); the formatted SEREN
-    // reader declares the file's h provided (:794) and keeps t = 0 unless the run is a restart (:677-687)
+    // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su | sf).  The smoothing lengths
+    // are recomputed from scratch by the setup whatever the file holds: the formatted SEREN reader does declare the file's h
+    // provided (SimulationIO.hpp:794), but ic = file clears the flag again right after the read (SimulationIC.hpp:91).  The
+    // readers differ in the time they leave behind: column and su set it (SimulationIO.hpp:1382), sf only for a restart
+    // (:677-687) - a run from an sf file starts at t = 0.
     Snapshot snap;
     const std::string form = sp["in_file_form"];
     ReadSnapshotFile(sp["in_file"], form, snap);
@@ -187,7 +188,7 @@ void SphSimulation::GenerateIC()
     q.r = snap.r; q.v = snap.v; q.m = snap.m; q.h = snap.h; q.u = snap.u;
     const bool sf = form == "sf" || form == "seren_form";
     t = sf ? 0.0 : snap.t;
-    initial_h_provided = sf;
+    initial_h_provided = false;
     return;
   }
   const int N = ip["Nhydro"];

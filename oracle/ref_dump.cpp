@@ -229,8 +229,8 @@ static int run(const string &mode_in, Parameters *params, SimulationBase *simbas
 #endif
   if (getenv("REF_H_PROVIDED")) {
     // SimulationBase::SetupSimulation (Simulation.cpp:639-694) call for call, declaring the smoothing lengths of the IC
-    // file as provided: only the SEREN *formatted* reader sets that flag (SimulationIO.hpp:794), the unformatted (su)
-    // reader does not although it reads h too - and without it PostInitialConditionsSetup replaces h by one global
+    // file as provided: ic = file always leaves that flag false (SimulationIC.hpp:91) although the readers read h,
+    // and without it PostInitialConditionsSetup replaces h by one global
     // guess (Sph.cpp:76-119) and spends ~500 s converging it at 1M Plummer particles.
     // bench.py's same-size CPU baseline starts the reference from the GPU run's state this way.
     sim->ProcessParameters();

@@ -237,10 +237,10 @@ def test_run_from_reference_snapshot(tmp_path):
 
 
 def test_run_from_reference_sf_snapshot():
-    """ic = file with in_file_form = sf: the reference's formatted reader declares the file's smoothing lengths provided and,
-    unlike the column / su readers, leaves the time at 0 unless the run is a restart (SimulationIO.hpp:677-687, 794) - the
-    run from tests/golden/snapshots/sod.sf therefore starts at t = 0 with the file's h; setup + 20 steps against the
-    reference's own run from the same file"""
+    """ic = file with in_file_form = sf: unlike the column / su readers, the reference's formatted reader leaves the time at
+    0 unless the run is a restart (SimulationIO.hpp:677-687); the smoothing lengths are recomputed from scratch as for every
+    snapshot (the reader's "h provided" is cleared again by SimulationIC.hpp:91).  The run from tests/golden/snapshots/sod.sf:
+    setup + 20 steps against the reference's own run from the same file"""
     from gandalf_amd.host import Simulation
     here = os.path.dirname(__file__)
     g = np.load(os.path.join(here, "golden", "adsod_1d_sf_fromfile_steps.npz"))
