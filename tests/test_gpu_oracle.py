@@ -274,8 +274,10 @@ def test_restocked_tree_runs_match_reference(case):
     assert np.max(np.linalg.norm(a - ar, axis=1)/np.maximum(np.linalg.norm(ar, axis=1), np.linalg.norm(ar, axis=1).mean())) < 1e-8
 
 
-def test_potmin_flags_vs_oracle():
-    """the potential-minimum flag (GradhSph.cpp:270-280, with its stale-distance quirk) for EVERY particle the sink search could
+@pytest.mark.parametrize("nleafmax", [6, 16])
+def test_potmin_flags_vs_oracle(nleafmax):
+    """(Nleafmax = 16: leaves of up to 16 particles go through the serial kernel - the wave kernel takes 8 slots per leaf.)
+    The potential-minimum flag (GradhSph.cpp:270-280, with its stale-distance quirk) for EVERY particle the sink search could
     read it from: the Boss-Bodenheimer cloud with rho_sink lowered so that thousands of particles qualify and Nsinkfixed = 0 so that no
     sink forms; after two steps (real potentials) the flags of all particles with rho >= rho_sink equal the CPU restatement's,
     and they are a non-trivial pattern (neither all set nor all clear)"""
@@ -287,6 +289,7 @@ def test_potmin_flags_vs_oracle():
     g = load_golden("bb_sinks_8k_steps")
     p = read_params_file("%s/bb_sinks_8k.dat" % PARAMS)
     p["rho_sink"] = "0.28"; p["Nsinkfixed"] = "0"      # (h floor 0.092 < the initial h 0.0965: below that every ComputeH call returns -1)
+    p["Nleafmax"] = str(nleafmax)
     r, v, m, u = g["setup_r"], g["setup_v"], g["setup_m"], g["setup_u"]
     h0 = bb_initial_h(p, m)
     sim = gandalf_amd.GandalfHip(p)
