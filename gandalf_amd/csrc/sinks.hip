@@ -465,7 +465,15 @@ __global__ void k_sink_levelneib(DevicePtrs d, const int *idx, const int *lvl, i
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// one field of every particle in caller (slot) order
+__global__ void k_slot_order(DevicePtrs d, int field, double *out)
+{
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < d.N) out[d.iorig[i]] = d.f[field][i];
+}
+
 struct SinkScratch {
+  double *d_slot = nullptr, *h_slot = nullptr; size_t cap_slot = 0;     // masses in slot order (device, pinned host): mmean
   double *d_st = nullptr;        // star table: r[3n] v[3n] a[3n] rad[n] + centre[3]
   int *d_i = nullptr;            // counters / lists
   double *d_rows = nullptr, *h_rows = nullptr;
@@ -493,6 +501,8 @@ void gh_sinks_free(gh_ctx *ctx)
   if (W->d_st) (void) hipFree(W->d_st);
   if (W->d_i) (void) hipFree(W->d_i);
   if (W->d_rows) (void) hipFree(W->d_rows);
+  if (W->d_slot) (void) hipFree(W->d_slot);
+  if (W->h_slot) (void) hipHostFree(W->h_slot);
   delete W;
   ctx->sink_scratch = nullptr;
 }
@@ -874,10 +884,23 @@ int gh_sinks_step(gh_ctx *ctx, gh_host_stars &S, double t, double timestep)
   // Several ranks: every rank sums its own particles (tree order), the partial sums are added in rank order - mmean only
   // enters the "what is left is less than smooth_accrete_frac*mmean" test of the smooth accretion
   if (ctx->nranks == 1) {
-    std::vector<double> m((size_t) ctx->N);
-    if ((rc = gh_download(ctx, GH_F_M, m.data()))) return rc;
+    // (the masses are put into slot order on the device and come over in one pinned copy; the sum itself stays the
+    //  reference's serial loop - through gh_download, with its pageable copies and the scatter on the host, this was ~12 ms
+    //  of a 2 000 000-particle sink step)
+    const size_t n = (size_t) ctx->N;
+    if (W.cap_slot < n) {
+      if (W.d_slot) (void) hipFree(W.d_slot);
+      if (W.h_slot) (void) hipHostFree(W.h_slot);
+      W.d_slot = nullptr; W.h_slot = nullptr; W.cap_slot = 0;
+      GH_CHECK(ctx, hipMalloc((void**) &W.d_slot, sizeof(double)*(n + n/8 + 64)));
+      GH_CHECK(ctx, hipHostMalloc((void**) &W.h_slot, sizeof(double)*(n + n/8 + 64)));
+      W.cap_slot = n + n/8 + 64;
+    }
+    hipLaunchKernelGGL(k_slot_order, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), D_M, W.d_slot);
+    GH_CHECK(ctx, hipMemcpyAsync(W.h_slot, W.d_slot, sizeof(double)*n, hipMemcpyDeviceToHost, ctx->stream));
+    GH_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0.0;
-    for (size_t i = 0; i < m.size(); i++) sum += m[i];
+    for (size_t i = 0; i < n; i++) sum += W.h_slot[i];
     ctx->mmean = sum/(double) ctx->N;
   }
   else {
