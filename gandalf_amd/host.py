@@ -25,6 +25,11 @@ HOST_SYMBOLS = {
     "gah_get_ic": (C.c_int, [_H, _PD, _PD, _PD, _PD, _PD]),
     "gah_post_ic_setup": (C.c_int, [_H]),
     "gah_init_comm": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "gah_run": (C.c_int, [_H, C.c_int]),
+    "gah_set_restart": (C.c_int, [_H, C.c_int]),
+    "gah_set_output": (C.c_int, [_H, C.c_int]),
+    "gah_nsteps": (C.c_int, [_H]),
+    "gah_noutsnap": (C.c_int, [_H]),
     "gah_upload_ic": (C.c_int, [_H]),
     "gah_setup": (C.c_int, [_H]),
     "gah_main_loop": (C.c_int, [_H, C.c_int]),
@@ -194,6 +199,26 @@ class Simulation:
 
     def main_loop(self, nsteps=1):
         self._chk(self.lib.gah_main_loop(self.h, nsteps))
+
+    def run(self, nsteps=-1):
+        """SimulationBase::Run: MainLoop + Output until tend / Nstepsmax (or nsteps more steps)"""
+        self._chk(self.lib.gah_run(self.h, nsteps))
+
+    def set_output(self, on=True):
+        """regular snapshots <run_id>.<out_file_form>.NNNNN + <run_id>.restart in the working directory (before setup())"""
+        self.lib.gah_set_output(self.h, 1 if on else 0)
+
+    def set_restart(self, on=True):
+        """continue from the snapshot named in <run_id>.restart (the reference's `gandalf -r`); before setup()"""
+        self.lib.gah_set_restart(self.h, 1 if on else 0)
+
+    @property
+    def Nsteps(self):
+        return self.lib.gah_nsteps(self.h)
+
+    @property
+    def Noutsnap(self):
+        return self.lib.gah_noutsnap(self.h)
 
     @property
     def t(self):

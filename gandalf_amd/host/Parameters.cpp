@@ -22,6 +22,8 @@ void Parameters::SetDefaultValues()
   floatparams["tend"] = 1.0;
   intparams["Nstepsmax"] = 99999999;
   intparams["noutputstep"] = 128;
+  floatparams["dt_snap"] = 0.2;
+  floatparams["tsnapfirst"] = 0.0;
   intparams["dimensionless"] = 0;
   floatparams["accel_mult"] = 0.3;
   floatparams["courant_mult"] = 0.15;

@@ -140,6 +140,8 @@ void SphSimulation::ProcessParameters()
   cfg.smooth_accrete_frac = fp["smooth_accrete_frac"]; cfg.smooth_accrete_dt = fp["smooth_accrete_dt"];
   if (cfg.sink_particles && ip["dimensionless"] == 0) throw GandalfError("sink runs: dimensionless units required");
   tend = fp["tend"]; Nstepsmax = ip["Nstepsmax"];
+  dt_snap = fp["dt_snap"]; tsnapnext = fp["tsnapfirst"];                 // Simulation.cpp:1207, 1227 (dimensionless units)
+  out_file_form = simparams->stringparams["out_file_form"]; run_id = simparams->stringparams["run_id"];
   delete sph; delete randnumb;
   sph = new Sph(ndim, cfg.h_fac, (cfg.kernel == GH_KERNEL_QUINTIC || cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0);
   randnumb = new XorshiftRand((uint64_t) ip["randseed"]);
@@ -173,6 +175,33 @@ void SphSimulation::GenerateIC()
 {
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
+  if (restart) {
+    // SimulationIC.hpp:64-82: a restart re-reads the last regular snapshot, whose name and format Output() left in
+    // <run_id>.restart; no such file -> an ordinary start.  What the readers restore for a restart (SimulationIO.hpp:677-687,
+    // 1385-1393: Noutsnap, Nsteps, t, tsnaplast - su and sf; column: t and tsnaplast = t, :206-207), then
+    // ConvertToCodeUnits' tsnapnext = tsnaplast + dt_snap (:2553-2556).  initial_h_provided is what the reader left: only the
+    // formatted reader declares h provided, and the ic = file branch that clears it again is not taken here.
+    std::ifstream f((run_id + ".restart").c_str());
+    std::string form, file;
+    if (f && (f >> form >> file)) {
+      // (the tree schedule of HydroTree::BuildTree counts Nsteps, which the device library restarts at 0)
+      if (ip["ntreebuildstep"] > 1 || ip["ntreestockstep"] > 1) throw GandalfError("restart with ntreebuildstep / ntreestockstep > 1 is not built");
+      Snapshot snap;
+      ReadSnapshotFile(file, form, snap);
+      if (snap.ndim != ndim) throw GandalfError("Incorrect no. of dimensions in file");
+      sph->AllocateMemory(std::max(snap.N, 1));
+      HydroParticles &q = sph->part;
+      q.r = snap.r; q.v = snap.v; q.m = snap.m; q.h = snap.h; q.u = snap.u;
+      t = snap.t;
+      if (form == "column") tsnaplast = t;
+      else { Noutsnap = (int) snap.Noutsnap; Nsteps = (int) snap.Nsteps; tsnaplast = snap.tsnaplast; }
+      tsnapnext = tsnaplast + dt_snap;
+      initial_h_provided = form == "sf" || form == "seren_form";
+      restart_iorig = snap.iorig; restarted_ids = form != "column";        // (the setup keeps iorig for a restart, SphSimulation.cpp:215-217)
+      return;
+    }
+    restart = false;
+  }
   if (ic == "file") {
     // SimulationIC.hpp:88-92: particles from a snapshot (in_file, in_file_form = column | su | sf).  The smoothing lengths
     // are recomputed from scratch by the setup whatever the file holds: the formatted SEREN reader does declare the file's h
@@ -475,7 +504,7 @@ void SphSimulation::PostInitialConditionsSetup()
     check(ctx, gh_hybrid_setup(ctx, nbody, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
   }
   else check(ctx, gh_setup(ctx, initial_h_provided ? 1 : 0, &timestep), "PostInitialConditionsSetup");
-  Nsteps = 0;
+  if (!restart) Nsteps = 0;
   setup = true;
   { struct timeval tv; gettimeofday(&tv, 0); wall_start = tv.tv_sec + 1e-6*tv.tv_usec; }
 }
@@ -487,6 +516,31 @@ void SphSimulation::SetupSimulation()
   GenerateIC();
   if (simparams->intparams["com_frame"] == 1) SetComFrame();
   PostInitialConditionsSetup();
+  Output();                                // "Initial output before simulation begins", Simulation.cpp:686
+}
+
+// SimulationBase::Output (Simulation.cpp:500-600): when the time has reached tsnapnext, the next regular snapshot
+// <run_id>.<out_file_form>.NNNNN and the two lines of <run_id>.restart (format, snapshot name) - both relative to the working
+// directory, as the reference writes them.  (Lite snapshots, the periodic diagnostics print and the wall-clock kill switch
+// are not part of this path.)
+std::string SphSimulation::Output()
+{
+  std::string filename;
+  if (!write_output) return filename;
+  if (t >= tsnapnext) {
+    Noutsnap++;
+    tsnaplast = tsnapnext;
+    tsnapnext += dt_snap;
+    char no[16];
+    snprintf(no, sizeof(no), "%05d", Noutsnap);
+    filename = run_id + "." + out_file_form + "." + no;
+    WriteSnapshotFile(filename, out_file_form);
+    if (comm_rank == 0) {
+      std::ofstream out((run_id + ".restart").c_str());
+      out << out_file_form << std::endl << filename << std::endl;
+    }
+  }
+  return filename;
 }
 
 void SphSimulation::MainLoop(int nsteps)
@@ -502,7 +556,7 @@ void SphSimulation::MainLoop(int nsteps)
 void SphSimulation::Run(int Nadvance)
 {
   const int Ntarget = Nadvance < 0 ? Nstepsmax : Nsteps + Nadvance;
-  while (t < tend && Nsteps < Ntarget) MainLoop(1);
+  while (t < tend && Nsteps < Ntarget) { MainLoop(1); Output(); }
 }
 
 // SimulationBase::WriteSnapshotFile (SimulationIO.hpp:96-125): current device state in the caller's particle order
@@ -510,10 +564,12 @@ void SphSimulation::WriteSnapshotFile(const std::string &filename, const std::st
 {
   Snapshot s;
   s.ndim = ndim; s.N = sph->part.N; s.t = t; s.Nsteps = Nsteps; s.h_fac = cfg.h_fac;
+  s.Noutsnap = Noutsnap; s.tsnaplast = tsnaplast;
   Download(GH_F_R, s.r); Download(GH_F_V, s.v); Download(GH_F_M, s.m); Download(GH_F_H, s.h);
   Download(GH_F_RHO, s.rho); Download(GH_F_U, s.u);
   s.iorig.resize(s.N);
   for (int i = 0; i < s.N; i++) s.iorig[i] = i;
+  if (restarted_ids && (int) restart_iorig.size() == s.N) s.iorig = restart_iorig;      // a restarted run keeps the ids it was given
   for (int i = 0; i < s.N; i++) s.mmean += s.m[i];                        // sph->mmean, SphSimulation.cpp:260-262
   if (s.N > 0) s.mmean /= (double) s.N;
   ::WriteSnapshotFile(filename, fileform, s);

@@ -69,7 +69,8 @@ class SphSimulation {
   void PostInitialConditionsSetup();       // SphSimulation.cpp:204
   void SetupSimulation();                  // Simulation.cpp:639
   void MainLoop(int nsteps = 1);           // SphSimulation.cpp:574
-  void Run(int Nadvance = -1);             // Simulation.cpp:382
+  void Run(int Nadvance = -1);             // Simulation.cpp:382 (MainLoop + Output until tend / Nstepsmax)
+  std::string Output();                    // Simulation.cpp:500-600: regular snapshots <run_id>.<form>.NNNNN + <run_id>.restart
   void Download(int field, std::vector<double> &out);
   void WriteSnapshotFile(const std::string &filename, const std::string &fileform);   // SimulationIO.hpp:96
   void CalculateDiagnostics(double *out29);        // SimAnalysis.hpp:52-200 (returns the numbers of one .diag line)
@@ -87,6 +88,14 @@ class SphSimulation {
   XorshiftRand *randnumb = nullptr;
   bool initial_h_provided = false;
   bool setup = false;
+  // snapshot cadence and restarts (SimulationBase: restart, Noutsnap, tsnapnext, tsnaplast, dt_snap, run_id, out_file_form)
+  bool write_output = false;               // Output() writes files (the executable: yes; an embedding host decides - gah_set_output)
+  bool restart = false;                    // continue from the snapshot named in <run_id>.restart (gandalf.cpp -r)
+  bool restarted_ids = false;              // ... whose particle ids (porig) this run keeps writing
+  std::vector<int> restart_iorig;
+  int Noutsnap = 0;
+  double tsnapnext = 0.0, tsnaplast = 0.0, dt_snap = 0.2;
+  std::string run_id, out_file_form = "su";
   int Nsteps = 0, Nstepsmax = 0;
   double t = 0.0, timestep = 0.0, tend = 0.0;
 };

@@ -1,10 +1,11 @@
-// gandalf_main.cpp -- `gandalf_hip <params.dat> [nsteps]`: the reference's command-line flow
+// gandalf_main.cpp -- `gandalf_hip <params.dat> [nsteps] [-r]`: the reference's command-line flow
 // (gandalf.cpp:40-190: ReadParamsFile -> SimulationFactory -> SetupSimulation -> Run) on the HIP path,
 // with a per-phase timing table that uses the reference's block names (CodeTiming).
 #include "SphSimulation.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 int main(int argc, char **argv)
 {
@@ -13,11 +14,13 @@ int main(int argc, char **argv)
   try {
     params.ReadParamsFile(argv[1]);
     SphSimulation *sim = SphSimulation::SimulationFactory(params.intparams["ndim"], params.stringparams["sim"], &params);
+    sim->write_output = true;              // regular snapshots + <run_id>.restart, like the reference's executable
+    for (int a = 2; a < argc; a++) if (std::string(argv[a]) == "-r") sim->restart = true;      // gandalf.cpp:108-111
     auto t0 = std::chrono::steady_clock::now();
     sim->SetupSimulation();
     auto t1 = std::chrono::steady_clock::now();
     gh_reset_timers(sim->ctx);
-    const int nsteps = argc > 2 ? atoi(argv[2]) : -1;
+    const int nsteps = (argc > 2 && std::string(argv[2]) != "-r") ? atoi(argv[2]) : -1;
     sim->Run(nsteps);
     auto t2 = std::chrono::steady_clock::now();
     double ms[GH_T_COUNT];

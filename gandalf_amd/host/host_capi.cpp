@@ -4,7 +4,7 @@
 #include <cstring>
 #include <string>
 
-struct gah_sim { Parameters params; SphSimulation *sim = nullptr; std::string err; };
+struct gah_sim { Parameters params; SphSimulation *sim = nullptr; std::string err; bool restart = false, output = false; };
 
 #define GAH_TRY(s, body) try { body; return 0; } catch (const std::exception &e) { (s)->err = e.what(); return -1; }
 
@@ -27,6 +27,7 @@ int gah_generate_ic(gah_sim *s)
 {
   GAH_TRY(s, {
     if (!s->sim) s->sim = SphSimulation::SimulationFactory(s->params.intparams["ndim"], s->params.stringparams["sim"], &s->params);
+    s->sim->restart = s->restart; s->sim->write_output = s->output;
     s->sim->ProcessParameters();
     s->sim->GenerateIC();
     if (s->params.intparams["com_frame"] == 1) s->sim->SetComFrame();
@@ -71,10 +72,17 @@ int gah_setup(gah_sim *s)
 {
   GAH_TRY(s, {
     if (!s->sim) s->sim = SphSimulation::SimulationFactory(s->params.intparams["ndim"], s->params.stringparams["sim"], &s->params);
+    s->sim->restart = s->restart; s->sim->write_output = s->output;
     s->sim->SetupSimulation();
   })
 }
 int gah_main_loop(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->MainLoop(nsteps)) }
+// SimulationBase::Run (MainLoop + Output until tend / Nstepsmax / nsteps more steps); restart: gandalf.cpp's -r
+int gah_run(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->Run(nsteps)) }
+int gah_set_restart(gah_sim *s, int on) { s->restart = on != 0; if (s->sim) s->sim->restart = s->restart; return 0; }
+int gah_set_output(gah_sim *s, int on) { s->output = on != 0; if (s->sim) s->sim->write_output = s->output; return 0; }
+int gah_nsteps(gah_sim *s) { return s->sim ? s->sim->Nsteps : 0; }
+int gah_noutsnap(gah_sim *s) { return s->sim ? s->sim->Noutsnap : 0; }
 double gah_time(gah_sim *s) { return s->sim->t; }
 double gah_timestep(gah_sim *s) { return s->sim->timestep; }
 gh_ctx *gah_ctx(gah_sim *s) { return s->sim ? s->sim->ctx : nullptr; }

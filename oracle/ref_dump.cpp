@@ -14,6 +14,8 @@
 //       pass has an (input state, output state) pair.
 //   ref_dump steps  <params.dat> <out_prefix> <nsteps>
 //       SetupSimulation(), dump "setup"; nsteps x MainLoop(); dump "final".
+//   ref_dump run    <params.dat> <out_prefix> <nsteps>
+//       SetupSimulation() (REF_RESTART=1: as a restart) and SimulationBase::Run(nsteps) with its regular snapshots.
 //   ref_dump snap   <params.dat> <out_prefix> [nsteps]
 //       SetupSimulation(), nsteps x MainLoop(), then the reference's column, SEREN-unformatted and SEREN-formatted snapshot writers.
 //   ref_dump time   <params.dat> <nsteps> [warmup]
@@ -240,7 +242,10 @@ static int run(const string &mode_in, Parameters *params, SimulationBase *simbas
     sim->PostInitialConditionsSetup();
     sim->Output();
   }
-  else sim->SetupSimulation();
+  else {
+    if (getenv("REF_RESTART")) sim->restart = true;          // gandalf.cpp -r: continue from the snapshot named in <run_id>.restart
+    sim->SetupSimulation();
+  }
   sph = static_cast<Sph<ndim>*>(sim->hydro);
 
   if (mode == "time") {
@@ -306,6 +311,14 @@ static int run(const string &mode_in, Parameters *params, SimulationBase *simbas
     const int nsteps = atoi(argv[4]);
     for (int s = 0; s < nsteps; s++) sim->MainLoop();
     { Dump out(prefix + "_final.gdmp"); dump_particles<ndim>(out, sim); }
+  }
+  else if (mode == "run") {
+    // SimulationBase::Run: MainLoop + Output (regular snapshots and <run_id>.restart in the working directory)
+    const int nsteps = atoi(argv[4]);
+    sim->Run(nsteps);
+    Dump out(prefix + "_final.gdmp"); dump_particles<ndim>(out, sim);
+    vector<double> v; v.push_back(sim->t); v.push_back(sim->tsnaplast); v.push_back(sim->tsnapnext); out.d("run_t_tsnaplast_tsnapnext", v);
+    vector<int> w; w.push_back(sim->Noutsnap); w.push_back(sim->Nsteps); out.i("run_Noutsnap_Nsteps", w);
   }
   return 0;
 }

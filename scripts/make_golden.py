@@ -32,8 +32,8 @@ TREE = ["tree_Ncell_ltot_gtot_Ntot_Nleafmax", "cell_cnext", "cell_copen", "cell_
         "inext"]
 
 
-def run(args, cwd, threads=None):
-    env = dict(os.environ)
+def run(args, cwd, threads=None, env=None):
+    env = dict(env or os.environ)
     env.setdefault("OMP_NUM_THREADS", "8")
     if threads:
         env["OMP_NUM_THREADS"] = str(threads)
@@ -225,6 +225,40 @@ def snapshots():
         print("snapshots:", tag)
 
 
+def restart():
+    """SimulationBase::Run with regular snapshots, then a restart (`ref_dump run`, REF_RESTART=1): the 1-D shock tube with
+    dt_snap = 0.003 for 12 steps (snapshots 00001..00003 + ADSOD1D.restart), then - from a directory that holds only the
+    restart file and the snapshot it names - 8 more steps as a restart.  -> tests/golden/restart/ADSOD1D.su.00003 (the
+    reference's snapshot, a data file) and restart.npz"""
+    dst = os.path.join(GOLD, "restart")
+    os.makedirs(dst, exist_ok=True)
+    src = open(os.path.join(ROOT, "tests", "params", "adsod_1d.dat")).read().replace("dt_snap = 100.0", "dt_snap = 0.003").replace("tsnapfirst = 100.0", "tsnapfirst = 0.0")
+    with tempfile.TemporaryDirectory() as tmp:
+        par = os.path.join(tmp, "p.dat")
+        open(par, "w").write(src)
+        run(["run", par, os.path.join(tmp, "a"), "12"], tmp, threads=1)
+        names_a = sorted(f for f in os.listdir(tmp) if f.startswith("ADSOD1D.su."))
+        text = open(os.path.join(tmp, "ADSOD1D.restart")).read()
+        a = read_gdmp(os.path.join(tmp, "a_final.gdmp"))
+        last = text.split()[1]
+        shutil.copy(os.path.join(tmp, last), os.path.join(dst, last))
+        tb = os.path.join(tmp, "b")
+        os.makedirs(tb)
+        for f in ("p.dat", "ADSOD1D.restart", last):
+            shutil.copy(os.path.join(tmp, f), os.path.join(tb, f))
+        env = dict(os.environ, REF_RESTART="1")
+        run(["run", os.path.join(tb, "p.dat"), os.path.join(tb, "b"), "8"], tb, threads=1, env=env)
+        names_b = sorted(f for f in os.listdir(tb) if f.startswith("ADSOD1D.su."))
+        bs, b = read_gdmp(os.path.join(tb, "b_setup.gdmp")), read_gdmp(os.path.join(tb, "b_final.gdmp"))
+        out = {"names_first_run": np.array(names_a), "restart_text": np.array([text]), "names_restarted_run": np.array(names_b),
+               "first_t_tsnaplast_tsnapnext": a["run_t_tsnaplast_tsnapnext"], "first_Noutsnap_Nsteps": a["run_Noutsnap_Nsteps"],
+               "restarted_t_tsnaplast_tsnapnext": b["run_t_tsnaplast_tsnapnext"], "restarted_Noutsnap_Nsteps": b["run_Noutsnap_Nsteps"]}
+        for k in ("r", "v", "h", "rho", "u", "t_timestep"):
+            out["first_final_" + k] = a[k]; out["restart_setup_" + k] = bs[k]; out["restarted_final_" + k] = b[k]
+        np.savez_compressed(os.path.join(dst, "restart.npz"), **out)
+        print("restart:", names_a, "->", names_b)
+
+
 NBODY_FIELDS = ["r", "v", "a", "adot", "r0", "v0", "a0", "m", "h", "gpot", "dt", "t_dt"]
 
 
@@ -270,6 +304,8 @@ if __name__ == "__main__":
             fromfile(cfg)
         elif cfg == "snapshots":
             snapshots()
+        elif cfg == "restart":
+            restart()
         elif "_sinks" in cfg:
             sinks(cfg, 40 if cfg.endswith("_levels") else 12)
         elif cfg.endswith("_stars_levels"):

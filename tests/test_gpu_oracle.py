@@ -257,6 +257,61 @@ def test_run_from_reference_sf_snapshot():
     assert np.max(np.abs(dev.download("u")/g["final_u"] - 1)) < 1e-10
 
 
+def test_regular_snapshots_and_restart(tmp_path, monkeypatch):
+    """SimulationBase::Run with its regular snapshots, then a restart (Simulation.cpp:382-600, SimulationIC.hpp:64-82): the 1-D
+    shock tube with dt_snap = 0.003.  (1) 12 steps from the IC: the snapshot files <run_id>.su.NNNNN the reference wrote, by
+    name, its <run_id>.restart text, the header of the last one (Noutsnap, Nsteps, tsnaplast) and its particle data.  (2) A
+    directory that holds only the REFERENCE's restart file and the snapshot it names: started as a restart, the run picks up
+    t, Nsteps, Noutsnap and the snapshot clock from the file, and after 8 more steps equals the reference's own restarted run -
+    including the names of the snapshots written on the way.  Fixture: scripts/make_golden.py restart."""
+    import shutil
+    from gandalf_amd.host import Simulation, read_snapshot
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "restart", "restart.npz"))
+    over = {"dt_snap": 0.003, "tsnapfirst": 0.0}
+    # (1) from the IC
+    d1 = tmp_path/"first"; d1.mkdir(); monkeypatch.chdir(d1)
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d.dat"), **over)
+    sim.set_output(True)
+    sim.setup()
+    sim.run(12)
+    assert sorted(f for f in os.listdir(d1) if ".su." in f) == list(g["names_first_run"])
+    assert open(d1/"ADSOD1D.restart").read() == str(g["restart_text"][0])
+    assert (sim.Noutsnap, sim.Nsteps) == tuple(int(x) for x in g["first_Noutsnap_Nsteps"])
+    assert abs(sim.t - g["first_t_tsnaplast_tsnapnext"][0]) < 1e-12
+    last = str(g["restart_text"][0]).split()[1]
+    ours, ref = read_snapshot(str(d1/last), "su"), read_snapshot(os.path.join(here, "golden", "restart", last), "su")
+    for k in ("Noutsnap", "Nsteps", "tsnaplast", "N"):
+        assert ours[k] == ref[k], k
+    assert abs(ours["t"] - ref["t"]) < 1e-12 and np.array_equal(ours["iorig"], ref["iorig"])
+    for k in ("r", "v", "h", "rho", "u"):
+        assert np.max(np.abs(ours[k] - ref[k])) <= 1e-10*np.max(np.abs(ref[k])), k
+    # (2) restart from the reference's files
+    d2 = tmp_path/"again"; d2.mkdir(); monkeypatch.chdir(d2)
+    shutil.copy(os.path.join(here, "golden", "restart", last), d2/last)
+    (d2/"ADSOD1D.restart").write_text(str(g["restart_text"][0]))
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d.dat"), **over)
+    sim.set_output(True); sim.set_restart(True)
+    sim.setup()
+    dev = sim.device()
+    assert sim.t == g["restart_setup_t_timestep"][0] and sim.Nsteps == ref["Nsteps"] and sim.Noutsnap == ref["Noutsnap"]
+    assert abs(sim.timestep - g["restart_setup_t_timestep"][1]) < 1e-12*sim.timestep
+    assert np.max(np.abs(dev.download("h")/g["restart_setup_h"] - 1)) < 1e-12
+    sim.run(8)
+    assert (sim.Noutsnap, sim.Nsteps) == tuple(int(x) for x in g["restarted_Noutsnap_Nsteps"])
+    assert abs(sim.t - g["restarted_t_tsnaplast_tsnapnext"][0]) < 1e-12
+    assert sorted(f for f in os.listdir(d2) if ".su." in f) == list(g["names_restarted_run"])
+    assert np.max(np.abs(dev.download("r") - g["restarted_final_r"])) < 1e-11
+    assert np.max(np.abs(dev.download("rho")/g["restarted_final_rho"] - 1)) < 1e-10
+    assert np.max(np.abs(dev.download("u")/g["restarted_final_u"] - 1)) < 1e-10
+    # a restart without a restart file is an ordinary start (SimulationIC.hpp:77-80)
+    d3 = tmp_path/"none"; d3.mkdir(); monkeypatch.chdir(d3)
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d.dat"), **over)
+    sim.set_restart(True)
+    sim.setup()
+    assert sim.t == 0.0 and sim.Nsteps == 0
+
+
 @pytest.mark.parametrize("case", ["box3d_4k_tb4", "plummer_4k_tb4", "plummer_4k_ts3"])
 def test_restocked_tree_runs_match_reference(case):
     """ntreebuildstep = 4: from the IC through the setup and ten steps - the tree is rebuilt on steps 1, 4, 8 and re-stocked
