@@ -22,6 +22,7 @@ void Parameters::SetDefaultValues()
   floatparams["tend"] = 1.0;
   intparams["Nstepsmax"] = 99999999;
   intparams["noutputstep"] = 128;
+  intparams["nrestartstep"] = 512;
   floatparams["dt_snap"] = 0.2;
   floatparams["tsnapfirst"] = 0.0;
   intparams["dimensionless"] = 0;

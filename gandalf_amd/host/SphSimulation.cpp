@@ -140,6 +140,7 @@ void SphSimulation::ProcessParameters()
   cfg.smooth_accrete_frac = fp["smooth_accrete_frac"]; cfg.smooth_accrete_dt = fp["smooth_accrete_dt"];
   if (cfg.sink_particles && ip["dimensionless"] == 0) throw GandalfError("sink runs: dimensionless units required");
   tend = fp["tend"]; Nstepsmax = ip["Nstepsmax"];
+  nrestartstep = ip["nrestartstep"];
   dt_snap = fp["dt_snap"]; tsnapnext = fp["tsnapfirst"];                 // Simulation.cpp:1207, 1227 (dimensionless units)
   out_file_form = simparams->stringparams["out_file_form"]; run_id = simparams->stringparams["run_id"];
   delete sph; delete randnumb;
@@ -540,7 +541,24 @@ std::string SphSimulation::Output()
       out << out_file_form << std::endl << filename << std::endl;
     }
   }
+  // a temporary snapshot to restart from, every nrestartstep steps (at a resynchronisation of the block clock; every
+  // global-timestep step is one) - Simulation.cpp:592-596
+  if (ctx && (cfg.Nlevels <= 1 || [&]() { int32_t c[4]; gh_get_block_clock(ctx, c, nullptr); return c[1] > 0 && c[0]%c[1] == 0; }()) &&
+      Nsteps - nlastrestart >= nrestartstep) {
+    RestartSnapshot();
+    nlastrestart = Nsteps;
+  }
   return filename;
+}
+
+void SphSimulation::RestartSnapshot()
+{
+  const std::string filename = run_id + "." + out_file_form + ".tmp";
+  WriteSnapshotFile(filename, out_file_form);
+  if (comm_rank == 0) {
+    std::ofstream out((run_id + ".restart").c_str());
+    out << out_file_form << std::endl << filename << std::endl;
+  }
 }
 
 void SphSimulation::MainLoop(int nsteps)
@@ -562,6 +580,8 @@ void SphSimulation::Run(int Nadvance)
 // SimulationBase::WriteSnapshotFile (SimulationIO.hpp:96-125): current device state in the caller's particle order
 void SphSimulation::WriteSnapshotFile(const std::string &filename, const std::string &fileform)
 {
+  // (several ranks: every rank holds its own particles only - gh_download - and nothing here gathers them)
+  if (comm_nranks > 1) throw GandalfError("snapshot files of a multi-rank run are not built (gather the ranks' arrays in the host)");
   Snapshot s;
   s.ndim = ndim; s.N = sph->part.N; s.t = t; s.Nsteps = Nsteps; s.h_fac = cfg.h_fac;
   s.Noutsnap = Noutsnap; s.tsnaplast = tsnaplast;

@@ -93,7 +93,8 @@ class SphSimulation {
   bool restart = false;                    // continue from the snapshot named in <run_id>.restart (gandalf.cpp -r)
   bool restarted_ids = false;              // ... whose particle ids (porig) this run keeps writing
   std::vector<int> restart_iorig;
-  int Noutsnap = 0;
+  int Noutsnap = 0, nrestartstep = 512, nlastrestart = 0;
+  void RestartSnapshot();                  // Simulation.cpp:609-632: <run_id>.<form>.tmp + <run_id>.restart naming it
   double tsnapnext = 0.0, tsnaplast = 0.0, dt_snap = 0.2;
   std::string run_id, out_file_form = "su";
   int Nsteps = 0, Nstepsmax = 0;

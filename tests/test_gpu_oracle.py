@@ -304,6 +304,15 @@ def test_regular_snapshots_and_restart(tmp_path, monkeypatch):
     assert np.max(np.abs(dev.download("r") - g["restarted_final_r"])) < 1e-11
     assert np.max(np.abs(dev.download("rho")/g["restarted_final_rho"] - 1)) < 1e-10
     assert np.max(np.abs(dev.download("u")/g["restarted_final_u"] - 1)) < 1e-10
+    # a temporary restart snapshot every nrestartstep steps (Simulation.cpp:592-632): <run_id>.su.tmp, named in <run_id>.restart
+    d4 = tmp_path/"tmpsnap"; d4.mkdir(); monkeypatch.chdir(d4)
+    sim = Simulation(os.path.join(PARAMS, "adsod_1d.dat"), nrestartstep=5, **over)
+    sim.set_output(True)
+    sim.setup()
+    sim.run(5)
+    assert open(d4/"ADSOD1D.restart").read().split() == ["su", "ADSOD1D.su.tmp"]
+    f = read_snapshot(str(d4/"ADSOD1D.su.tmp"), "su")
+    assert f["Nsteps"] == 5 and f["t"] == sim.t
     # a restart without a restart file is an ordinary start (SimulationIC.hpp:77-80)
     d3 = tmp_path/"none"; d3.mkdir(); monkeypatch.chdir(d3)
     sim = Simulation(os.path.join(PARAMS, "adsod_1d.dat"), **over)
