@@ -26,6 +26,15 @@ void Parameters::SetDefaultValues()
   floatparams["dt_snap"] = 0.2;
   floatparams["tsnapfirst"] = 0.0;
   intparams["dimensionless"] = 0;
+  // output (= code) units of a run with physical units (Parameters.cpp:214-235); the input units default to them
+  stringparams["routunit"] = "pc"; stringparams["moutunit"] = "m_sun"; stringparams["toutunit"] = "myr";
+  stringparams["voutunit"] = "km_s"; stringparams["aoutunit"] = "km_s2"; stringparams["rhooutunit"] = "g_cm3";
+  stringparams["sigmaoutunit"] = "m_sun_pc2"; stringparams["pressoutunit"] = "Pa"; stringparams["foutunit"] = "N";
+  stringparams["Eoutunit"] = "J"; stringparams["momoutunit"] = "m_sunkm_s"; stringparams["angmomoutunit"] = "m_sunkm2_s";
+  stringparams["angveloutunit"] = "rad_s"; stringparams["dmdtoutunit"] = "m_sun_yr"; stringparams["Loutunit"] = "L_sun";
+  stringparams["kappaoutunit"] = "m2_kg"; stringparams["Boutunit"] = "tesla"; stringparams["Qoutunit"] = "C";
+  stringparams["Jcuroutunit"] = "C_s_m2"; stringparams["uoutunit"] = "J_kg"; stringparams["dudtoutunit"] = "J_kg_s";
+  stringparams["tempoutunit"] = "K";
   floatparams["accel_mult"] = 0.3;
   floatparams["courant_mult"] = 0.15;
   intparams["Nlevels"] = 1;

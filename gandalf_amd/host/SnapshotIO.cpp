@@ -79,7 +79,7 @@ void WriteSerenUnformSnapshotFile(const std::string &filename, const Snapshot &s
   int32_t idata[50] = {0}; int64_t ilpdata[50] = {0}; double rdata[50] = {0.0}, ddata[50] = {0.0};
   idata[0] = N; idata[1] = 0;               // Nhydro (live), Nstar
   idata[4] = N;                             // particles per type: icm, GAS, cdm, dust (:2151-2156)
-  idata[19] = 0; idata[20] = ndata;         // no unit strings when dimensionless
+  idata[19] = (int32_t) s.units.size(); idata[20] = ndata;      // unit strings: none when dimensionless, 21 otherwise (:2066-2090)
   ilpdata[0] = s.Noutsnap; ilpdata[1] = s.Nsteps; ilpdata[10] = s.Noutlitesnap;
   rdata[0] = s.h_fac;
   ddata[0] = s.t; ddata[1] = s.tsnaplast; ddata[2] = s.mmean; ddata[10] = s.tlitesnaplast;
@@ -90,6 +90,7 @@ void WriteSerenUnformSnapshotFile(const std::string &filename, const Snapshot &s
   for (int i = 0; i < 50; i++) put<int64_t>(out, ilpdata[i]);
   for (int i = 0; i < 50; i++) put<double>(out, rdata[i]);
   for (int i = 0; i < 50; i++) put<double>(out, ddata[i]);
+  for (size_t i = 0; i < s.units.size(); i++) put_str(out, s.units[i]);
   for (int a = 0; a < ndata; a++) put_str(out, arrs[a].id);
   for (int a = 0; a < ndata; a++) for (int j = 0; j < 5; j++) put<int32_t>(out, arrs[a].t[j]);
   if (N > 0) {
@@ -173,7 +174,7 @@ void WriteSerenFormSnapshotFile(const std::string &filename, const Snapshot &s)
                        {"v", {nd, 1, N, 4, 4}}, {"rho", {1, 1, N, 4, 6}}, {"u", {1, 1, N, 4, 20}}};
   const int ndata = N > 0 ? 7 : 0;
   int idata[50] = {0}, ilpdata[50] = {0}; double rdata[50] = {0.0}, ddata[50] = {0.0};
-  idata[0] = N; idata[1] = 0; idata[4] = N; idata[19] = 0; idata[20] = ndata;
+  idata[0] = N; idata[1] = 0; idata[4] = N; idata[19] = (int) s.units.size(); idata[20] = ndata;
   ilpdata[0] = s.Noutsnap; ilpdata[1] = s.Nsteps; ilpdata[10] = s.Noutlitesnap;       // (the reference's ilpdata are ints here)
   rdata[0] = s.h_fac;
   ddata[0] = s.t; ddata[1] = s.tsnaplast; ddata[2] = s.mmean; ddata[10] = s.tlitesnaplast;
@@ -185,6 +186,7 @@ void WriteSerenFormSnapshotFile(const std::string &filename, const Snapshot &s)
   for (int i = 0; i < 50; i++) { pi(ilpdata[i]); out << std::endl; }
   for (int i = 0; i < 50; i++) { pf(rdata[i]); out << std::endl; }
   for (int i = 0; i < 50; i++) { pf(ddata[i]); out << std::endl; }
+  for (size_t i = 0; i < s.units.size(); i++) out << s.units[i] << std::endl;
   for (int a = 0; a < ndata; a++) out << arrs[a].id << std::endl;
   for (int a = 0; a < ndata; a++) { for (int j = 0; j < 5; j++) pi(arrs[a].t[j]); out << std::endl; }
   if (N > 0) {

@@ -15,6 +15,7 @@ struct Snapshot {
   std::vector<double> r, v;                 // [N][ndim]
   std::vector<double> m, h, rho, u;         // [N]
   std::vector<int> iorig;                   // [N]   (su only: "porig")
+  std::vector<std::string> units;           // su / sf: the 21 unit ids of a run with physical units (none: dimensionless)
   // su header words the reference fills from its Simulation object (SimulationIO.hpp:2151-2168)
   long Noutsnap = 0, Nsteps = 0, Noutlitesnap = 0;
   double h_fac = 1.2, tsnaplast = 0.0, mmean = 0.0, tlitesnaplast = 0.0;

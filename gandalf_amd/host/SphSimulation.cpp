@@ -121,31 +121,119 @@ void SphSimulation::ProcessParameters()
   cfg.sph_single_timestep = ip["sph_single_timestep"];
   cfg.device = ip["device"];
   cfg.energy_integration = sp["gas_eos"] == "energy_eqn" ? 1 : 0;     // GradhSphSimulation.cpp:114-122
+  simunits.SetupUnits(simparams);                                      // Simulation.cpp:1121
   for (int k = 0; k < 3; k++) {
     const std::string idx = "[" + std::to_string(k) + "]";
     cfg.boundary_lhs[k] = enum_of(sp["boundary_lhs" + idx], bd, 3, "boundary_lhs" + idx);
     cfg.boundary_rhs[k] = enum_of(sp["boundary_rhs" + idx], bd, 3, "boundary_rhs" + idx);
-    cfg.boxmin[k] = fp["boxmin" + idx]; cfg.boxmax[k] = fp["boxmax" + idx];
+    cfg.boxmin[k] = fp["boxmin" + idx]/simunits.r.outscale; cfg.boxmax[k] = fp["boxmax" + idx]/simunits.r.outscale;      // :1127-1155
   }
   cfg.h_fac = fp["h_fac"]; cfg.h_converge = fp["h_converge"];
   cfg.alpha_visc = fp["alpha_visc"]; cfg.beta_visc = fp["beta_visc"];
-  cfg.gamma_eos = fp["gamma_eos"]; cfg.temp0 = fp["temp0"]; cfg.mu_bar = fp["mu_bar"]; cfg.rho_bary = fp["rho_bary"];
+  // thermal physics constants in code units (IsothermalEOS.cpp:37, BarotropicEOS.cpp:40-42: rho_bary is given in g cm^-3)
+  cfg.gamma_eos = fp["gamma_eos"]; cfg.temp0 = fp["temp0"]/simunits.temp.outscale; cfg.mu_bar = fp["mu_bar"];
+  cfg.rho_bary = fp["rho_bary"]/simunits.rho.outscale/simunits.rho.outcgs;
   cfg.thetamaxsqd = fp["thetamaxsqd"];
   cfg.courant_mult = fp["courant_mult"]; cfg.accel_mult = fp["accel_mult"]; cfg.energy_mult = fp["energy_mult"];
   // sink particles (SphSimulation.cpp:116-136; dimensionless runs: rho_sink and sink_radius need no unit scaling)
   cfg.sink_particles = ip["sink_particles"]; cfg.create_sinks = cfg.sink_particles ? ip["create_sinks"] : 0;
   cfg.smooth_accretion = ip["smooth_accretion"]; cfg.Nsinkfixed = ip["Nsinkfixed"];
   cfg.sink_radius_mode = sp["sink_radius_mode"] == "fixed" ? 0 : (sp["sink_radius_mode"] == "hmult" ? 1 : 2);
-  cfg.rho_sink = fp["rho_sink"]; cfg.sink_radius = fp["sink_radius"]; cfg.alpha_ss = fp["alpha_ss"];
+  // SphSimulation.cpp:128-136: rho_sink in g cm^-3, a fixed sink radius in length units, a multiple of h as it is
+  cfg.rho_sink = fp["rho_sink"]/(simunits.rho.outscale*simunits.rho.outcgs);
+  cfg.sink_radius = cfg.sink_radius_mode == 0 ? fp["sink_radius"]/simunits.r.outscale : fp["sink_radius"];
+  cfg.alpha_ss = fp["alpha_ss"];
   cfg.smooth_accrete_frac = fp["smooth_accrete_frac"]; cfg.smooth_accrete_dt = fp["smooth_accrete_dt"];
-  if (cfg.sink_particles && ip["dimensionless"] == 0) throw GandalfError("sink runs: dimensionless units required");
-  tend = fp["tend"]; Nstepsmax = ip["Nstepsmax"];
+  tend = fp["tend"]/simunits.t.outscale; Nstepsmax = ip["Nstepsmax"];      // Simulation.cpp:1225
   nrestartstep = ip["nrestartstep"];
-  dt_snap = fp["dt_snap"]; tsnapnext = fp["tsnapfirst"];                 // Simulation.cpp:1207, 1227 (dimensionless units)
+  dt_snap = fp["dt_snap"]/simunits.t.outscale; tsnapnext = fp["tsnapfirst"]/simunits.t.outscale;     // Simulation.cpp:1207, 1227
   out_file_form = simparams->stringparams["out_file_form"]; run_id = simparams->stringparams["run_id"];
   delete sph; delete randnumb;
   sph = new Sph(ndim, cfg.h_fac, (cfg.kernel == GH_KERNEL_QUINTIC || cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 3.0 : 2.0);
   randnumb = new XorshiftRand((uint64_t) ip["randseed"]);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// SimUnits::SetupUnits (SimUnits.cpp:825-1118) with the unit tables of SimUnits.cpp:72-790 and the constants of
+// Constants.h:34-51, for the quantities of this path
+// ---------------------------------------------------------------------------------------------
+static double si_of(const std::string &kind, const std::string &unit)
+{
+  const double r_pc = 3.08568025E16, r_au = 1.49597870E11, r_sun = 6.955E8, r_earth = 6.371E6;
+  const double m_sun = 1.98892E30, m_jup = 1.8986E27, m_earth = 5.9736E24, myr = 3.1556952E13, yr = 3.1556952E7, day = 8.64E4;
+  if (unit == "") return 1.0;
+  if (kind == "r") {
+    if (unit == "mpc") return 1.0E6*r_pc; if (unit == "kpc") return 1.0E3*r_pc; if (unit == "pc") return r_pc; if (unit == "au") return r_au;
+    if (unit == "r_sun") return r_sun; if (unit == "r_earth") return r_earth; if (unit == "km") return 1000.0; if (unit == "m") return 1.0; if (unit == "cm") return 0.01;
+  }
+  else if (kind == "m") {
+    if (unit == "m_sun") return m_sun; if (unit == "m_jup") return m_jup; if (unit == "m_earth") return m_earth; if (unit == "kg") return 1.0; if (unit == "g") return 1.0e-3;
+  }
+  else if (kind == "t") {
+    if (unit == "gyr") return 1000.0*myr; if (unit == "myr") return myr; if (unit == "yr") return yr; if (unit == "day") return day; if (unit == "s") return 1.0;
+  }
+  else if (kind == "v") {
+    if (unit == "km_s") return 1000.0; if (unit == "au_yr") return r_au/yr; if (unit == "m_s") return 1.0; if (unit == "cm_s") return 0.01;
+  }
+  else if (kind == "a") {
+    if (unit == "km_s2") return 1000.0; if (unit == "au_yr2") return r_au/(yr*yr); if (unit == "m_s2") return 1.0; if (unit == "cm_s2") return 0.01;
+  }
+  else if (kind == "rho") {
+    if (unit == "m_sun_pc3") return m_sun/(r_pc*r_pc*r_pc); if (unit == "kg_m3") return 1.0; if (unit == "g_cm3") return 1000.0;
+  }
+  else if (kind == "u") { if (unit == "J_kg") return 1.0; if (unit == "erg_g") return 1.0e-4; }
+  else if (kind == "temp") { if (unit == "K") return 1.0; }
+  else if (kind == "angvel") { if (unit == "rad_s") return 1.0; }
+  throw GandalfError("Parameter error : Unrecognised unit = " + unit);
+}
+
+void SimUnits::SetupUnits(Parameters *params)
+{
+  dimensionless = params->intparams["dimensionless"] != 0;
+  if (dimensionless) return;
+  const double G_const = 6.67384E-11, m_hydrogen = 1.66054E-27, k_boltzmann = 1.3806503E-23;
+  auto &sp = params->stringparams;
+  r.outunit = sp["routunit"]; r.outSI = si_of("r", r.outunit); r.outcgs = 100.0*r.outSI; r.outscale = 1.0;
+  m.outunit = sp["moutunit"]; m.outSI = si_of("m", m.outunit); m.outcgs = 1000.0*m.outSI; m.outscale = 1.0;
+  t.outunit = sp["toutunit"]; t.outSI = si_of("t", t.outunit);
+  t.outscale = pow(r.outscale*r.outSI, 1.5)/sqrt(m.outscale*m.outSI*G_const);
+  t.outscale /= t.outSI;
+  t.outcgs = t.outSI;
+  v.outunit = sp["voutunit"]; v.outSI = si_of("v", v.outunit);
+  v.outscale = r.outscale*r.outSI/(t.outscale*t.outSI);
+  v.outscale /= v.outSI;
+  v.outcgs = 100.0*v.outSI;
+  a.outunit = sp["aoutunit"]; a.outSI = si_of("a", a.outunit);
+  a.outscale = (r.outscale*r.outSI)/(t.outscale*t.outSI*t.outscale*t.outSI);
+  a.outscale = a.outscale/a.outSI;
+  a.outcgs = 100.0*a.outSI;
+  rho.outunit = sp["rhooutunit"]; rho.outSI = si_of("rho", rho.outunit);
+  rho.outscale = (m.outscale*m.outSI)/pow(r.outscale*r.outSI, 3);
+  rho.outscale = rho.outscale/rho.outSI;
+  rho.outcgs = 1.0e-3*rho.outSI;
+  angvel.outunit = sp["angveloutunit"]; angvel.outSI = si_of("angvel", angvel.outunit);
+  angvel.outscale = 1.0/(t.outscale*t.outSI);
+  angvel.outscale = angvel.outscale/angvel.outSI;
+  angvel.outcgs = angvel.outSI;
+  u.outunit = sp["uoutunit"]; u.outSI = si_of("u", u.outunit);
+  u.outscale = pow(r.outscale*r.outSI, 2)/pow(t.outscale*t.outSI, 2);
+  u.outscale = u.outscale/u.outSI;
+  u.outcgs = 1.0e4*u.outSI;
+  temp.outunit = sp["tempoutunit"]; temp.outSI = si_of("temp", temp.outunit);
+  temp.outscale = (m_hydrogen*u.outscale*u.outSI)/k_boltzmann;
+  temp.outscale = temp.outscale/temp.outSI;
+  temp.outcgs = temp.outSI;
+}
+
+std::vector<std::string> SimUnits::unit_strings(Parameters *params) const
+{
+  static const char *keys[21] = {"routunit", "moutunit", "toutunit", "voutunit", "aoutunit", "rhooutunit", "sigmaoutunit", "pressoutunit", "foutunit",
+                                 "Eoutunit", "momoutunit", "angmomoutunit", "angveloutunit", "dmdtoutunit", "Loutunit", "kappaoutunit", "kappaoutunit",
+                                 "kappaoutunit", "kappaoutunit", "uoutunit", "tempoutunit"};      // (B, Q and Jcur carry the opacity unit: SimUnits.cpp:1060-1075)
+  std::vector<std::string> out;
+  if (!dimensionless) for (const char *k : keys) out.push_back(params->stringparams[k]);
+  return out;
 }
 
 // the device context is created on first use, so that parameter handling and IC generation work
@@ -176,6 +264,8 @@ void SphSimulation::GenerateIC()
 {
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
+  if ((restart || ic == "file") && !simunits.dimensionless)
+    throw GandalfError("snapshots in physical units are written but not read back (ic = file / restart need dimensionless = 1)");
   if (restart) {
     // SimulationIC.hpp:64-82: a restart re-reads the last regular snapshot, whose name and format Output() left in
     // <run_id>.restart; no such file -> an ordinary start.  What the readers restore for a restart (SimulationIO.hpp:677-687,
@@ -357,11 +447,12 @@ void SphSimulation::GenerateIC()
     // perturbation (Ic::AddAzimuthalDensityPerturbation, Ic.cpp:850-915) and solid-body rotation about z
     // (Ic::AddRotationalVelocityField, Ic.cpp:974-1021)
     if (ndim != 3) throw GandalfError("Boss-Bodenheimer test only runs in 3D");
-    if (ip["dimensionless"] == 0) throw GandalfError("dimensionless units required");
     const std::string dist = sp["particle_distribution"];
     if (dist != "cubic_lattice" && dist != "hexagonal_lattice") throw GandalfError("Invalid particle distribution option");
     const double pi = 3.14159265358979, twopi = 6.28318530717959, small_number = 1.0e-20;
-    const double amp = fp["amp"], angvel = fp["angvel"], mcloud = fp["mcloud"], radius = fp["radius"], temp0 = fp["temp0"];
+    // physical units: the cloud's parameters into code units first (BossBodenheimerIc.cpp:55-58)
+    const double amp = fp["amp"], angvel = fp["angvel"]/simunits.angvel.outscale, mcloud = fp["mcloud"]/simunits.m.outscale,
+                 radius = fp["radius"]/simunits.r.outscale, temp0 = fp["temp0"]/simunits.temp.outscale;
     const double gammaone = fp["gamma_eos"] - 1.0, mu_bar = fp["mu_bar"];
     const double u0 = temp0/gammaone/mu_bar;
     const double rho0 = 3.0*mcloud/(4.0*pi*pow(radius, 3));
@@ -590,8 +681,19 @@ void SphSimulation::WriteSnapshotFile(const std::string &filename, const std::st
   s.iorig.resize(s.N);
   for (int i = 0; i < s.N; i++) s.iorig[i] = i;
   if (restarted_ids && (int) restart_iorig.size() == s.N) s.iorig = restart_iorig;      // a restarted run keeps the ids it was given
+  s.units = simunits.unit_strings(simparams);
   for (int i = 0; i < s.N; i++) s.mmean += s.m[i];                        // sph->mmean, SphSimulation.cpp:260-262
   if (s.N > 0) s.mmean /= (double) s.N;
+  if (!simunits.dimensionless) {
+    // output units (SimulationIO.hpp:302-337, 1140-1220, 2151-2250: every array and the header's times and masses)
+    for (double &x : s.r) x *= simunits.r.outscale;
+    for (double &x : s.v) x *= simunits.v.outscale;
+    for (double &x : s.m) x *= simunits.m.outscale;
+    for (double &x : s.h) x *= simunits.r.outscale;
+    for (double &x : s.rho) x *= simunits.rho.outscale;
+    for (double &x : s.u) x *= simunits.u.outscale;
+    s.t *= simunits.t.outscale; s.tsnaplast *= simunits.t.outscale; s.tlitesnaplast *= simunits.t.outscale; s.mmean *= simunits.m.outscale;
+  }
   ::WriteSnapshotFile(filename, fileform, s);
 }
 

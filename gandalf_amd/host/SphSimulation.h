@@ -43,6 +43,18 @@ class Sph {
   int Ngather = 0;
 };
 
+// SimUnits (SimUnits.cpp:825-1118) for the quantities this path reads or writes.  Code units ARE the output units of length
+// and mass (outscale = 1) with G = 1; every other quantity follows: x[code] = x[output unit] / outscale.  A dimensionless
+// run has every factor 1.  outSI: the output unit in SI; outcgs: in cgs (rho_sink and rho_bary are given in g cm^-3
+// whatever rhooutunit is, SphSimulation.cpp:129, BarotropicEOS.cpp:42).
+struct SimUnit { double outscale = 1.0, outSI = 1.0, outcgs = 1.0; std::string outunit; };
+struct SimUnits {
+  bool dimensionless = true;
+  SimUnit r, m, t, v, a, rho, u, temp, angvel;
+  void SetupUnits(Parameters *params);
+  std::vector<std::string> unit_strings(Parameters *params) const;      // the 21 unit ids of a snapshot header (SimulationIO.hpp:1040-1064)
+};
+
 class SphNeighbourSearch {                 // neib_search = kdtree on the GPU
  public:
   explicit SphNeighbourSearch(gh_ctx *ctx) : ctx(ctx) {}
@@ -80,6 +92,7 @@ class SphSimulation {
 
   int ndim;
   Parameters *simparams;
+  SimUnits simunits;
   gh_config cfg;
   gh_ctx *ctx = nullptr;
   gh_nbody *nbody = nullptr;               // sink runs: the stars the sinks are (Nbody, Sinks; SphSimulation.cpp:116-136)
