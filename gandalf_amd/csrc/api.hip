@@ -82,6 +82,15 @@ int gh_sync_collect(gh_ctx *ctx, const char *where)
       return gh_fail(ctx, GH_ERR_UNSUPPORTED, std::string(where) + ": multi-GPU: a median split separates particles with equal coordinates (lattice "
                      "initial conditions?) - the reference's quick-select tie order is reproduced on one rank only");
   }
+  if (ctx->cfg.sink_particles && ctx->nranks == 1 && !ctx->sink_exact_sticky) {
+    // sink runs: does any tree build have to keep the reference's order inside the leaves yet?  (see gh_tree_build_impl;
+    // -1 = no density pass has counted yet; once needed, always needed)
+    int dense = -1;
+    GH_CHECK(ctx, hipMemcpy(&dense, ctx->d_blk + 19, sizeof(int), hipMemcpyDeviceToHost));
+    const bool need = ctx->cfg.create_sinks != 1 || dense != 0 || !ctx->sinks.empty() || ctx->nstars > 0 || getenv("GH_SINK_EXACT_ALWAYS");
+    if (need && dense >= 0) ctx->sink_exact_sticky = true;
+    ctx->sink_exact = need;
+  }
   if (ctx->cfg.self_gravity && !flags) { const int rc = gh_grav_list_headroom(ctx); if (rc) return rc; }
   if (flags) {
     GH_CHECK(ctx, hipMemset(ctx->d_flags, 0, sizeof(int)));
@@ -333,10 +342,12 @@ extern "C" int gh_upload_particles(gh_ctx *ctx, int64_t N, const double *r, cons
   ctx->nresync = 0; ctx->level_max = 0; ctx->level_step = 0; ctx->dt_max = 0.0;
   ctx->rebuild_tree = true;
   ctx->exact_armed = false;
+  ctx->sink_exact = true; ctx->sink_exact_sticky = false;
   ctx->glist_checked = -1;
   double tt[3] = {0.0, 0.0, 0.0};
   GH_CHECK(ctx, hipMemcpy(gh_time_dev(ctx), tt, sizeof(tt), hipMemcpyHostToDevice));
   GH_CHECK(ctx, hipMemset(ctx->d_blk, 0, sizeof(int)*24));
+  { const int none = -1; GH_CHECK(ctx, hipMemcpy(ctx->d_blk + 19, &none, sizeof(int), hipMemcpyHostToDevice)); }     // "no density pass has counted yet"
   return GH_OK;
 }
 

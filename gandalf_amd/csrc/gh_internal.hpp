@@ -148,6 +148,8 @@ struct gh_ctx {
   int *qs_ids = nullptr; double *qs_keys = nullptr;   // exact (quick-select order) build, tree.hip
   double *qw_k[2] = {nullptr, nullptr}; int *qw_i[2] = {nullptr, nullptr}, *qw_rk = nullptr, *qw_blk = nullptr; void *qw_st = nullptr; size_t qw_words = 0;   // ... its device-wide passes (top levels)
   bool exact_armed = false;        // a build split equal coordinates: every later build runs the gated exact kernels
+  bool sink_exact_sticky = false;  // ... decided for good
+  bool sink_exact = true;          // sink runs: builds keep the reference's quick-select order (needed once a particle is dense enough to be a sink candidate, or a sink exists; see gh_tree_build_impl)
   int *leafact = nullptr;          // [gtot] active particles per leaf at the last stocking (ntreestockstep > 1 and Nlevels > 1 only)
   double *leaf_amin = nullptr;
   bool mac_bootstrap = false;      // gh_setup's first force pass of a relative MAC runs geometric (SphSimulation.cpp:381-388)

@@ -213,9 +213,25 @@ __global__ void k_potmin_redo(DevicePtrs d, double kernrangesqd, const int *redo
   for (int c = blockIdx.x*blockDim.x + threadIdx.x; c < n; c += gridDim.x*blockDim.x) potmin_serial(d, redo[c], kernrangesqd, flags);
 }
 
+// particles within a factor two of the sink density: while there are none (and no sink or star exists) the tree builds need
+// not keep the reference's order inside the leaves (gh_tree_build_impl); the count is read at the next host synchronisation
+__global__ void k_count_near_sink_density(DevicePtrs d, double rho_half, int p0, int pn, int *count)
+{
+  const int i = p0 + blockIdx.x*blockDim.x + threadIdx.x;
+  const bool dense = i < p0 + pn && !((int) d.f[D_FLAGS][i] & GH_FLAG_DEAD) && d.f[D_RHO][i] >= rho_half;
+  const unsigned long long m = __ballot(dense);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
 int gh_sinks_potmin(gh_ctx *ctx)
 {
   if (!ctx->cfg.sink_particles || ctx->cfg.create_sinks != 1) return GH_OK;
+  {
+    int *word = ctx->d_blk + 19;
+    GH_CHECK(ctx, hipMemsetAsync(word, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_count_near_sink_density, dim3(cdiv(ctx->own_count, 256)), dim3(256), 0, ctx->stream, gh_dev(ctx), 0.5*ctx->cfg.rho_sink,
+                       (int) ctx->own_first, (int) ctx->own_count, word);
+  }
   const double krs = (ctx->cfg.kernel == GH_KERNEL_QUINTIC || ctx->cfg.kernel == GH_KERNEL_QUINTIC_TAB) ? 9.0 : 4.0;
   // scratch: candidate list and redo list in the (otherwise idle) sort-value buffer, two counters behind the block clock
   int *list = ctx->P[0][0], *redo = ctx->P[0][1], *cnt = ctx->d_blk + 16;
