@@ -224,10 +224,10 @@ static void free_particles(gh_ctx *ctx)
     if (ctx->Wpre[k]) (void) hipFree(ctx->Wpre[k]); ctx->Wpre[k] = nullptr;
   }
   void *ptrs[] = {ctx->posm, ctx->hrec, ctx->side, ctx->sortkeys_out, ctx->sortvals, ctx->qs_ids, ctx->qs_keys, ctx->pm_invhsqd, ctx->pm_cullsqd,
-                  ctx->qw_k[0], ctx->qw_k[1], ctx->qw_i[0], ctx->qw_i[1], ctx->qw_rk, ctx->qw_blk, ctx->qw_st};
+                  ctx->qw_k[0], ctx->qw_k[1], ctx->qw_i[0], ctx->qw_i[1], ctx->qw_rk, ctx->qw_gp, ctx->qw_blk, ctx->qw_st};
   for (void *p : ptrs) if (p) (void) hipFree(p);
   ctx->qs_ids = nullptr; ctx->qs_keys = nullptr; ctx->pm_invhsqd = nullptr; ctx->pm_cullsqd = nullptr;
-  ctx->qw_k[0] = ctx->qw_k[1] = nullptr; ctx->qw_i[0] = ctx->qw_i[1] = nullptr; ctx->qw_rk = nullptr; ctx->qw_blk = nullptr; ctx->qw_st = nullptr; ctx->qw_words = 0;
+  ctx->qw_k[0] = ctx->qw_k[1] = nullptr; ctx->qw_i[0] = ctx->qw_i[1] = nullptr; ctx->qw_rk = nullptr; ctx->qw_gp = nullptr; ctx->qw_blk = nullptr; ctx->qw_st = nullptr; ctx->qw_words = 0;
   ctx->posm = nullptr; ctx->hrec = nullptr; ctx->side = nullptr; ctx->sortkeys_out = nullptr; ctx->sortvals = nullptr;
   ctx->iota_N = -1;
   ctx->Ncap = 0; ctx->N = 0; ctx->tree_layout_N = -1; ctx->tree_valid = false;

@@ -146,7 +146,7 @@ struct gh_ctx {
   void *sink_scratch = nullptr;
   double *cvel = nullptr;          // [Ncell][3] mass-weighted mean velocity at stock time (ntreestockstep > 1 only)
   int *qs_ids = nullptr; double *qs_keys = nullptr;   // exact (quick-select order) build, tree.hip
-  double *qw_k[2] = {nullptr, nullptr}; int *qw_i[2] = {nullptr, nullptr}, *qw_rk = nullptr, *qw_blk = nullptr; void *qw_st = nullptr; size_t qw_words = 0;   // ... its device-wide passes (top levels)
+  double *qw_k[2] = {nullptr, nullptr}; int *qw_i[2] = {nullptr, nullptr}, *qw_rk = nullptr, *qw_gp = nullptr, *qw_blk = nullptr; void *qw_st = nullptr; size_t qw_words = 0;   // ... its device-wide passes (top levels)
   bool exact_armed = false;        // a build split equal coordinates: every later build runs the gated exact kernels
   bool sink_exact_sticky = false;  // ... decided for good
   bool sink_exact = true;          // sink runs: builds keep the reference's quick-select order (needed once a particle is dense enough to be a sink candidate, or a sink exists; see gh_tree_build_impl)

@@ -344,6 +344,7 @@ struct QSel {
   int left, right;                   // current range (the pivot search continues in it)
   int cur, done, conv;               // buffer the range lives in; range fits LDS or converged; converged (pivot landed on the median)
   int f0, nb4, jguess, none;         // this pass: first "> pivot" position, "<=" elements before it, where the pivot lands, no element > pivot
+  int kg, fewg;                      // ... number of "> pivot" elements; few enough for the segment walk of k_qw_gather
   int nleft, nright, nconv;          // the range after this pass
   double rpiv;                       // last pivot value
 };
@@ -576,7 +577,8 @@ __global__ __launch_bounds__(1024) void k_qselect_level(DevicePtrs d, int level,
 struct QWArgs {
   QSel *st_cur, *st_next;            // state read by this pass / written for the next one
   double *k[2]; int *i[2];           // the two buffers (keys, ids)
-  int *rk;                           // "<=" rank of every position of the pass
+  int *rk;                           // "<=" rank of every position of the pass ("> pivot": minus its number among them)
+  int *gp;                           // gp[lo + j - 1]: op index of the j-th "> pivot" element of the cell's pass
   int *blkcnt, *blkfirst, *blkpre;   // per (cell, block)
   int *out;                          // final ids
   int nb, level, qcap;
@@ -594,7 +596,7 @@ __global__ void k_qw_init(DevicePtrs d, QWArgs a, const int *ids, const double *
     QSel S;
     S.left = first; S.right = first + cnt - 1; S.cur = 0; S.conv = 0;
     S.done = cnt <= a.qcap ? 1 : 0;
-    S.f0 = S.nb4 = S.jguess = S.none = 0; S.nleft = S.left; S.nright = S.right; S.nconv = 0;
+    S.f0 = S.nb4 = S.jguess = S.none = 0; S.kg = 0; S.fewg = 0; S.nleft = S.left; S.nright = S.right; S.nconv = 0;
     S.rpiv = dbbmin[n*3 + kd];
     a.st_cur[c] = S;
   }
@@ -666,6 +668,11 @@ __global__ __launch_bounds__(1024) void k_qw_scan(DevicePtrs d, QWArgs a)
     S.none = f0 == 0x7fffffff ? 1 : 0;
     if (S.none) { S.f0 = hi; S.nb4 = hi - lo; S.jguess = hi; }
     else { S.f0 = f0; S.nb4 = f0 - lo; S.jguess = f0 + (tot_le - S.nb4); }
+    S.kg = (hi - lo) - tot_le;
+    // a chain of k_qw_gather is ~M/K hops long with K "> pivot" elements among M: with few of them (a pivot near the top of
+    // the range - one pass in a few dozen, but then thousands of dependent hops: the 20 longest of 1 248 launches were half
+    // of the kernel's time) it walks segment by segment instead, at most K steps
+    S.fewg = (!S.none && (long long) S.kg*S.kg < (long long) (hi - lo)) ? 1 : 0;
     S.nleft = lo; S.nright = hi; S.nconv = 0;
     if (S.jguess < jpivot) S.nleft = S.jguess + 1;
     else if (S.jguess > jpivot) S.nright = S.jguess - 1;
@@ -697,9 +704,17 @@ __global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_rank(QWArgs a)
   __syncthreads();
   int pre = a.blkpre[(size_t) c*a.nb + blockIdx.x];
   for (int w = 0; w < wv; w++) pre += s_c[w];
-  // "<=" elements: inclusive count of "<=" in [lo, q]; "> pivot" elements: -1 (the chains of k_qw_gather stop there, and
-  // one 4-byte word per hop is all they read)
-  if (q < hi) a.rk[q] = le ? pre + __popcll(m & ((2ull << lane) - 1ull)) : -1;
+  // "<=" elements: inclusive count of "<=" in [lo, q]; "> pivot" elements: minus their number among the "> pivot" ones (the
+  // chains of k_qw_gather stop at a negative word, and one 4-byte word per hop is all they read)
+  if (q < hi) {
+    const int linc = pre + __popcll(m & ((2ull << lane) - 1ull));
+    if (le) a.rk[q] = linc;
+    else {
+      const int i = q - S.f0 + 1, j = i - (linc - S.nb4);     // op number, number among the "> pivot" elements (both from 1)
+      a.rk[q] = -j;
+      if (S.fewg) a.gp[lo + j - 1] = i;
+    }
+  }
 }
 
 __global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_gather(QWArgs a)
@@ -727,7 +742,22 @@ __global__ __launch_bounds__(GH_QW_BLOCK) void k_qw_gather(QWArgs a)
   if (cd >= 0) put(S.f0 + (cd - S.nb4) - 1, aq, iq);
   if (q >= S.jguess) {
     int src = q;
-    while (cd >= 0) { src = S.f0 + (cd - S.nb4) - 1; cd = a.rk[src]; }
+    if (!S.fewg) while (cd >= 0) { src = S.f0 + (cd - S.nb4) - 1; cd = a.rk[src]; }
+    else if (cd >= 0) {
+      // ops between the j-th and the (j+1)-th "> pivot" element are all "<=" and each of them sends the chain j ops back:
+      // the whole stretch in one step - landing on the j-th "> pivot" op itself ends the chain, otherwise it goes on below it
+      int i = cd - S.nb4;                                  // op the first hop leads to
+      for (;;) {
+        src = S.f0 + i - 1;
+        const int c2 = a.rk[src];
+        if (c2 < 0) break;
+        const int j = i - (c2 - S.nb4);
+        const int gj = a.gp[lo + j - 1];
+        const int dd = i - gj, nn = dd/j;
+        if (dd - nn*j == 0) { src = S.f0 + gj - 1; break; }
+        i -= (nn + 1)*j;
+      }
+    }
     put(q == S.jguess ? hi : q, qw_key(A, src, jg0, hi), qw_id(Ai, src, jg0, hi));            // (the element at jguess changes places with the pivot)
   }
 }
@@ -780,6 +810,7 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
           GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_i[b], sizeof(int)*(size_t) ctx->Ncap));
         }
         GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_rk, sizeof(int)*(size_t) ctx->Ncap));
+        GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_gp, sizeof(int)*(size_t) ctx->Ncap));
         // per (cell, block) words: at most Ncap/1024 + one per cell; states: two per cell of the deepest wide level
         ctx->qw_words = (size_t) ctx->Ncap/GH_QW_BLOCK + 2*(size_t) (ctx->Ncap/std::max(wide_min, 1) + 2) + 1024;
         GH_CHECK(ctx, hipMalloc((void**) &ctx->qw_blk, sizeof(int)*3*ctx->qw_words));
@@ -787,7 +818,7 @@ static int exact_build_gated(gh_ctx *ctx, int *perm_out, const int *gate)
       }
       QWArgs a;
       a.k[0] = ctx->qw_k[0]; a.k[1] = ctx->qw_k[1]; a.i[0] = ctx->qw_i[0]; a.i[1] = ctx->qw_i[1];
-      a.rk = ctx->qw_rk; a.out = ctx->qs_ids;
+      a.rk = ctx->qw_rk; a.gp = ctx->qw_gp; a.out = ctx->qs_ids;
       a.nb = cdiv(mx, GH_QW_BLOCK); a.level = l; a.qcap = GH_QCAP;
       if ((size_t) a.nb*ncells > ctx->qw_words || (size_t) ncells > ctx->qw_words) return gh_fail(ctx, GH_ERR_CAPACITY, "exact tree build: wide quick-select scratch too small");
       a.blkcnt = ctx->qw_blk; a.blkfirst = ctx->qw_blk + ctx->qw_words; a.blkpre = ctx->qw_blk + 2*ctx->qw_words;
