@@ -264,8 +264,19 @@ void SphSimulation::GenerateIC()
 {
   auto &ip = simparams->intparams; auto &fp = simparams->floatparams; auto &sp = simparams->stringparams;
   const std::string ic = sp["ic"];
-  if ((restart || ic == "file") && !simunits.dimensionless)
-    throw GandalfError("snapshots in physical units are written but not read back (ic = file / restart need dimensionless = 1)");
+  // Simulation::ConvertToCodeUnits (SimulationIO.hpp:2508-2560) for a snapshot that was read: every array and the header's
+  // times by the INPUT scale, which - the unit ids of the file are noted but SetupUnits has already run with the output units
+  // as input units (SimUnits.cpp:838-862) - is the output scale
+  auto to_code_units = [&](Snapshot &q) {
+    if (simunits.dimensionless) return;
+    for (double &x : q.r) x /= simunits.r.outscale;
+    for (double &x : q.v) x /= simunits.v.outscale;
+    for (double &x : q.m) x /= simunits.m.outscale;
+    for (double &x : q.h) x /= simunits.r.outscale;
+    for (double &x : q.u) x /= simunits.u.outscale;
+    for (double &x : q.rho) x /= simunits.rho.outscale;
+    q.t /= simunits.t.outscale; q.tsnaplast /= simunits.t.outscale; q.tlitesnaplast /= simunits.t.outscale; q.mmean /= simunits.m.outscale;
+  };
   if (restart) {
     // SimulationIC.hpp:64-82: a restart re-reads the last regular snapshot, whose name and format Output() left in
     // <run_id>.restart; no such file -> an ordinary start.  What the readers restore for a restart (SimulationIO.hpp:677-687,
@@ -279,6 +290,7 @@ void SphSimulation::GenerateIC()
       if (ip["ntreebuildstep"] > 1 || ip["ntreestockstep"] > 1) throw GandalfError("restart with ntreebuildstep / ntreestockstep > 1 is not built");
       Snapshot snap;
       ReadSnapshotFile(file, form, snap);
+      to_code_units(snap);
       if (snap.ndim != ndim) throw GandalfError("Incorrect no. of dimensions in file");
       sph->AllocateMemory(std::max(snap.N, 1));
       HydroParticles &q = sph->part;
@@ -302,6 +314,7 @@ void SphSimulation::GenerateIC()
     Snapshot snap;
     const std::string form = sp["in_file_form"];
     ReadSnapshotFile(sp["in_file"], form, snap);
+    to_code_units(snap);
     if (snap.ndim != ndim) throw GandalfError("Incorrect no. of dimensions in file");
     sph->AllocateMemory(std::max(snap.N, 1));
     HydroParticles &q = sph->part;

@@ -293,6 +293,11 @@ def test_reference_bossbodenheimer_settings_in_physical_units(tmp_path):
         ref = g["snap_" + k]
         assert np.max(np.abs(f[k][:64] - ref)) <= 1e-10*np.max(np.abs(ref)), k
     assert abs(f["mmean"] - g["snap_t_mmean_hfac"][1]) <= 1e-13*f["mmean"]
+    # ... and back: a run that starts from that file (ic = file) divides by the same scales (Simulation::ConvertToCodeUnits)
+    again = Simulation(os.path.join(PARAMS, "bb_units_1600.dat"), ic="file", in_file=out, in_file_form="su")
+    ic2 = again.generate_ic()
+    assert np.max(np.abs(ic2["r"] - g["setup_r"])) < 1e-14*np.abs(g["setup_r"]).max() and np.max(np.abs(ic2["m"]/g["setup_m"] - 1)) < 1e-14
+    assert np.max(np.abs(ic2["u"]/g["setup_u"] - 1)) < 1e-12 and np.max(np.abs(ic2["v"] - g["setup_v"])) < 1e-13*np.abs(g["setup_v"]).max()
     sim.main_loop(int(g["nsteps"][0]))
     assert abs(sim.t - g["final_t_timestep"][0]) < 1e-11*sim.t
     for k in ("level", "nstep", "nlast"):
