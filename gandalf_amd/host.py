@@ -29,6 +29,7 @@ HOST_SYMBOLS = {
     "gah_set_restart": (C.c_int, [_H, C.c_int]),
     "gah_set_output": (C.c_int, [_H, C.c_int]),
     "gah_nsteps": (C.c_int, [_H]),
+    "gah_unit_outscale": (C.c_double, [_H, C.c_char_p]),
     "gah_noutsnap": (C.c_int, [_H]),
     "gah_upload_ic": (C.c_int, [_H]),
     "gah_setup": (C.c_int, [_H]),
@@ -211,6 +212,10 @@ class Simulation:
     def set_restart(self, on=True):
         """continue from the snapshot named in <run_id>.restart (the reference's `gandalf -r`); before setup()"""
         self.lib.gah_set_restart(self.h, 1 if on else 0)
+
+    def unit_outscale(self, quantity):
+        """SimUnits: x[code units] = x[output units] / scale, for r, m, t, v, a, rho, u, temp, angvel (1 when dimensionless)"""
+        return self.lib.gah_unit_outscale(self.h, quantity.encode())
 
     @property
     def Nsteps(self):

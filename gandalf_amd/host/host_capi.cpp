@@ -81,6 +81,16 @@ int gah_main_loop(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->MainLoop(nsteps))
 int gah_run(gah_sim *s, int nsteps) { GAH_TRY(s, s->sim->Run(nsteps)) }
 int gah_set_restart(gah_sim *s, int on) { s->restart = on != 0; if (s->sim) s->sim->restart = s->restart; return 0; }
 int gah_set_output(gah_sim *s, int on) { s->output = on != 0; if (s->sim) s->sim->write_output = s->output; return 0; }
+// output scale of a quantity (r, m, t, v, a, rho, u, temp, angvel) after gah_generate_ic / gah_setup: x[code] = x[output unit]/scale
+double gah_unit_outscale(gah_sim *s, const char *q)
+{
+  if (!s->sim) return 0.0;
+  const SimUnits &u = s->sim->simunits;
+  const std::string k(q);
+  const SimUnit *p = k == "r" ? &u.r : k == "m" ? &u.m : k == "t" ? &u.t : k == "v" ? &u.v : k == "a" ? &u.a : k == "rho" ? &u.rho : k == "u" ? &u.u :
+                     k == "temp" ? &u.temp : k == "angvel" ? &u.angvel : nullptr;
+  return p ? p->outscale : 0.0;
+}
 int gah_nsteps(gah_sim *s) { return s->sim ? s->sim->Nsteps : 0; }
 int gah_noutsnap(gah_sim *s) { return s->sim ? s->sim->Noutsnap : 0; }
 double gah_time(gah_sim *s) { return s->sim->t; }

@@ -77,3 +77,32 @@ def test_ic_generators_bitwise(case):
     assert np.array_equal(ic["u"], g["in_u"])
     assert np.array_equal(ic["v"], g["in_v"])
     assert ic["initial_h_provided"] == (case != "plummer_4k")
+
+
+def test_physical_units_scale_factors():
+    """SimUnits::SetupUnits restated in the host shell (SimUnits.cpp:825-1118): code units are pc and m_sun with G = 1 for the
+    settings of the reference's bossbodenheimer.dat; every other scale follows from them - checked against the formulas
+    evaluated here with the constants of Constants.h:34-51 - and the bb cloud the host generates carries them (angular
+    velocity in rad/s, temperature in K -> u in code units)."""
+    import numpy as np
+    from gandalf_amd.host import Simulation
+    here = os.path.dirname(os.path.abspath(__file__))
+    sim = Simulation(os.path.join(here, "params", "bb_units_1600.dat"), Nhydro=1000)
+    ic = sim.generate_ic()
+    pc, msun, myr, G, mH, kB = 3.08568025E16, 1.98892E30, 3.1556952E13, 6.67384E-11, 1.66054E-27, 1.3806503E-23
+    t_unit = pc**1.5/np.sqrt(msun*G)                       # seconds per code time
+    want = {"r": 1.0, "m": 1.0, "t": t_unit/myr, "v": pc/t_unit/1000.0, "rho": msun/pc**3/1000.0, "u": (pc/t_unit)**2,
+            "temp": mH*(pc/t_unit)**2/kB, "angvel": 1.0/t_unit}
+    for k, v in want.items():
+        assert abs(sim.unit_outscale(k) - v) <= 1e-14*abs(v), (k, sim.unit_outscale(k), v)
+    assert abs(sim.unit_outscale("t") - 14.9) < 0.1        # a code time is ~15 Myr
+    # the cloud: mass 1 m_sun, u = temp0/(gamma - 1)/mu_bar with temp0 = 10 K in code units, solid-body rotation at 1.6e-12 rad/s
+    assert abs(ic["m"].sum() - 1.0) < 1e-12
+    u0 = 10.0/want["temp"]/(5.0/3.0 - 1.0)/2.35
+    assert np.max(np.abs(ic["u"]/u0 - 1)) < 1e-12
+    r, v = ic["r"], ic["v"]
+    w = 1.6e-12*t_unit                                     # code units; v = w x r about z in the frame before the COM shift
+    vz = v[:, 2]
+    assert np.max(np.abs(vz)) < 1e-12*np.abs(v).max()
+    dv = v - v.mean(axis=0); dr = r - r.mean(axis=0)
+    assert np.max(np.abs(dv[:, 0] + w*dr[:, 1])) < 1e-9*np.abs(v).max() and np.max(np.abs(dv[:, 1] - w*dr[:, 0])) < 1e-9*np.abs(v).max()
