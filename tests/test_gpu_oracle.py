@@ -306,6 +306,41 @@ def test_reference_bossbodenheimer_settings_in_physical_units(tmp_path):
     assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-8 and np.max(np.abs(dev.download("u")/g["final_u"] - 1)) < 1e-8
 
 
+def test_reference_examples_bossbodenheimer_settings(tmp_path):
+    """tests/params/bb_units_ex_1600.dat = the settings of the reference's examples/bossbodenheimer.dat: physical units, 1 600
+    particles, leaves of 8 particles (Nleafmax = 8), global timestep, sinks, formatted SEREN files.  Setup + 20 steps against
+    the reference's run of that file; the sf snapshot of the setup state against the file the reference wrote
+    (tests/golden/snapshots/bb_units_ex.sf): header, unit ids and array descriptors line for line, the numbers to the 11
+    digits the format keeps."""
+    from gandalf_amd.host import Simulation, read_snapshot
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "bb_units_ex_1600_steps.npz"))
+    sim = Simulation(os.path.join(PARAMS, "bb_units_ex_1600.dat"))
+    sim.setup()
+    dev = sim.device()
+    assert dev.N == int(g["Nhydro"][0]) and abs(sim.timestep - g["setup_t_timestep"][1]) < 1e-10*sim.timestep
+    assert np.max(np.abs(dev.download("h")/g["setup_h"] - 1)) < 1e-11 and np.max(np.abs(dev.download("rho")/g["setup_rho"] - 1)) < 1e-11
+    a, ar = dev.download("a"), g["setup_a"]
+    assert np.max(np.linalg.norm(a - ar, axis=1)/np.maximum(np.linalg.norm(ar, axis=1), np.linalg.norm(ar, axis=1).mean())) < 1e-9
+    out = str(tmp_path/"bbex.sf")
+    sim.write_snapshot(out, "sf")
+    ours, ref = open(out).read().splitlines(), open(os.path.join(here, "golden", "snapshots", "bb_units_ex.sf")).read().splitlines()
+    nhead = 5 + 200 + 21 + 7 + 7
+    assert len(ours) == len(ref) == nhead + 7*dev.N
+    for i in range(nhead):
+        if ours[i] != ref[i]:                                  # (a header real may differ in its last printed digit: mmean)
+            assert abs(float(ours[i]) - float(ref[i])) <= 1e-9*abs(float(ref[i])), (i, ours[i], ref[i])
+    assert ours[205:226] == ref[205:226] and ours[226:240] == ref[226:240]         # unit ids; array ids and descriptors
+    f, fr = read_snapshot(out, "sf"), read_snapshot(os.path.join(here, "golden", "snapshots", "bb_units_ex.sf"), "sf")
+    for k in ("r", "v", "m", "h", "rho", "u"):
+        assert np.max(np.abs(f[k] - fr[k])) <= 1e-9*np.max(np.abs(fr[k])), k
+    assert sum(x != y for x, y in zip(ours, ref)) < 0.01*len(ref)              # nearly every line is the same text
+    sim.main_loop(int(g["nsteps"][0]))
+    assert abs(sim.t - g["final_t_timestep"][0]) < 1e-11*sim.t
+    assert np.max(np.abs(dev.download("r") - g["final_r"])) < 1e-10*np.abs(g["final_r"]).max()
+    assert np.max(np.abs(dev.download("rho")/g["final_rho"] - 1)) < 1e-8 and np.max(np.abs(dev.download("u")/g["final_u"] - 1)) < 1e-8
+
+
 def test_regular_snapshots_and_restart(tmp_path, monkeypatch):
     """SimulationBase::Run with its regular snapshots, then a restart (Simulation.cpp:382-600, SimulationIC.hpp:64-82): the 1-D
     shock tube with dt_snap = 0.003.  (1) 12 steps from the IC: the snapshot files <run_id>.su.NNNNN the reference wrote, by
